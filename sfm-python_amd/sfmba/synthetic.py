@@ -1,0 +1,122 @@
+"""Synthetic bundle-adjustment problems (SURVEY.md §8d generator).
+
+The reference ships no BA inputs (its SceauxCastle submodule is an empty directory), so every
+configuration of BASELINE.json is represented by this seeded generator.  It reproduces the *layout*
+the reference's caller hands to ``least_squares`` (``/root/reference/sfm_lite/sfm.py:248-262``):
+
+* observations in point-major order, as ``Graph.pt3ds_pt2ds`` yields them
+  (``/root/reference/sfm_lite/graph.py:186-191``);
+* integer pixel observations truncated toward zero (``graph.py:112-113``), dtype int64;
+* ``x0 = [C x (rotvec, T) | P x (X, Y, Z)]`` float64 (``sfm.py:257``);
+* the residual model ``pi(K R(w) (X - T)) - uv`` of
+  ``/root/reference/sfm_lite/bundle_adjustment.py:20-42``.
+
+Nothing here touches the GPU or the oracle: the truth projection is computed with a small local
+vectorised Rodrigues so that the generator has no dependency on test infrastructure.
+"""
+from __future__ import annotations
+
+import dataclasses
+
+import numpy as np
+
+# SceauxCastle intrinsics, the only literal the reference holds for that dataset
+# (/root/reference/cv2_lite/solve_pnp.py:81-83, recover_pose.py:96-98).
+K_SCEAUX = np.array([[2905.88, 0.0, 1416.0],
+                     [0.0, 2905.88, 1064.0],
+                     [0.0, 0.0, 1.0]], dtype=np.float64)
+
+# BASELINE.json configs (C, P, N); cfg1 and cfg2 share the SceauxCastle-scale size.
+CONFIGS = {
+    "cfg2": (11, 3000, 10000),
+    "cfg3": (200, 20000, 200000),
+    "cfg4": (1000, 100000, 1000000),
+    "cfg5": (5000, 1000000, 10000000),
+}
+
+
+@dataclasses.dataclass
+class BAProblem:
+    """Arguments of the reference's least_squares call, plus the generating truth."""
+    n_cameras: int
+    n_points: int
+    camera_indices: np.ndarray   # (N,) int64
+    point_indices: np.ndarray    # (N,) int64, non-decreasing (point-major)
+    points_2d: np.ndarray        # (N, 2) int64 pixels
+    K: np.ndarray                # (3, 3) float64
+    x0: np.ndarray               # (6C + 3P,) float64
+    x_true: np.ndarray           # (6C + 3P,) float64
+
+    @property
+    def n_obs(self) -> int:
+        return int(self.camera_indices.shape[0])
+
+    @property
+    def args(self):
+        """The ``args=`` tuple of sfm.py:268."""
+        return (self.n_cameras, self.n_points, self.camera_indices, self.point_indices,
+                self.points_2d, self.K)
+
+
+def _rodrigues_batch(w: np.ndarray) -> np.ndarray:
+    """(C,3) rotation vectors -> (C,3,3) matrices (closed-form Rodrigues, series near 0)."""
+    th2 = np.einsum("ij,ij->i", w, w)
+    th = np.sqrt(th2)
+    small = th < 1e-4
+    ths = np.where(small, 1.0, th)
+    a = np.where(small, 1.0 - th2 / 6.0, np.sin(ths) / ths)
+    half = 0.5 * ths
+    b = np.where(small, 0.5 - th2 / 24.0, 0.5 * (np.sin(half) / half) ** 2)
+    Wx = np.zeros((w.shape[0], 3, 3))
+    Wx[:, 0, 1], Wx[:, 0, 2] = -w[:, 2], w[:, 1]
+    Wx[:, 1, 0], Wx[:, 1, 2] = w[:, 2], -w[:, 0]
+    Wx[:, 2, 0], Wx[:, 2, 1] = -w[:, 1], w[:, 0]
+    return np.eye(3)[None] + a[:, None, None] * Wx + b[:, None, None] * (Wx @ Wx)
+
+
+def make_problem(n_cameras: int, n_points: int, n_obs: int, seed: int = 0,
+                 K: np.ndarray | None = None, pixel_noise: float = 0.5,
+                 x0_noise: float = 0.01, point_offset: int = 0,
+                 camera_seed: int | None = None) -> BAProblem:
+    """SURVEY.md §8d generator.
+
+    ``camera_seed`` (default: ``seed``) seeds the cameras separately so that several ranks can
+    generate *different* points/observations of ONE problem that shares its cameras
+    (multi-GPU weak scaling: each rank calls this with its own ``seed`` and a common
+    ``camera_seed``).  ``point_offset`` is unused by the arithmetic and only recorded by callers.
+    """
+    if n_obs < n_points:
+        raise ValueError("every point needs at least one observation (n_obs >= n_points)")
+    K = K_SCEAUX.copy() if K is None else np.asarray(K, dtype=np.float64)
+    rng = np.random.default_rng(seed)
+    crng = rng if camera_seed is None else np.random.default_rng(camera_seed)
+    cam_w = crng.normal(0.0, 0.1, (n_cameras, 3))
+    cam_T = crng.normal(0.0, 0.5, (n_cameras, 3))
+    pts = rng.normal(0.0, 1.0, (n_points, 3)) + np.array([0.0, 0.0, 10.0])
+    pt_idx = np.concatenate([np.arange(n_points, dtype=np.int64),
+                             rng.integers(0, n_points, n_obs - n_points, dtype=np.int64)])
+    cam_idx = rng.integers(0, n_cameras, n_obs, dtype=np.int64)
+    order = np.argsort(pt_idx, kind="stable")
+    pt_idx, cam_idx = pt_idx[order], cam_idx[order]
+
+    R = _rodrigues_batch(cam_w)
+    v = pts[pt_idx] - cam_T[cam_idx]
+    q = np.einsum("nij,nj->ni", R[cam_idx], v)
+    p = q @ K.T
+    proj = p[:, :2] / p[:, 2:3]
+    uv = np.trunc(proj + rng.normal(0.0, pixel_noise, proj.shape)).astype(np.int64)
+
+    x_true = np.concatenate([np.hstack([cam_w, cam_T]).ravel(), pts.ravel()])
+    if camera_seed is None:
+        x0 = x_true + rng.normal(0.0, x0_noise, x_true.shape)
+    else:
+        x0 = x_true.copy()
+        x0[:6 * n_cameras] += np.random.default_rng(camera_seed + 7919).normal(
+            0.0, x0_noise, 6 * n_cameras)
+        x0[6 * n_cameras:] += rng.normal(0.0, x0_noise, 3 * n_points)
+    return BAProblem(n_cameras, n_points, cam_idx, pt_idx, uv, K, x0, x_true)
+
+
+def make_config(name: str, seed: int = 0) -> BAProblem:
+    C, P, N = CONFIGS[name]
+    return make_problem(C, P, N, seed=seed)

@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own hot-path module in the build container.
+
+Runs only where /root/reference exists (never on the GPU box).  The reference package itself cannot be
+imported (``sfm_lite/__init__.py`` pulls in cv2, which is not installed), but its BA module
+``/root/reference/sfm_lite/bundle_adjustment.py`` depends only on numpy + scipy and is loaded by file
+path.  Outputs are data only: inputs + the reference's outputs (+ scipy's, driven with the exact kwargs
+of /root/reference/sfm_lite/sfm.py:266-268).  No reference source is written anywhere.
+
+    python tools/gen_golden.py            # fast fixtures (seconds)
+    python tools/gen_golden.py --cfg2     # also the ~7 min scipy run on the SceauxCastle-scale synthetic
+"""
+from __future__ import annotations
+
+import argparse
+import importlib.util
+import io
+import json
+import os
+import re
+import sys
+import time
+from contextlib import redirect_stdout
+
+import numpy as np
+from scipy.optimize import least_squares
+from scipy.optimize._numdiff import approx_derivative
+from scipy.spatial.transform import Rotation as Rot
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "sfm-python_amd"))
+from sfmba.synthetic import make_problem  # noqa: E402
+
+REF_BA = "/root/reference/sfm_lite/bundle_adjustment.py"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def load_ref():
+    spec = importlib.util.spec_from_file_location("ref_ba", REF_BA)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def residual_cases(ba):
+    """Inputs -> reference compute_residuals outputs."""
+    out = {}
+    n = 0
+
+    def add(tag, x, C, P, ci, pi, uv, K):
+        nonlocal n
+        r = ba.compute_residuals(np.asarray(x, dtype=np.float64), C, P, ci, pi, uv, K)
+        pre = f"c{n:02d}_"
+        out[pre + "tag"] = np.array(tag)
+        out[pre + "x"] = np.asarray(x, dtype=np.float64)
+        out[pre + "dims"] = np.array([C, P, len(ci)], dtype=np.int64)
+        out[pre + "ci"] = np.asarray(ci, dtype=np.int64)
+        out[pre + "pi"] = np.asarray(pi, dtype=np.int64)
+        out[pre + "uv"] = np.asarray(uv)
+        out[pre + "K"] = np.asarray(K, dtype=np.float64)
+        out[pre + "r"] = r
+        n += 1
+
+    for seed in range(3):
+        pb = make_problem(3, 8, 20, seed=seed)
+        add(f"rand_3_8_20_s{seed}", pb.x0, *pb.args)
+        pb = make_problem(4, 30, 120, seed=10 + seed)
+        add(f"rand_4_30_120_s{seed}", pb.x0, *pb.args)
+    # rotation magnitudes across scipy's Taylor switch (theta <= 1e-3) and large angles
+    pb = make_problem(11, 12, 44, seed=5)
+    mags = [0.0, 1e-12, 1e-8, 1e-4, 1e-3, 1.1e-3, 0.1, 1.0, 3.0, np.pi, 5.0]
+    rng = np.random.default_rng(99)
+    x = pb.x0.copy()
+    for c, m in enumerate(mags):
+        u = rng.normal(size=3)
+        u /= np.linalg.norm(u)
+        x[6 * c:6 * c + 3] = m * u
+    add("theta_sweep", x, *pb.args)
+    # K with skew and unequal focal lengths
+    Ksk = np.array([[1200.5, 3.25, 640.0], [0.0, 1100.25, 360.5], [0.0, 0.0, 1.0]])
+    pb = make_problem(4, 30, 120, seed=21, K=Ksk)
+    add("skewK", pb.x0, *pb.args)
+    # a fully general 3x3 "K" (utils.py:34 only asserts the shape)
+    Kg = np.array([[900.0, 2.0, 500.0], [1.5, 950.0, 400.0], [1e-3, -2e-3, 1.0]])
+    pb = make_problem(4, 30, 120, seed=22, K=Kg)
+    add("generalK", pb.x0, *pb.args)
+    # float observations instead of int64
+    pb = make_problem(4, 30, 120, seed=23)
+    add("float_uv", pb.x0, pb.n_cameras, pb.n_points, pb.camera_indices, pb.point_indices,
+        pb.points_2d.astype(np.float64) + 0.25, pb.K)
+    # duplicated (camera, point) pairs (track merging, graph.py:86)
+    pb = make_problem(3, 8, 20, seed=24)
+    ci = pb.camera_indices.copy()
+    ci[1] = ci[0]
+    pi = pb.point_indices.copy()
+    pi[1] = pi[0]
+    add("dup_pairs", pb.x0, 3, 8, ci, pi, pb.points_2d, pb.K)
+    # single observation
+    pb = make_problem(1, 1, 1, seed=25)
+    add("single", pb.x0, *pb.args)
+    out["n_cases"] = np.array(n)
+    return out
+
+
+def sparsity_cases(ba):
+    """A3: CSR structure of create_sparsity_matrix, with and without fixed cameras."""
+    pb = make_problem(4, 10, 30, seed=3)
+    out = {"dims": np.array([4, 10, 30]), "ci": pb.camera_indices, "pi": pb.point_indices}
+    for tag, fixed in (("free", ()), ("fixed", (0, 2))):
+        M = ba.create_sparsity_matrix(4, 10, 30, pb.camera_indices, pb.point_indices,
+                                      fixed_camera_indices=fixed).tocsr()
+        M.sort_indices()
+        out[tag + "_indptr"] = M.indptr.astype(np.int64)
+        out[tag + "_indices"] = M.indices.astype(np.int64)
+        out[tag + "_data"] = M.data.astype(np.int64)
+        out[tag + "_shape"] = np.array(M.shape)
+        out[tag + "_fixed"] = np.array(fixed, dtype=np.int64)
+    return out
+
+
+def jacobian_cases(ba):
+    """A6: scipy finite differences of the REFERENCE residual (3-point and the 2-point scheme scipy
+    actually uses with jac_sparsity)."""
+    out = {}
+    for k, (C, P, N, seed) in enumerate([(3, 8, 20, 0), (4, 30, 120, 11)]):
+        pb = make_problem(C, P, N, seed=seed)
+        fun = lambda x: ba.compute_residuals(x, *pb.args)  # noqa: E731
+        J3 = approx_derivative(fun, pb.x0, method="3-point")
+        S = ba.create_sparsity_matrix(C, P, N, pb.camera_indices, pb.point_indices)
+        J2 = approx_derivative(fun, pb.x0, method="2-point", sparsity=S).toarray()
+        pre = f"j{k}_"
+        out[pre + "dims"] = np.array([C, P, N])
+        out[pre + "seed"] = np.array(seed)
+        out[pre + "x"] = pb.x0
+        out[pre + "J3"] = J3
+        out[pre + "J2"] = J2
+    out["n_cases"] = np.array(2)
+    return out
+
+
+def lsq_tiny(ba):
+    """A5-A9: full scipy runs with the kwargs of sfm.py:266-268 on tiny problems."""
+    out = {}
+    for k, (C, P, N, seed) in enumerate([(3, 8, 40, 0), (4, 30, 120, 11), (6, 60, 400, 12)]):
+        pb = make_problem(C, P, N, seed=seed)
+        S = ba.create_sparsity_matrix(C, P, N, pb.camera_indices, pb.point_indices)
+        res = least_squares(ba.compute_residuals, pb.x0, jac_sparsity=S, verbose=0, x_scale="jac",
+                            ftol=1e-10, method="trf", args=pb.args)
+        pre = f"l{k}_"
+        out[pre + "dims"] = np.array([C, P, N])
+        out[pre + "seed"] = np.array(seed)
+        out[pre + "x0"] = pb.x0
+        out[pre + "x"] = res.x
+        out[pre + "fun"] = res.fun
+        out[pre + "summary"] = np.array([res.status, res.nfev, res.njev, res.cost,
+                                         np.sqrt(np.mean(res.fun ** 2)), res.optimality])
+        print(f"  lsq tiny {C}/{P}/{N}: status {res.status} nfev {res.nfev} cost {res.cost:.6f}")
+    out["n_cases"] = np.array(3)
+    return out
+
+
+def pack_cases():
+    """A4: rotation log/exp per camera as scipy does it at sfm.py:255,277."""
+    rng = np.random.default_rng(7)
+    w = rng.normal(0, 1.0, (12, 3))
+    w[0] = 0.0
+    w[1] *= 1e-9
+    w[2] = w[2] / np.linalg.norm(w[2]) * (np.pi - 1e-6)     # near pi
+    w[3] = w[3] / np.linalg.norm(w[3]) * 3.0
+    R = Rot.from_rotvec(w).as_matrix()
+    back = Rot.from_matrix(R).as_rotvec()
+    T = rng.normal(0, 2.0, (12, 3))
+    H = np.tile(np.eye(4), (12, 1, 1))
+    H[:, :3, :3] = R
+    H[:, :3, 3] = T
+    return {"w": w, "R": R, "rotvec_from_matrix": back, "H": H}
+
+
+def lsq_cfg2(ba):
+    """The SceauxCastle-scale synthetic (11/3000/10000): full scipy run, ~6-7 min single thread."""
+    pb = make_problem(11, 3000, 10000, seed=0)
+    t = time.time()
+    S = ba.create_sparsity_matrix(11, 3000, 10000, pb.camera_indices, pb.point_indices)
+    t_sp = time.time() - t
+    buf = io.StringIO()
+    t = time.time()
+    with redirect_stdout(buf):
+        res = least_squares(ba.compute_residuals, pb.x0, jac_sparsity=S, verbose=2, x_scale="jac",
+                            ftol=1e-10, method="trf", args=pb.args)
+    t_lsq = time.time() - t
+    rows = []
+    for line in buf.getvalue().splitlines():
+        m = re.match(r"\s*(\d+)\s+(\d+)\s+([0-9.e+-]+)\s*([0-9.e+-]+)?\s*([0-9.e+-]+)?\s*([0-9.e+-]+)?", line)
+        if m:
+            rows.append([float(v) if v else None for v in m.groups()])
+    summary = dict(
+        config=dict(n_cameras=11, n_points=3000, n_obs=10000, seed=0, ftol=1e-10),
+        scipy_version=__import__("scipy").__version__, numpy_version=np.__version__,
+        status=int(res.status), nfev=int(res.nfev), njev=int(res.njev), cost=float(res.cost),
+        rmse=float(np.sqrt(np.mean(res.fun ** 2))), optimality=float(res.optimality),
+        rmse0=float(np.sqrt(np.mean(ba.compute_residuals(pb.x0, *pb.args) ** 2))),
+        seconds_least_squares=t_lsq, seconds_create_sparsity=t_sp,
+        iterations_per_sec=res.njev / t_lsq, host="build container, 1 thread",
+        table_columns=["iteration", "nfev", "cost", "cost_reduction", "step_norm", "optimality"],
+        table=rows)
+    with open(os.path.join(OUT, "scipy_cfg2_run.json"), "w") as f:
+        json.dump(summary, f, indent=1)
+    np.savez_compressed(os.path.join(OUT, "scipy_cfg2_x.npz"), x=res.x, fun=res.fun)
+    print(f"  cfg2: {res.njev} iterations in {t_lsq:.1f}s, rmse {summary['rmse']:.9f}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cfg2", action="store_true")
+    a = ap.parse_args()
+    if not os.path.exists(REF_BA):
+        sys.exit("reference not present: fixtures can only be generated in the build container")
+    os.makedirs(OUT, exist_ok=True)
+    ba = load_ref()
+    np.savez_compressed(os.path.join(OUT, "residual_cases.npz"), **residual_cases(ba))
+    np.savez_compressed(os.path.join(OUT, "sparsity_cases.npz"), **sparsity_cases(ba))
+    np.savez_compressed(os.path.join(OUT, "jacobian_fd_cases.npz"), **jacobian_cases(ba))
+    np.savez_compressed(os.path.join(OUT, "lsq_tiny_cases.npz"), **lsq_tiny(ba))
+    np.savez_compressed(os.path.join(OUT, "pack_cases.npz"), **pack_cases())
+    print("fast fixtures written to", OUT)
+    if a.cfg2:
+        lsq_cfg2(ba)
+
+
+if __name__ == "__main__":
+    main()
