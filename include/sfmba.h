@@ -1,0 +1,139 @@
+/*
+ * sfmba.h -- C-ABI of libsfmba.so, the MI355X (gfx950) bundle-adjustment back end.
+ *
+ * Drop-in boundary: the one call the reference makes into its optimiser,
+ *
+ *     result = least_squares(compute_residuals, x0, jac_sparsity=..., verbose=..., x_scale='jac',
+ *                            ftol=tol, method='trf',
+ *                            args=(n_cam, n_points, camera_indices, pt_indices, pt2ds, K))
+ *                                                     -- /root/reference/sfm_lite/sfm.py:266-268
+ *
+ * plus the model function it hands over, compute_residuals
+ *                                                     -- /root/reference/sfm_lite/bundle_adjustment.py:35-42
+ *
+ * The reference is pure Python, so the "FFI" a maintainer adds is a ctypes binding of exactly these
+ * entry points (shown in INTEGRATION.md; shipped as sfm-python_amd/sfmba/_capi.py).  Plain C types
+ * only: caller-owned, C-contiguous HOST arrays are borrowed for the duration of a call and copied to
+ * HBM inside it; nothing returned is library-owned except the handle and the error string.
+ *
+ * Return codes: 0 OK; -1 bad argument / shape / index out of range; -2 residuals not finite at x0
+ * (scipy raises ValueError there, SCIPY/optimize/_lsq/least_squares.py:844-845); -3 HIP failure;
+ * -4 out of memory; -5 collective (all-reduce callback) failure.  The solver outcome is NOT an error:
+ * it is sfmba_result.status, scipy's 0..4 (SCIPY/optimize/_lsq/least_squares.py:18-25).
+ *
+ * Threading: one handle is not thread-safe; distinct handles are independent; every entry point
+ * selects the handle's device on entry, so it may be called from any thread (the reference's GUI runs
+ * BA on a worker thread, /root/reference/app.py:80-85).
+ */
+#ifndef SFMBA_H
+#define SFMBA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sfmba_handle sfmba_handle;
+
+/* Options of sfmba_solve.  Fill with sfmba_default_options() first.
+ * ftol/xtol/gtol/max_nfev/verbose mirror the least_squares kwargs of sfm.py:266-268 (xtol, gtol,
+ * max_nfev at scipy's defaults 1e-8, 1e-8, 100*n when the caller passes none). */
+typedef struct sfmba_options {
+    double  ftol;          /* scipy ftol; reference passes ba_tol (1e-10)                         */
+    double  xtol;          /* 1e-8                                                               */
+    double  gtol;          /* 1e-8                                                               */
+    int64_t max_nfev;      /* <=0: 100 * n  (SCIPY trf.py:437-438)                               */
+    int32_t verbose;       /* 0 silent, 1 summary (printed by the host shim), 2 iteration table  */
+    int32_t max_iter;      /* <=0: unlimited; otherwise stop after this many outer iterations    */
+    double  pcg_tol;       /* relative preconditioned-residual tolerance of the Schur PCG (1e-6,
+                              the atol/btol scipy gives LSMR, SCIPY lsmr.py:29)                   */
+    int32_t pcg_max_iter;  /* <=0: 2 * 6 * n_cameras                                             */
+    int32_t pcg_check_every; /* host polls the device-side convergence flag every k iterations   */
+    double  reg_min;       /* floor of the Levenberg-Marquardt term (1e-10), see DESIGN.md        */
+    int32_t profile;       /* 1: bracket every residual+Jacobian launch with HIP events          */
+    int32_t reserved;
+} sfmba_options;
+
+typedef struct sfmba_result {
+    double  cost;          /* 0.5 |f|^2 at the returned x                                        */
+    double  cost0;         /* 0.5 |f|^2 at x0                                                    */
+    double  optimality;    /* |J^T f|_inf                                                        */
+    double  rmse;          /* sqrt(2 cost / (2 N_total))                                         */
+    double  rmse0;
+    int64_t nfev;
+    int64_t njev;
+    int64_t iterations;    /* outer (trust-region) iterations                                    */
+    int64_t pcg_iterations;/* total inner PCG iterations                                         */
+    int32_t status;        /* 0 max_nfev/max_iter, 1 gtol, 2 ftol, 3 xtol, 4 ftol+xtol           */
+    int32_t reserved;
+    double  seconds_total; /* wall time of the call, host clock, H2D/D2H included                */
+    double  seconds_device;/* wall time between upload and download                              */
+    double  resjac_avg_us; /* HIP-event average of the residual+Jacobian kernel (profile=1)      */
+    int64_t resjac_launches;
+    double  last_step_norm;
+    double  last_reg;
+} sfmba_result;
+
+/* All-reduce hook for observation-sharded problems (one process per GPU).  `dev_ptr` points into the
+ * exchange arena registered with sfmba_set_exchange; `count` doubles are reduced in place over all
+ * ranks on the handle's stream; op 0 = sum, 1 = max.  Return 0 on success. */
+typedef int (*sfmba_allreduce_fn)(void* ctx, void* dev_ptr, int64_t count, int32_t op);
+
+/* ---- lifetime ---------------------------------------------------------------------------- */
+int  sfmba_create(sfmba_handle** out, int device_id);
+void sfmba_destroy(sfmba_handle* h);
+const char* sfmba_last_error(const sfmba_handle* h);     /* valid until the next call on h */
+void sfmba_default_options(sfmba_options* opt);
+/* Run every kernel of `h` on this hipStream_t (default: a stream the handle owns). */
+int  sfmba_set_stream(sfmba_handle* h, void* hip_stream);
+
+/* ---- problem (the args= tuple of sfm.py:268) ---------------------------------------------- */
+/* camera_indices, point_indices: (N) int64; points_2d: (N,2) float64 (caller converts the
+ * reference's int64 pixels, bundle_adjustment.py:41 promotes them the same way); K: 3x3 row-major.
+ * Indices are range-checked here (the reference's fancy indexing would raise IndexError,
+ * bundle_adjustment.py:40).  Any observation order is accepted; point-major (what
+ * Graph.pt3ds_pt2ds produces, graph.py:186-191) is the fast path. */
+int  sfmba_set_problem(sfmba_handle* h, int64_t n_cameras, int64_t n_points, int64_t n_obs,
+                       const int64_t* camera_indices, const int64_t* point_indices,
+                       const double* points_2d, const double* K);
+
+/* Observation sharding: this handle holds the local shard (its own points + their observations,
+ * all cameras replicated); n_obs_total counts all shards.  `arena` is device memory of at least
+ * sfmba_exchange_doubles(n_cameras) doubles that `fn` can all-reduce (e.g. a torch tensor).
+ * Pass fn = NULL to return to single-process operation. */
+int64_t sfmba_exchange_doubles(int64_t n_cameras);
+int  sfmba_set_exchange(sfmba_handle* h, void* arena, int64_t arena_doubles,
+                        sfmba_allreduce_fn fn, void* ctx, int64_t n_obs_total);
+
+/* ---- compute_residuals (bundle_adjustment.py:35-42) ----------------------------------------- */
+/* x: (6C+3P) float64 -> r_out: (2N) float64, interleaved x,y in the caller's observation order. */
+int  sfmba_residuals(sfmba_handle* h, const double* x, double* r_out);
+
+/* Residual and analytic Jacobian blocks (replaces scipy's sparse 2-point finite differences,
+ * SCIPY/optimize/_numdiff.py:628-705).  Jc: (N,2,6) d r/d(rotvec,T); Jp: (N,2,3) d r/d X. */
+int  sfmba_residual_jacobian(sfmba_handle* h, const double* x, double* r_out, double* Jc_out,
+                             double* Jp_out);
+
+/* ---- least_squares(method='trf', x_scale='jac') (sfm.py:266-268) ---------------------------- */
+/* x_inout: x0 on entry, result.x on success (untouched on failure). */
+int  sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt, sfmba_result* out);
+/* After a successful sfmba_solve: result.fun (2N) and result.grad (6C+3P); either may be NULL. */
+int  sfmba_get_fun_grad(sfmba_handle* h, double* fun_out, double* grad_out);
+
+/* ---- measurement / test entry points -------------------------------------------------------- */
+/* `reps` back-to-back launches of one kernel at x, bracketed by HIP events on the handle's stream.
+ * which: 0 residual+Jacobian sweep, 1 residual-only sweep, 2 normal-equation blocks,
+ *        3 one implicit Schur mat-vec.  avg_us: average launch duration. */
+int  sfmba_time_kernel(sfmba_handle* h, const double* x, int32_t which, int32_t reps, double* avg_us);
+/* Normal-equation blocks at x: U (C,21 upper triangle row-major), V (P,6 upper), gc (C,6), gp (P,3). */
+int  sfmba_normal_blocks(sfmba_handle* h, const double* x, double* U, double* V, double* gc,
+                         double* gp);
+/* y = S v with S = U + diag(dc) - W (V + diag(dp))^-1 W^T at x (v, dc, y: 6C; dp: 3P). */
+int  sfmba_schur_matvec(sfmba_handle* h, const double* x, const double* dc, const double* dp,
+                        const double* v, double* y);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SFMBA_H */

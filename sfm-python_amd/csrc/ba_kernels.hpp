@@ -1,0 +1,914 @@
+// ba_kernels.hpp -- HIP kernels (gfx950 / CDNA4, wave64) of the bundle-adjustment back end.
+//
+// Model (what /root/reference/sfm_lite/bundle_adjustment.py:20-42 computes per observation):
+//     r_i = pi(K R(w_c) (X_p - T_c)) - uv_i ,   x = [C x (w, T) | P x (X, Y, Z)]
+// Observations are stored point-major (the order Graph.pt3ds_pt2ds yields,
+// /root/reference/sfm_lite/graph.py:186-191): every point owns one contiguous run.
+//
+// HBM layout (fp64):
+//   cam_idx, pt_idx   int32  [ld]          uv, r   double2 [ld]   (ld = N rounded up to 256)
+//   Jc                double [12][ld]      plane k = 6*row + col  (row: x/y residual; col: w0 w1 w2 T0 T1 T2)
+//   Jp                double [6][ld]       plane k = 3*row + col
+//   camtab            double [C][17]       R(9) T(3) w(3) b c   -- staged in LDS by the sweeps
+//   per point         V[P][6] (upper), Vinv[P][6], gp[P][3], dp[P][3] ...
+//   per camera        Ugc[C][27] = U upper (21) | gc (6)
+//
+// Every kernel is HBM-bound streaming/gather work (~1.4 flop/byte); no MFMA on this path.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sfmba {
+
+constexpr int kCamTab = 17;          // doubles per camera-table row
+constexpr int kSweepThreads = 1024;  // one workgroup per CU, 16 waves sharing one LDS camera table
+constexpr int kWavesPerSweepBlock = kSweepThreads / 64;
+
+struct KMat { double k[9]; };
+
+// device-resident control block of the PCG (lets the host enqueue iterations without reading back)
+struct PcgCtrl {
+    double rz;        // r^T M^-1 r of the current iterate
+    double rz0;       // ... of the initial residual
+    double tol2;      // (pcg_tol)^2
+    int    iters;
+    int    max_iters;
+    int    done;      // 1 converged, 2 max_iters, 3 breakdown (pAp <= 0 or non-finite)
+    int    pad;
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+
+// Block-wide sum of NQ values per thread; result valid on thread 0.  `red` holds >= 16*NQ doubles.
+template <int NQ>
+__device__ __forceinline__ void block_sum(double (&v)[NQ], double* red) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) v[q] = wave_sum(v[q]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) red[w * NQ + q] = v[q];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            double s = 0.0;
+            for (int k = 0; k < nw; ++k) s += red[k * NQ + q];   // fixed order
+            v[q] = s;
+        }
+    }
+}
+
+// Segmented reduction over a wave whose keys are sorted: afterwards the first lane of every run of
+// equal keys holds the sum over its run.  All 64 lanes must call it.
+template <int NV>
+__device__ __forceinline__ void seg_reduce(double (&v)[NV], int key, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int k2 = __shfl_down(key, off);
+        const bool ok = (lane + off < 64) && (k2 == key);
+#pragma unroll
+        for (int n = 0; n < NV; ++n) {
+            const double o = __shfl_down(v[n], off);
+            if (ok) v[n] += o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K0: per-camera table.  R = I + a [w]x + b [w]x^2 (== scipy Rotation.from_rotvec(w).as_matrix(),
+// bundle_adjustment.py:25, which the reference rebuilds per OBSERVATION), and the coefficients of the
+// right Jacobian Jr = I - b [w]x + c [w]x^2 used by d r / d w.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_cam_table(const double* __restrict__ xc, int C, double* __restrict__ tab) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double wx = xc[6 * c + 0], wy = xc[6 * c + 1], wz = xc[6 * c + 2];
+    const double th2 = wx * wx + wy * wy + wz * wz;
+    const double th = sqrt(th2);
+    double a, b, cc;
+    if (th < 1e-4) {
+        a = 1.0 - th2 / 6.0 + th2 * th2 / 120.0;
+        b = 0.5 - th2 / 24.0 + th2 * th2 / 720.0;
+    } else {
+        a = sin(th) / th;
+        const double h = 0.5 * th;
+        const double s = sin(h) / h;
+        b = 0.5 * s * s;                       // (1 - cos t)/t^2 without cancellation
+    }
+    if (th < 0.3) {
+        cc = 1.0 / 6.0 - th2 / 120.0 + th2 * th2 / 5040.0 - th2 * th2 * th2 / 362880.0 +
+             th2 * th2 * th2 * th2 / 39916800.0 - th2 * th2 * th2 * th2 * th2 / 6227020800.0;
+    } else {
+        cc = (th - sin(th)) / (th2 * th);
+    }
+    double* t = tab + (size_t)c * kCamTab;
+    t[0] = 1.0 + b * (wx * wx - th2); t[1] = -a * wz + b * wx * wy;     t[2] = a * wy + b * wx * wz;
+    t[3] = a * wz + b * wx * wy;      t[4] = 1.0 + b * (wy * wy - th2); t[5] = -a * wx + b * wy * wz;
+    t[6] = -a * wy + b * wx * wz;     t[7] = a * wx + b * wy * wz;      t[8] = 1.0 + b * (wz * wz - th2);
+    t[9] = xc[6 * c + 3]; t[10] = xc[6 * c + 4]; t[11] = xc[6 * c + 5];
+    t[12] = wx; t[13] = wy; t[14] = wz;
+    t[15] = b; t[16] = cc;
+}
+
+// One observation: residual and (JAC) the 2x6 / 2x3 blocks.
+//   v = X - T, q = R v, p = K q, A = dpi/dp K;  dr/dX = A R;  dr/dT = -A R;
+//   row k of dr/dw = -(m - b (m x w) + c ((m x w) x w)),  m = (row k of A R) x v.
+template <bool JAC>
+__device__ __forceinline__ void observe(const double* __restrict__ t, double X, double Y, double Z,
+                                        double u, double v, const KMat& K, double& rx, double& ry,
+                                        double* __restrict__ jc, double* __restrict__ jp) {
+    const double vx = X - t[9], vy = Y - t[10], vz = Z - t[11];
+    const double qx = t[0] * vx + t[1] * vy + t[2] * vz;
+    const double qy = t[3] * vx + t[4] * vy + t[5] * vz;
+    const double qz = t[6] * vx + t[7] * vy + t[8] * vz;
+    const double px = K.k[0] * qx + K.k[1] * qy + K.k[2] * qz;
+    const double py = K.k[3] * qx + K.k[4] * qy + K.k[5] * qz;
+    const double pz = K.k[6] * qx + K.k[7] * qy + K.k[8] * qz;
+    const double iz = 1.0 / pz;
+    const double u0 = px * iz, u1 = py * iz;
+    rx = u0 - u;
+    ry = u1 - v;
+    if (JAC) {
+        const double wx = t[12], wy = t[13], wz = t[14], b = t[15], c = t[16];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const double pk = k == 0 ? u0 : u1;
+            const double a0 = (K.k[3 * k + 0] - pk * K.k[6]) * iz;
+            const double a1 = (K.k[3 * k + 1] - pk * K.k[7]) * iz;
+            const double a2 = (K.k[3 * k + 2] - pk * K.k[8]) * iz;
+            const double j0 = a0 * t[0] + a1 * t[3] + a2 * t[6];      // row k of A R
+            const double j1 = a0 * t[1] + a1 * t[4] + a2 * t[7];
+            const double j2 = a0 * t[2] + a1 * t[5] + a2 * t[8];
+            jp[3 * k + 0] = j0; jp[3 * k + 1] = j1; jp[3 * k + 2] = j2;
+            const double m0 = j1 * vz - j2 * vy, m1 = j2 * vx - j0 * vz, m2 = j0 * vy - j1 * vx;
+            const double s0 = m1 * wz - m2 * wy, s1 = m2 * wx - m0 * wz, s2 = m0 * wy - m1 * wx;
+            const double t0 = s1 * wz - s2 * wy, t1 = s2 * wx - s0 * wz, t2 = s0 * wy - s1 * wx;
+            jc[6 * k + 0] = -(m0 - b * s0 + c * t0);
+            jc[6 * k + 1] = -(m1 - b * s1 + c * t1);
+            jc[6 * k + 2] = -(m2 - b * s2 + c * t2);
+            jc[6 * k + 3] = -j0; jc[6 * k + 4] = -j1; jc[6 * k + 5] = -j2;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1 / K1r: residual (+ Jacobian) sweep.  One lane owns two consecutive observations so that every
+// stream is moved 16 B per lane (global_load/store_dwordx4, 1 KiB per wave instruction); the camera
+// table sits in LDS (LDS_TAB) or, past 160 KiB, in L2.  cost_part[block] = sum r^2 of the block.
+// ---------------------------------------------------------------------------------------------
+template <bool LDS_TAB, bool JAC, bool STORE_R>
+__global__ __launch_bounds__(kSweepThreads) void k_resjac(
+    const double* __restrict__ camtab, const double* __restrict__ pts, const int* __restrict__ cam_idx,
+    const int* __restrict__ pt_idx, const double* __restrict__ uv, double* __restrict__ r,
+    double* __restrict__ Jc, double* __restrict__ Jp, int N, int64_t ld, int C, KMat K,
+    double* __restrict__ cost_part) {
+    extern __shared__ __align__(16) double smem[];
+    __shared__ double red[kWavesPerSweepBlock];
+    if (LDS_TAB) {
+        const int n = C * kCamTab;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) smem[i] = camtab[i];
+        __syncthreads();
+    }
+    const double* __restrict__ tab = LDS_TAB ? smem : camtab;
+    double acc = 0.0;
+    const int npair = (N + 1) >> 1;
+    for (int pr = blockIdx.x * blockDim.x + threadIdx.x; pr < npair; pr += gridDim.x * blockDim.x) {
+        const int i0 = 2 * pr;
+        const int2 c2 = *reinterpret_cast<const int2*>(cam_idx + i0);
+        const int2 p2 = *reinterpret_cast<const int2*>(pt_idx + i0);
+        const double2 uva = *reinterpret_cast<const double2*>(uv + 2 * (size_t)i0);
+        const double2 uvb = *reinterpret_cast<const double2*>(uv + 2 * (size_t)i0 + 2);
+        const double* __restrict__ Xa = pts + 3 * (size_t)p2.x;
+        const double* __restrict__ Xb = pts + 3 * (size_t)p2.y;
+        const double ax = Xa[0], ay = Xa[1], az = Xa[2];
+        const double bx = Xb[0], by = Xb[1], bz = Xb[2];
+        double jca[12], jpa[6], jcb[12], jpb[6];
+        double rax, ray, rbx, rby;
+        observe<JAC>(tab + c2.x * kCamTab, ax, ay, az, uva.x, uva.y, K, rax, ray, jca, jpa);
+        observe<JAC>(tab + c2.y * kCamTab, bx, by, bz, uvb.x, uvb.y, K, rbx, rby, jcb, jpb);
+        acc += rax * rax + ray * ray;
+        if (i0 + 1 < N) acc += rbx * rbx + rby * rby;
+        if (STORE_R) {
+            *reinterpret_cast<double2*>(r + 2 * (size_t)i0) = make_double2(rax, ray);
+            *reinterpret_cast<double2*>(r + 2 * (size_t)i0 + 2) = make_double2(rbx, rby);
+        }
+        if (JAC) {
+#pragma unroll
+            for (int k = 0; k < 12; ++k)
+                *reinterpret_cast<double2*>(Jc + k * ld + i0) = make_double2(jca[k], jcb[k]);
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+                *reinterpret_cast<double2*>(Jp + k * ld + i0) = make_double2(jpa[k], jpb[k]);
+        }
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) s += red[k];
+        cost_part[blockIdx.x] = s;
+    }
+}
+
+// Unpack the SoA Jacobian planes into the row-major (N,2,6)/(N,2,3) blocks of the C-ABI (test entry).
+__global__ void k_unpack_jac(const double* __restrict__ Jc, const double* __restrict__ Jp, int N,
+                             int64_t ld, double* __restrict__ jc_out, double* __restrict__ jp_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    for (int k = 0; k < 12; ++k) jc_out[(size_t)i * 12 + k] = Jc[k * ld + i];
+    for (int k = 0; k < 6; ++k) jp_out[(size_t)i * 6 + k] = Jp[k * ld + i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Point-major sweep skeleton.  Each WAVE owns an observation range cut at point boundaries
+// (host-built), walks it in steps of <= 64 observations that also end on a point boundary, reduces
+// per-point sums with wave shuffles, hands the per-point result back to the point's lanes, and
+// accumulates per-camera sums with fp64 atomics (LDS table per workgroup, flushed once; or global).
+// A point with more than 64 observations is handled by the wave looping over its run.
+// ---------------------------------------------------------------------------------------------
+struct ObsArrays {
+    const int* __restrict__ cam_idx;
+    const int* __restrict__ pt_idx;
+    const int* __restrict__ pt_ptr;   // [P+1] run offsets
+    const double* __restrict__ Jc;
+    const double* __restrict__ Jp;
+    int64_t ld;
+};
+
+__device__ __forceinline__ void load_blocks(const ObsArrays& o, int i, double* jc, double* jp) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) jc[k] = o.Jc[k * o.ld + i];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) jp[k] = o.Jp[k * o.ld + i];
+}
+
+// K2+K3: V_p = sum Jp^T Jp (6), g_p = sum Jp^T r (3) by segmented reduction;
+//        U_c = sum Jc^T Jc (21), g_c = sum Jc^T r (6) by global fp64 atomics into Ugc[C][27].
+__global__ __launch_bounds__(kSweepThreads) void k_normal_blocks(
+    const int2* __restrict__ ranges, int n_ranges, ObsArrays o, const double* __restrict__ r,
+    double* __restrict__ V, double* __restrict__ gp, double* __restrict__ Ugc) {
+    const int wg = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (wg >= n_ranges) return;
+    const int lane = threadIdx.x & 63;
+    const int2 rg = ranges[wg];
+    int pos = rg.x;
+    const int end = rg.y;
+
+    auto cam_accumulate = [&](int i, const double* jc, double rx, double ry) {
+        double* u = Ugc + (size_t)o.cam_idx[i] * 27;
+        int n = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = a; b < 6; ++b) unsafeAtomicAdd(u + n++, jc[a] * jc[b] + jc[6 + a] * jc[6 + b]);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) unsafeAtomicAdd(u + 21 + a, jc[a] * rx + jc[6 + a] * ry);
+    };
+    auto point_terms = [&](const double* jp, double rx, double ry, double* v) {
+        v[0] = jp[0] * jp[0] + jp[3] * jp[3]; v[1] = jp[0] * jp[1] + jp[3] * jp[4];
+        v[2] = jp[0] * jp[2] + jp[3] * jp[5]; v[3] = jp[1] * jp[1] + jp[4] * jp[4];
+        v[4] = jp[1] * jp[2] + jp[4] * jp[5]; v[5] = jp[2] * jp[2] + jp[5] * jp[5];
+        v[6] = jp[0] * rx + jp[3] * ry; v[7] = jp[1] * rx + jp[4] * ry; v[8] = jp[2] * rx + jp[5] * ry;
+    };
+
+    while (pos < end) {
+        const int i = pos + lane;
+        const bool in = i < end;
+        const int p = in ? o.pt_idx[i] : o.pt_idx[pos];
+        const int sb = o.pt_ptr[p], se = o.pt_ptr[p + 1];
+        const bool complete = in && (se <= pos + 64);
+        const int n_take = __popcll(__ballot(complete));
+        double jc[12], jp[6], v[9];
+        if (n_take == 0) {                         // one point with > 64 observations: [pos, run_end)
+            const int run_end = __shfl(se, 0);
+            const int pp = __shfl(p, 0);
+#pragma unroll
+            for (int q = 0; q < 9; ++q) v[q] = 0.0;
+            for (int j = pos + lane; j < run_end; j += 64) {
+                load_blocks(o, j, jc, jp);
+                const double rx = r[2 * (size_t)j], ry = r[2 * (size_t)j + 1];
+                cam_accumulate(j, jc, rx, ry);
+                double w[9];
+                point_terms(jp, rx, ry, w);
+#pragma unroll
+                for (int q = 0; q < 9; ++q) v[q] += w[q];
+            }
+#pragma unroll
+            for (int q = 0; q < 9; ++q) v[q] = wave_sum(v[q]);
+            if (lane == 0) {
+#pragma unroll
+                for (int q = 0; q < 6; ++q) V[(size_t)pp * 6 + q] = v[q];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) gp[(size_t)pp * 3 + q] = v[6 + q];
+            }
+            pos = run_end;
+            continue;
+        }
+        const bool act = lane < n_take;
+        if (act) {
+            load_blocks(o, i, jc, jp);
+            const double rx = r[2 * (size_t)i], ry = r[2 * (size_t)i + 1];
+            cam_accumulate(i, jc, rx, ry);
+            point_terms(jp, rx, ry, v);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) v[q] = 0.0;
+        }
+        seg_reduce<9>(v, act ? sb : -1 - lane, lane);
+        if (act && i == sb) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) V[(size_t)p * 6 + q] = v[q];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) gp[(size_t)p * 3 + q] = v[6 + q];
+        }
+        pos += n_take;
+    }
+}
+
+// Column scale of x_scale='jac' (SCIPY common.py:598-610): si = |J col|_2 = sqrt(diag(J^T J)),
+// zeros -> 1 on the first call, running max afterwards; also sg = g / si^2 (= D^2 g).
+__global__ void k_update_scale(const double* __restrict__ Ugc, const double* __restrict__ V,
+                               const double* __restrict__ gp, int C, int P, int first,
+                               double* __restrict__ si, double* __restrict__ g,
+                               double* __restrict__ sg) {
+    const int64_t n6 = 6 * (int64_t)C, n = n6 + 3 * (int64_t)P;
+    const int diagU[6] = {0, 6, 11, 15, 18, 20};
+    const int diagV[3] = {0, 3, 5};
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        double d, ge;
+        if (e < n6) {
+            const int c = (int)(e / 6), k = (int)(e % 6);
+            d = Ugc[(size_t)c * 27 + diagU[k]];
+            ge = Ugc[(size_t)c * 27 + 21 + k];
+        } else {
+            const int64_t q = e - n6;
+            const int p = (int)(q / 3), k = (int)(q % 3);
+            d = V[(size_t)p * 6 + diagV[k]];
+            ge = gp[q];
+        }
+        double s = sqrt(d);
+        if (first) { if (s == 0.0) s = 1.0; } else { s = fmax(s, si[e]); }
+        si[e] = s;
+        g[e] = ge;
+        sg[e] = ge / (s * s);
+    }
+}
+
+// Reductions over a slice [e0, e1) of the parameter vector.  Partials per block, fixed order.
+//   q0 = max|g|   q1 = sum (g/si)^2   q2 = sum (x si)^2   q3 = sum x^2   q4 = sum (g/si^2)^2
+//   q5 = sum g p  q6 = sum (p si)^2   q7 = sum (g/si^2) p q8 = sum p^2
+constexpr int kNQ = 9;
+__global__ __launch_bounds__(256) void k_vec_reduce(const double* __restrict__ g,
+                                                    const double* __restrict__ si,
+                                                    const double* __restrict__ x,
+                                                    const double* __restrict__ sg,
+                                                    const double* __restrict__ p, int64_t e0,
+                                                    int64_t e1, double* __restrict__ part) {
+    __shared__ double red[4 * kNQ];
+    double q[kNQ];
+#pragma unroll
+    for (int k = 0; k < kNQ; ++k) q[k] = 0.0;
+    for (int64_t e = e0 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < e1;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const double ge = g[e], s = si[e], xe = x[e], sge = sg[e], pe = p ? p[e] : 0.0;
+        q[0] = fmax(q[0], fabs(ge));
+        q[1] += (ge / s) * (ge / s);
+        q[2] += (xe * s) * (xe * s);
+        q[3] += xe * xe;
+        q[4] += sge * sge;
+        q[5] += ge * pe;
+        q[6] += (pe * s) * (pe * s);
+        q[7] += sge * pe;
+        q[8] += pe * pe;
+    }
+    // q0 is a max: reduce separately
+    double m = wave_max(q[0]);
+    q[0] = 0.0;
+    __shared__ double mred[4];
+    if ((threadIdx.x & 63) == 0) mred[threadIdx.x >> 6] = m;
+    block_sum<kNQ>(q, red);
+    if (threadIdx.x == 0) {
+        double mm = 0.0;
+        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) mm = fmax(mm, mred[k]);
+        part[(size_t)blockIdx.x * kNQ + 0] = mm;
+        for (int k = 1; k < kNQ; ++k) part[(size_t)blockIdx.x * kNQ + k] = q[k];
+    }
+}
+
+// out[k] = sum (k>=first_sum) or max (k<first_sum) over `nparts` partial rows of width nq.
+__global__ void k_finish(const double* __restrict__ part, int nparts, int nq, int first_sum,
+                         double* __restrict__ out) {
+    const int k = threadIdx.x;
+    if (k >= nq) return;
+    double s = 0.0;
+    if (k < first_sum) { for (int b = 0; b < nparts; ++b) s = fmax(s, part[(size_t)b * nq + k]); }
+    else               { for (int b = 0; b < nparts; ++b) s += part[(size_t)b * nq + k]; }
+    out[k] = s;
+}
+
+// t1_i = J (D^2 g) per observation and sum |t1|^2 (the quadratic of the 1-D Cauchy problem,
+// SCIPY trf.py:471-475 / common.py:251-299).  Camera slice of D^2 g staged in LDS.
+template <bool LDS_VEC>
+__global__ __launch_bounds__(kSweepThreads) void k_jdot(ObsArrays o, const double* __restrict__ sgc,
+                                                        const double* __restrict__ sgp, int N, int C,
+                                                        double* __restrict__ t1,
+                                                        double* __restrict__ part) {
+    extern __shared__ __align__(16) double smem[];
+    __shared__ double red[kWavesPerSweepBlock];
+    if (LDS_VEC) {
+        for (int i = threadIdx.x; i < 6 * C; i += blockDim.x) smem[i] = sgc[i];
+        __syncthreads();
+    }
+    const double* __restrict__ vc = LDS_VEC ? smem : sgc;
+    double acc = 0.0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+        double jc[12], jp[6];
+        load_blocks(o, i, jc, jp);
+        const double* a = vc + 6 * o.cam_idx[i];
+        const double* b = sgp + 3 * (size_t)o.pt_idx[i];
+        double t0 = 0.0, t1v = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { t0 += jc[k] * a[k]; t1v += jc[6 + k] * a[k]; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { t0 += jp[k] * b[k]; t1v += jp[3 + k] * b[k]; }
+        *reinterpret_cast<double2*>(t1 + 2 * (size_t)i) = make_double2(t0, t1v);
+        acc += t0 * t0 + t1v * t1v;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) s += red[k];
+        part[blockIdx.x] = s;
+    }
+}
+
+__device__ __forceinline__ void chol3_inverse(const double* a /*upper 6*/, double* inv /*upper 6*/) {
+    // A = L L^T, inv = L^-T L^-1
+    const double l00 = sqrt(a[0]);
+    const double l10 = a[1] / l00, l20 = a[2] / l00;
+    const double l11 = sqrt(a[3] - l10 * l10);
+    const double l21 = (a[4] - l20 * l10) / l11;
+    const double l22 = sqrt(a[5] - l20 * l20 - l21 * l21);
+    const double m00 = 1.0 / l00, m11 = 1.0 / l11, m22 = 1.0 / l22;      // M = L^-1 (lower)
+    const double m10 = -l10 * m00 * m11;
+    const double m21 = -l21 * m11 * m22;
+    const double m20 = -(l20 * m00 + l21 * m10) * m22;
+    inv[0] = m00 * m00 + m10 * m10 + m20 * m20;
+    inv[1] = m10 * m11 + m20 * m21;
+    inv[2] = m20 * m22;
+    inv[3] = m11 * m11 + m21 * m21;
+    inv[4] = m21 * m22;
+    inv[5] = m22 * m22;
+}
+
+// Per point: Vinv = (V + reg diag(si_p^2))^-1 and e_p = Vinv g_p.
+__global__ void k_point_prep(const double* __restrict__ V, const double* __restrict__ gp,
+                             const double* __restrict__ sip, const double* __restrict__ dp_extra,
+                             int P, double reg, double* __restrict__ Vinv, double* __restrict__ e) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    double a[6], inv[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) a[k] = V[(size_t)p * 6 + k];
+    if (dp_extra) {                       // explicit diagonal (test entry sfmba_schur_matvec)
+        a[0] += dp_extra[3 * (size_t)p]; a[3] += dp_extra[3 * (size_t)p + 1]; a[5] += dp_extra[3 * (size_t)p + 2];
+    } else {
+        const double s0 = sip[3 * (size_t)p], s1 = sip[3 * (size_t)p + 1], s2 = sip[3 * (size_t)p + 2];
+        a[0] += reg * s0 * s0; a[3] += reg * s1 * s1; a[5] += reg * s2 * s2;
+    }
+    chol3_inverse(a, inv);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Vinv[(size_t)p * 6 + k] = inv[k];
+    if (e) {
+        const double g0 = gp[3 * (size_t)p], g1 = gp[3 * (size_t)p + 1], g2 = gp[3 * (size_t)p + 2];
+        e[3 * (size_t)p + 0] = inv[0] * g0 + inv[1] * g1 + inv[2] * g2;
+        e[3 * (size_t)p + 1] = inv[1] * g0 + inv[3] * g1 + inv[4] * g2;
+        e[3 * (size_t)p + 2] = inv[2] * g0 + inv[4] * g1 + inv[5] * g2;
+    }
+}
+
+// Per camera: Minv = (U + diag(Dc))^-1 (6x6, Cholesky), the block-Jacobi preconditioner of the
+// reduced camera system; Dc = reg si_c^2 is also written out.
+__global__ void k_cam_prep(const double* __restrict__ Ugc, const double* __restrict__ sic,
+                           const double* __restrict__ dc_extra, int C, double reg,
+                           double* __restrict__ Dc, double* __restrict__ Minv) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double A[6][6];
+    {
+        int n = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = a; b < 6; ++b) { A[a][b] = Ugc[(size_t)c * 27 + n]; A[b][a] = A[a][b]; ++n; }
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        const double d = dc_extra ? dc_extra[6 * (size_t)c + a]
+                                  : reg * sic[6 * (size_t)c + a] * sic[6 * (size_t)c + a];
+        Dc[6 * (size_t)c + a] = d;
+        A[a][a] += d;
+    }
+    double L[6][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double s = A[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) s -= L[j][k] * L[j][k];
+        const double ljj = sqrt(s);
+        L[j][j] = ljj;
+        const double inv = 1.0 / ljj;
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) {
+            double t = A[i][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) t -= L[i][k] * L[j][k];
+            L[i][j] = t * inv;
+        }
+    }
+    double M[6][6];                         // M = L^-1 (lower triangular)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        M[j][j] = 1.0 / L[j][j];
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) {
+            double t = 0.0;
+#pragma unroll
+            for (int k = j; k < i; ++k) t -= L[i][k] * M[k][j];
+            M[i][j] = t / L[i][i];
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            double t = 0.0;
+#pragma unroll
+            for (int k = (a > b ? a : b); k < 6; ++k) t += M[k][a] * M[k][b];
+            Minv[(size_t)c * 36 + a * 6 + b] = t;
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4/K5 sweep: one pass over the observations applies the implicit Schur complement,
+//   acc_c += sum_{i in c} Jc_i^T ( Jc_i v_c - Jp_i z_p ),  z_p = Vinv_p sum_{i in p} Jp_i^T Jc_i v_c
+// (MODE 0), or the reduced right-hand side term acc_c -= sum Jc_i^T Jp_i e_p (MODE 1, z = e given).
+// S v = acc + Dc v is completed by k_pcg_update.  LDS_ACC: v and acc live in LDS (2 * 6C doubles).
+// ---------------------------------------------------------------------------------------------
+template <bool LDS_ACC, int MODE>
+__global__ __launch_bounds__(kSweepThreads) void k_schur_sweep(
+    const int2* __restrict__ ranges, int n_ranges, ObsArrays o, const double* __restrict__ vin,
+    const double* __restrict__ Vinv, const double* __restrict__ zin, double* __restrict__ acc, int C,
+    const PcgCtrl* __restrict__ ctrl) {
+    extern __shared__ __align__(16) double smem[];
+    if (ctrl != nullptr && ctrl->done != 0) return;          // grid-uniform: written by a prior kernel
+    const int n6 = 6 * C;
+    double* s_v = smem;
+    double* s_acc = smem + n6;
+    if (LDS_ACC) {
+        for (int i = threadIdx.x; i < n6; i += blockDim.x) {
+            s_v[i] = (MODE == 0) ? vin[i] : 0.0;
+            s_acc[i] = 0.0;
+        }
+        __syncthreads();
+    }
+    const double* __restrict__ vv = LDS_ACC ? s_v : vin;
+    double* __restrict__ av = LDS_ACC ? s_acc : acc;
+
+    const int wg = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    int pos = 0, end = 0;
+    if (wg < n_ranges) { const int2 rg = ranges[wg]; pos = rg.x; end = rg.y; }
+
+    // per-observation pieces
+    auto jcv = [&](const double* jc, int c, double& t0, double& t1) {
+        t0 = 0.0; t1 = 0.0;
+        if (MODE == 0) {
+            const double* a = vv + 6 * c;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { t0 += jc[k] * a[k]; t1 += jc[6 + k] * a[k]; }
+        }
+    };
+    auto scatter = [&](const double* jc, const double* jp, int c, double t0, double t1, double z0,
+                       double z1, double z2) {
+        const double u0 = t0 - (jp[0] * z0 + jp[1] * z1 + jp[2] * z2);
+        const double u1 = t1 - (jp[3] * z0 + jp[4] * z1 + jp[5] * z2);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) unsafeAtomicAdd(av + 6 * c + k, jc[k] * u0 + jc[6 + k] * u1);
+    };
+
+    while (pos < end) {
+        const int i = pos + lane;
+        const bool in = i < end;
+        const int p = in ? o.pt_idx[i] : o.pt_idx[pos];
+        const int sb = o.pt_ptr[p], se = o.pt_ptr[p + 1];
+        const bool complete = in && (se <= pos + 64);
+        const int n_take = __popcll(__ballot(complete));
+        double jc[12], jp[6];
+        if (n_take == 0) {                         // long run
+            const int run_end = __shfl(se, 0);
+            const int pp = __shfl(p, 0);
+            double z0, z1, z2;
+            if (MODE == 0) {
+                double y[3] = {0.0, 0.0, 0.0};
+                for (int j = pos + lane; j < run_end; j += 64) {
+                    load_blocks(o, j, jc, jp);
+                    double t0, t1;
+                    jcv(jc, o.cam_idx[j], t0, t1);
+                    y[0] += jp[0] * t0 + jp[3] * t1; y[1] += jp[1] * t0 + jp[4] * t1;
+                    y[2] += jp[2] * t0 + jp[5] * t1;
+                }
+                y[0] = wave_sum(y[0]); y[1] = wave_sum(y[1]); y[2] = wave_sum(y[2]);
+                const double* vi = Vinv + 6 * (size_t)pp;
+                z0 = vi[0] * y[0] + vi[1] * y[1] + vi[2] * y[2];
+                z1 = vi[1] * y[0] + vi[3] * y[1] + vi[4] * y[2];
+                z2 = vi[2] * y[0] + vi[4] * y[1] + vi[5] * y[2];
+            } else {
+                z0 = zin[3 * (size_t)pp]; z1 = zin[3 * (size_t)pp + 1]; z2 = zin[3 * (size_t)pp + 2];
+            }
+            for (int j = pos + lane; j < run_end; j += 64) {
+                load_blocks(o, j, jc, jp);
+                const int c = o.cam_idx[j];
+                double t0, t1;
+                jcv(jc, c, t0, t1);
+                scatter(jc, jp, c, t0, t1, z0, z1, z2);
+            }
+            pos = run_end;
+            continue;
+        }
+        const bool act = lane < n_take;
+        int c = 0;
+        double t0 = 0.0, t1 = 0.0, z0 = 0.0, z1 = 0.0, z2 = 0.0;
+        if (act) {
+            load_blocks(o, i, jc, jp);
+            c = o.cam_idx[i];
+            jcv(jc, c, t0, t1);
+        }
+        if (MODE == 0) {
+            double y[3] = {0.0, 0.0, 0.0};
+            if (act) {
+                y[0] = jp[0] * t0 + jp[3] * t1; y[1] = jp[1] * t0 + jp[4] * t1;
+                y[2] = jp[2] * t0 + jp[5] * t1;
+            }
+            seg_reduce<3>(y, act ? sb : -1 - lane, lane);
+            if (act && i == sb) {
+                const double* vi = Vinv + 6 * (size_t)p;
+                z0 = vi[0] * y[0] + vi[1] * y[1] + vi[2] * y[2];
+                z1 = vi[1] * y[0] + vi[3] * y[1] + vi[4] * y[2];
+                z2 = vi[2] * y[0] + vi[4] * y[1] + vi[5] * y[2];
+            }
+            const int head = act ? lane - (i - sb) : lane;
+            z0 = __shfl(z0, head); z1 = __shfl(z1, head); z2 = __shfl(z2, head);
+        } else if (act) {
+            z0 = zin[3 * (size_t)p]; z1 = zin[3 * (size_t)p + 1]; z2 = zin[3 * (size_t)p + 2];
+        }
+        if (act) scatter(jc, jp, c, t0, t1, z0, z1, z2);
+        pos += n_take;
+    }
+    if (LDS_ACC) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < n6; i += blockDim.x) {
+            const double a = s_acc[i];
+            if (a != 0.0) unsafeAtomicAdd(acc + i, a);
+        }
+    }
+}
+
+// PCG start on the reduced camera system S dc = rhs, rhs = -g_c - acc (acc = -sum W e from the
+// MODE 1 sweep).  Single workgroup.  x = 0, r = rhs, z = Minv r, p = z.
+__global__ __launch_bounds__(1024) void k_pcg_init(const double* __restrict__ Ugc,
+                                                   double* __restrict__ acc,
+                                                   const double* __restrict__ Minv, int C,
+                                                   double* __restrict__ xk, double* __restrict__ rk,
+                                                   double* __restrict__ pk, double tol,
+                                                   int max_iters, PcgCtrl* __restrict__ ctrl) {
+    __shared__ double red[16];
+    const int n6 = 6 * C;
+    for (int e = threadIdx.x; e < n6; e += blockDim.x) {
+        rk[e] = -Ugc[(size_t)(e / 6) * 27 + 21 + (e % 6)] - acc[e];
+        acc[e] = 0.0;
+        xk[e] = 0.0;
+    }
+    __syncthreads();
+    double s[1] = {0.0};
+    for (int e = threadIdx.x; e < n6; e += blockDim.x) {
+        const int c = e / 6, k = e % 6;
+        const double* m = Minv + (size_t)c * 36 + k * 6;
+        const double* rr = rk + 6 * c;
+        double z = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) z += m[j] * rr[j];
+        pk[e] = z;
+        s[0] += z * rk[e];
+    }
+    block_sum<1>(s, red);
+    if (threadIdx.x == 0) {
+        ctrl->rz = s[0];
+        ctrl->rz0 = s[0];
+        ctrl->tol2 = tol * tol;
+        ctrl->iters = 0;
+        ctrl->max_iters = max_iters;
+        ctrl->done = (s[0] > 0.0) ? 0 : (s[0] == 0.0 ? 1 : 3);
+    }
+}
+
+// One PCG step after the sweep produced acc = (S - Dc) p.  Single workgroup; all scalars stay on
+// the device; a finished solve turns every later sweep/update into a no-op (ctrl->done).
+__global__ __launch_bounds__(1024) void k_pcg_update(double* __restrict__ acc,
+                                                     const double* __restrict__ Dc,
+                                                     const double* __restrict__ Minv, int C,
+                                                     double* __restrict__ xk, double* __restrict__ rk,
+                                                     double* __restrict__ pk, double* __restrict__ zk,
+                                                     PcgCtrl* __restrict__ ctrl) {
+    __shared__ double red[16];
+    __shared__ double sh_alpha, sh_beta;
+    __shared__ int sh_bad;
+    if (ctrl->done != 0) return;
+    const int n6 = 6 * C;
+    double s[1] = {0.0};
+    for (int e = threadIdx.x; e < n6; e += blockDim.x) {
+        const double ap = acc[e] + Dc[e] * pk[e];
+        acc[e] = ap;                                    // keep A p for the residual update
+        s[0] += pk[e] * ap;
+    }
+    block_sum<1>(s, red);
+    if (threadIdx.x == 0) {
+        const double a = ctrl->rz / s[0];
+        sh_alpha = a;
+        sh_bad = (!(s[0] > 0.0) || !isfinite(a)) ? 1 : 0;      // p^T S p <= 0: S not SPD / NaN
+        if (sh_bad) ctrl->done = 3;
+    }
+    __syncthreads();
+    const double alpha = sh_alpha;
+    if (sh_bad) {                                            // block-uniform
+        for (int e = threadIdx.x; e < n6; e += blockDim.x) acc[e] = 0.0;
+        return;
+    }
+    for (int e = threadIdx.x; e < n6; e += blockDim.x) {
+        xk[e] += alpha * pk[e];
+        rk[e] -= alpha * acc[e];
+        acc[e] = 0.0;                                   // ready for the next sweep's atomics
+    }
+    __syncthreads();
+    double t[1] = {0.0};
+    for (int e = threadIdx.x; e < n6; e += blockDim.x) {
+        const int c = e / 6, k = e % 6;
+        const double* m = Minv + (size_t)c * 36 + k * 6;
+        const double* rr = rk + 6 * c;
+        double z = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) z += m[j] * rr[j];
+        zk[e] = z;
+        t[0] += z * rk[e];
+    }
+    block_sum<1>(t, red);
+    if (threadIdx.x == 0) {
+        const double rz_new = t[0];
+        sh_beta = rz_new / ctrl->rz;
+        ctrl->rz = rz_new;
+        const int it = ctrl->iters + 1;
+        ctrl->iters = it;
+        if (!(rz_new > ctrl->tol2 * ctrl->rz0)) ctrl->done = 1;      // also catches NaN
+        else if (it >= ctrl->max_iters) ctrl->done = 2;
+    }
+    __syncthreads();
+    const double beta = sh_beta;
+    for (int e = threadIdx.x; e < n6; e += blockDim.x) pk[e] = zk[e] + beta * pk[e];
+}
+
+// Back-substitution dp = Vinv (-g_p - sum_i W_i^T dc) per point, fused with the products the 2-D
+// trust-region model needs (SCIPY trf.py:481-485): t2_i = J p (p = [dc; dp]),
+// part[block] = (sum t1.t2, sum t2.t2) with t1 = J D^2 g from k_jdot.
+template <bool LDS_VEC>
+__global__ __launch_bounds__(kSweepThreads) void k_backsub(
+    const int2* __restrict__ ranges, int n_ranges, ObsArrays o, const double* __restrict__ dc,
+    const double* __restrict__ Vinv, const double* __restrict__ gp, const double* __restrict__ t1,
+    double* __restrict__ dp, double* __restrict__ part, int C) {
+    extern __shared__ __align__(16) double smem[];
+    __shared__ double red[2 * kWavesPerSweepBlock];
+    if (LDS_VEC) {
+        for (int i = threadIdx.x; i < 6 * C; i += blockDim.x) smem[i] = dc[i];
+        __syncthreads();
+    }
+    const double* __restrict__ vv = LDS_VEC ? smem : dc;
+    const int wg = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    int pos = 0, end = 0;
+    if (wg < n_ranges) { const int2 rg = ranges[wg]; pos = rg.x; end = rg.y; }
+    double g12 = 0.0, g22 = 0.0;
+
+    auto jcv = [&](const double* jc, int c, double& t0, double& t1v) {
+        const double* a = vv + 6 * c;
+        t0 = 0.0; t1v = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { t0 += jc[k] * a[k]; t1v += jc[6 + k] * a[k]; }
+    };
+    auto solve_point = [&](int p, const double* y, double& z0, double& z1, double& z2) {
+        const double* vi = Vinv + 6 * (size_t)p;
+        const double b0 = -gp[3 * (size_t)p] - y[0], b1 = -gp[3 * (size_t)p + 1] - y[1],
+                     b2 = -gp[3 * (size_t)p + 2] - y[2];
+        z0 = vi[0] * b0 + vi[1] * b1 + vi[2] * b2;
+        z1 = vi[1] * b0 + vi[3] * b1 + vi[4] * b2;
+        z2 = vi[2] * b0 + vi[4] * b1 + vi[5] * b2;
+        dp[3 * (size_t)p] = z0; dp[3 * (size_t)p + 1] = z1; dp[3 * (size_t)p + 2] = z2;
+    };
+    auto gram = [&](int i, const double* jp, double t0, double t1v, double z0, double z1, double z2) {
+        const double a0 = t0 + jp[0] * z0 + jp[1] * z1 + jp[2] * z2;
+        const double a1 = t1v + jp[3] * z0 + jp[4] * z1 + jp[5] * z2;
+        const double2 tt = *reinterpret_cast<const double2*>(t1 + 2 * (size_t)i);
+        g12 += tt.x * a0 + tt.y * a1;
+        g22 += a0 * a0 + a1 * a1;
+    };
+
+    while (pos < end) {
+        const int i = pos + lane;
+        const bool in = i < end;
+        const int p = in ? o.pt_idx[i] : o.pt_idx[pos];
+        const int sb = o.pt_ptr[p], se = o.pt_ptr[p + 1];
+        const bool complete = in && (se <= pos + 64);
+        const int n_take = __popcll(__ballot(complete));
+        double jc[12], jp[6];
+        if (n_take == 0) {
+            const int run_end = __shfl(se, 0);
+            const int pp = __shfl(p, 0);
+            double y[3] = {0.0, 0.0, 0.0};
+            for (int j = pos + lane; j < run_end; j += 64) {
+                load_blocks(o, j, jc, jp);
+                double t0, t1v;
+                jcv(jc, o.cam_idx[j], t0, t1v);
+                y[0] += jp[0] * t0 + jp[3] * t1v; y[1] += jp[1] * t0 + jp[4] * t1v;
+                y[2] += jp[2] * t0 + jp[5] * t1v;
+            }
+            y[0] = wave_sum(y[0]); y[1] = wave_sum(y[1]); y[2] = wave_sum(y[2]);
+            double z0, z1, z2;
+            solve_point(pp, y, z0, z1, z2);              // every lane writes the same values
+            for (int j = pos + lane; j < run_end; j += 64) {
+                load_blocks(o, j, jc, jp);
+                double t0, t1v;
+                jcv(jc, o.cam_idx[j], t0, t1v);
+                gram(j, jp, t0, t1v, z0, z1, z2);
+            }
+            pos = run_end;
+            continue;
+        }
+        const bool act = lane < n_take;
+        double t0 = 0.0, t1v = 0.0, z0 = 0.0, z1 = 0.0, z2 = 0.0;
+        double y[3] = {0.0, 0.0, 0.0};
+        if (act) {
+            load_blocks(o, i, jc, jp);
+            jcv(jc, o.cam_idx[i], t0, t1v);
+            y[0] = jp[0] * t0 + jp[3] * t1v; y[1] = jp[1] * t0 + jp[4] * t1v;
+            y[2] = jp[2] * t0 + jp[5] * t1v;
+        }
+        seg_reduce<3>(y, act ? sb : -1 - lane, lane);
+        if (act && i == sb) solve_point(p, y, z0, z1, z2);
+        const int head = act ? lane - (i - sb) : lane;
+        z0 = __shfl(z0, head); z1 = __shfl(z1, head); z2 = __shfl(z2, head);
+        if (act) gram(i, jp, t0, t1v, z0, z1, z2);
+        pos += n_take;
+    }
+    g12 = wave_sum(g12);
+    g22 = wave_sum(g22);
+    if (lane == 0) { red[2 * (threadIdx.x >> 6)] = g12; red[2 * (threadIdx.x >> 6) + 1] = g22; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0;
+        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) { a += red[2 * k]; b += red[2 * k + 1]; }
+        part[2 * (size_t)blockIdx.x] = a;
+        part[2 * (size_t)blockIdx.x + 1] = b;
+    }
+}
+
+// x_new = x + c1 (g / si^2) + c2 p     (step = D step_h, SCIPY trf.py:495-497)
+__global__ void k_step(const double* __restrict__ x, const double* __restrict__ sg,
+                       const double* __restrict__ p, double c1, double c2, int64_t n,
+                       double* __restrict__ x_new) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n;
+         e += (int64_t)gridDim.x * blockDim.x)
+        x_new[e] = x[e] + c1 * sg[e] + c2 * p[e];
+}
+
+__global__ void k_fill(double* __restrict__ a, int64_t n, double v) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n;
+         e += (int64_t)gridDim.x * blockDim.x)
+        a[e] = v;
+}
+
+}  // namespace sfmba

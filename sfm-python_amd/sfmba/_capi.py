@@ -1,0 +1,86 @@
+"""ctypes binding of libsfmba.so (include/sfmba.h).  Thin by design: plain pointers and sizes.
+
+There is NO CPU fallback: if the HIP library is missing or no MI355X is visible the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsfmba.so")
+
+# every symbol include/sfmba.h declares (tests check the library exports each of them)
+SYMBOLS = (
+    "sfmba_create", "sfmba_destroy", "sfmba_last_error", "sfmba_default_options", "sfmba_set_stream",
+    "sfmba_set_problem", "sfmba_exchange_doubles", "sfmba_set_exchange", "sfmba_residuals",
+    "sfmba_residual_jacobian", "sfmba_solve", "sfmba_get_fun_grad", "sfmba_time_kernel",
+    "sfmba_normal_blocks", "sfmba_schur_matvec",
+)
+
+
+class Options(C.Structure):
+    _fields_ = [("ftol", C.c_double), ("xtol", C.c_double), ("gtol", C.c_double),
+                ("max_nfev", C.c_int64), ("verbose", C.c_int32), ("max_iter", C.c_int32),
+                ("pcg_tol", C.c_double), ("pcg_max_iter", C.c_int32), ("pcg_check_every", C.c_int32),
+                ("reg_min", C.c_double), ("profile", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Result(C.Structure):
+    _fields_ = [("cost", C.c_double), ("cost0", C.c_double), ("optimality", C.c_double),
+                ("rmse", C.c_double), ("rmse0", C.c_double), ("nfev", C.c_int64), ("njev", C.c_int64),
+                ("iterations", C.c_int64), ("pcg_iterations", C.c_int64), ("status", C.c_int32),
+                ("reserved", C.c_int32), ("seconds_total", C.c_double), ("seconds_device", C.c_double),
+                ("resjac_avg_us", C.c_double), ("resjac_launches", C.c_int64),
+                ("last_step_norm", C.c_double), ("last_reg", C.c_double)]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32)
+
+_lib = None
+
+
+def load():
+    """Load libsfmba.so (raises if it has not been built: there is no fallback path)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build the HIP back end first (python __graft_entry__.py, or "
+            "make -C sfm-python_amd).  sfmba has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    P = C.c_void_p
+    lib.sfmba_create.argtypes = [C.POINTER(P), C.c_int]
+    lib.sfmba_create.restype = C.c_int
+    lib.sfmba_destroy.argtypes = [P]
+    lib.sfmba_destroy.restype = None
+    lib.sfmba_last_error.argtypes = [P]
+    lib.sfmba_last_error.restype = C.c_char_p
+    lib.sfmba_default_options.argtypes = [C.POINTER(Options)]
+    lib.sfmba_default_options.restype = None
+    lib.sfmba_set_stream.argtypes = [P, P]
+    lib.sfmba_set_problem.argtypes = [P, C.c_int64, C.c_int64, C.c_int64, P, P, P, P]
+    lib.sfmba_exchange_doubles.argtypes = [C.c_int64]
+    lib.sfmba_exchange_doubles.restype = C.c_int64
+    lib.sfmba_set_exchange.argtypes = [P, P, C.c_int64, ALLREDUCE_FN, P, C.c_int64]
+    lib.sfmba_residuals.argtypes = [P, P, P]
+    lib.sfmba_residual_jacobian.argtypes = [P, P, P, P, P]
+    lib.sfmba_solve.argtypes = [P, P, C.POINTER(Options), C.POINTER(Result)]
+    lib.sfmba_get_fun_grad.argtypes = [P, P, P]
+    lib.sfmba_time_kernel.argtypes = [P, P, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
+    lib.sfmba_normal_blocks.argtypes = [P, P, P, P, P, P]
+    lib.sfmba_schur_matvec.argtypes = [P, P, P, P, P, P]
+    lib.sfmba_tr2d_solve.argtypes = [P, P, C.c_double, P]
+    for name in ("sfmba_set_stream", "sfmba_set_problem", "sfmba_set_exchange", "sfmba_residuals",
+                 "sfmba_residual_jacobian", "sfmba_solve", "sfmba_get_fun_grad", "sfmba_time_kernel",
+                 "sfmba_normal_blocks", "sfmba_schur_matvec", "sfmba_tr2d_solve"):
+        getattr(lib, name).restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)

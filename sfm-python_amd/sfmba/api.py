@@ -1,0 +1,249 @@
+"""Host-side mirror of the reference's bundle-adjustment interface, backed by the HIP path.
+
+Same names, argument meaning and error behaviour as the code it replaces:
+
+* ``least_squares``          <- ``scipy.optimize.least_squares`` as called at
+                                /root/reference/sfm_lite/sfm.py:266-268
+* ``compute_residuals``      <- /root/reference/sfm_lite/bundle_adjustment.py:35-42
+* ``project_points``         <- /root/reference/sfm_lite/bundle_adjustment.py:20-32
+* ``create_sparsity_matrix`` <- /root/reference/sfm_lite/bundle_adjustment.py:6-17
+* ``pack_cameras_points`` / ``unpack_cameras_points`` <- sfm.py:248-262 / 271-281
+
+Everything numeric runs on the GPU through libsfmba.so; there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import threading
+
+import numpy as np
+
+from . import _capi
+from .backend import Backend
+
+# scipy's termination messages (SCIPY/optimize/_lsq/least_squares.py:18-25)
+TERMINATION_MESSAGES = {
+    -1: "Improper input parameters status returned from `leastsq`",
+    0: "The maximum number of function evaluations is exceeded.",
+    1: "`gtol` termination condition is satisfied.",
+    2: "`ftol` termination condition is satisfied.",
+    3: "`xtol` termination condition is satisfied.",
+    4: "Both `ftol` and `xtol` termination conditions are satisfied.",
+}
+
+try:                                     # scipy is a dependency of the reference, so normally present
+    from scipy.optimize import OptimizeResult
+except Exception:                        # pragma: no cover
+    class OptimizeResult(dict):
+        __getattr__ = dict.get
+        __setattr__ = dict.__setitem__
+
+_local = threading.local()
+
+
+def get_backend(device: int = 0) -> Backend:
+    """One Backend per (thread, device): the reference may call BA from a worker thread
+    (/root/reference/app.py:80-85) and a handle is not thread-safe."""
+    cache = getattr(_local, "cache", None)
+    if cache is None:
+        cache = _local.cache = {}
+    be = cache.get(device)
+    if be is None:
+        be = cache[device] = Backend(device)
+    return be
+
+
+def _split_args(args):
+    if len(args) != 6:
+        raise ValueError("args must be (n_cameras, n_points, camera_indices, point_indices, points_2d, K) "
+                         "as in sfm_lite/sfm.py:268")
+    return args
+
+
+def create_sparsity_matrix(n_cameras, n_points, n_obs, camera_indices, point3d_indices,
+                           fixed_camera_indices=()):
+    """Same 0/1 ``lil_matrix`` (2 n_obs, 6 n_cameras + 3 n_points), dtype int, as the reference builds
+    with a Python loop (bundle_adjustment.py:9-15); built here from index arithmetic.  The solver only
+    reads its shape -- the block structure is implied by the index arrays."""
+    from scipy.sparse import csr_matrix
+    ci = np.asarray(camera_indices, dtype=np.int64)
+    pi = np.asarray(point3d_indices, dtype=np.int64)
+    assert len(ci) == len(pi)
+    fixed = np.isin(ci, np.asarray(list(fixed_camera_indices), dtype=np.int64))
+    cols_c = ci[:, None] * 6 + np.arange(6)[None, :]
+    cols_p = n_cameras * 6 + pi[:, None] * 3 + np.arange(3)[None, :]
+    rows_c = np.repeat(np.arange(n_obs)[~fixed] * 2, 6)
+    rows_p = np.repeat(np.arange(n_obs) * 2, 3)
+    rows = np.concatenate([rows_c, rows_c + 1, rows_p, rows_p + 1])
+    cc = cols_c[~fixed].ravel()
+    cp = cols_p.ravel()
+    cols = np.concatenate([cc, cc, cp, cp])
+    M = csr_matrix((np.ones(len(rows), dtype=int), (rows, cols)),
+                   shape=(n_obs * 2, n_cameras * 6 + n_points * 3), dtype=int)
+    M.data[:] = 1                                   # duplicated (cam, point) pairs still give 1
+    return M.tolil()
+
+
+def compute_residuals(x, n_cameras, n_points, camera_indices, point_indices, points_2d, K, device=0):
+    """(2N,) interleaved residuals pi(K R(w)(X - T)) - uv, evaluated by the HIP kernel."""
+    be = get_backend(device)
+    be.set_problem(n_cameras, n_points, camera_indices, point_indices, points_2d, K)
+    return be.residuals(x)
+
+
+def project_points(points, camera_params, K, device=0):
+    """(N,3), (N,6) -> (N,2) projections, one camera row per point as in bundle_adjustment.py:20-32."""
+    points = np.ascontiguousarray(points, dtype=np.float64)
+    camera_params = np.ascontiguousarray(camera_params, dtype=np.float64)
+    n = len(points)
+    x = np.concatenate([camera_params.ravel(), points.ravel()])
+    idx = np.arange(n, dtype=np.int64)
+    r = compute_residuals(x, n, n, idx, idx, np.zeros((n, 2)), K, device=device)
+    return r.reshape(n, 2)
+
+
+def least_squares(fun, x0, jac="2-point", bounds=(-np.inf, np.inf), method="trf", ftol=1e-8, xtol=1e-8,
+                  gtol=1e-8, x_scale=1.0, loss="linear", f_scale=1.0, diff_step=None, tr_solver=None,
+                  tr_options=None, jac_sparsity=None, max_nfev=None, verbose=0, args=(), kwargs=None,
+                  device=0, max_iter=None, pcg_tol=None, profile=False):
+    """Drop-in for the reference's ``least_squares(compute_residuals, x0, jac_sparsity=..., verbose=...,
+    x_scale='jac', ftol=tol, method='trf', args=(...))`` (sfm.py:266-268).
+
+    ``fun`` must be the bundle-adjustment residual (the reference's ``compute_residuals`` or this
+    module's): it is not called -- the same model runs as a HIP kernel with an analytic Jacobian.
+    ``jac_sparsity`` is accepted and shape-checked; ``jac``, ``diff_step``, ``tr_solver``,
+    ``tr_options`` are accepted and ignored (the Jacobian is analytic, the trust-region step comes
+    from the Schur-complement PCG).  Unsupported: bounds, robust losses, methods other than 'trf',
+    x_scale other than 'jac'.
+    """
+    if method != "trf":
+        raise ValueError("sfmba.least_squares implements method='trf' only (the reference's choice).")
+    if not (isinstance(x_scale, str) and x_scale == "jac"):
+        raise ValueError("sfmba.least_squares implements x_scale='jac' only (the reference's choice).")
+    if loss != "linear":
+        raise ValueError("only loss='linear' is supported")
+    lb, ub = bounds
+    if np.any(np.isfinite(np.atleast_1d(lb))) or np.any(np.isfinite(np.atleast_1d(ub))):
+        raise ValueError("bounds are not supported (the reference passes none)")
+    if verbose not in (0, 1, 2):
+        raise ValueError("`verbose` must be in [0, 1, 2].")
+    if max_nfev is not None and max_nfev <= 0:
+        raise ValueError("`max_nfev` must be None or positive integer.")
+    if kwargs:
+        raise ValueError("kwargs are not supported; pass the BA arguments through args")
+    n_cameras, n_points, camera_indices, point_indices, points_2d, K = _split_args(tuple(args))
+    x0 = np.atleast_1d(np.asarray(x0, dtype=np.float64))
+    if x0.ndim > 1:
+        raise ValueError("`x0` must have at most 1 dimension.")
+    n = 6 * int(n_cameras) + 3 * int(n_points)
+    if x0.shape[0] != n:
+        raise ValueError(f"`x0` has {x0.shape[0]} elements, expected 6*n_cameras + 3*n_points = {n}")
+    n_obs = len(camera_indices)
+    if jac_sparsity is not None and tuple(jac_sparsity.shape) != (2 * n_obs, n):
+        raise ValueError("`jac_sparsity` has wrong shape.")          # least_squares.py:160-161
+
+    be = get_backend(device)
+    be.set_problem(n_cameras, n_points, camera_indices, point_indices, points_2d, K)
+    opt = be.default_options()
+    opt.ftol = 0.0 if ftol is None else float(ftol)
+    opt.xtol = 0.0 if xtol is None else float(xtol)
+    opt.gtol = 0.0 if gtol is None else float(gtol)
+    opt.max_nfev = 0 if max_nfev is None else int(max_nfev)
+    opt.verbose = int(verbose)
+    opt.max_iter = 0 if max_iter is None else int(max_iter)
+    if pcg_tol is not None:
+        opt.pcg_tol = float(pcg_tol)
+    opt.profile = 1 if profile else 0
+    x, res, fun_v, grad = be.solve(x0, opt)
+    return _make_result(x, res, fun_v, grad, verbose)
+
+
+def _make_result(x, res, fun_v, grad, verbose):
+    status = int(res.status)
+    out = OptimizeResult(
+        x=x, cost=res.cost, fun=fun_v, jac=None, grad=grad, optimality=res.optimality,
+        active_mask=np.zeros_like(x), nfev=int(res.nfev), njev=int(res.njev), status=status,
+        message=TERMINATION_MESSAGES[status], success=status > 0,
+        # extras (not in scipy's result)
+        iterations=int(res.iterations), pcg_iterations=int(res.pcg_iterations), rmse=res.rmse,
+        rmse0=res.rmse0, cost0=res.cost0, seconds=res.seconds_total, seconds_device=res.seconds_device,
+        resjac_avg_us=res.resjac_avg_us, resjac_launches=int(res.resjac_launches))
+    if verbose >= 1:                                                  # least_squares.py:966-970
+        print(out.message)
+        print(f"Function evaluations {out.nfev}, initial cost {res.cost0:.4e}, final cost "
+              f"{out.cost:.4e}, first-order optimality {out.optimality:.2e}.")
+    return out
+
+
+# ---- pack / unpack of the caller (sfm.py:248-262, 271-281) -----------------------------------------
+
+def _rotvec_from_matrix(R):
+    R = np.asarray(R, dtype=np.float64)
+    q = np.empty(4)
+    t = np.trace(R)
+    if t > 0:
+        s = np.sqrt(t + 1.0) * 2
+        q[:] = (R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s, 0.25 * s
+    else:
+        i = int(np.argmax(np.diag(R)))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = np.sqrt(1.0 + R[i, i] - R[j, j] - R[k, k]) * 2
+        q[i] = 0.25 * s
+        q[j] = (R[j, i] + R[i, j]) / s
+        q[k] = (R[k, i] + R[i, k]) / s
+        q[3] = (R[k, j] - R[j, k]) / s
+    if q[3] < 0:
+        q = -q
+    nv = np.linalg.norm(q[:3])
+    if nv < 1e-12:
+        return 2.0 * q[:3]
+    return q[:3] * (2.0 * np.arctan2(nv, q[3]) / nv)
+
+
+def _matrix_from_rotvec(w):
+    w = np.asarray(w, dtype=np.float64)
+    th = np.linalg.norm(w)
+    Wx = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    if th < 1e-4:
+        a, b = 1.0 - th * th / 6.0, 0.5 - th * th / 24.0
+    else:
+        a, b = np.sin(th) / th, 0.5 * (np.sin(0.5 * th) / (0.5 * th)) ** 2
+    return np.eye(3) + a * Wx + b * (Wx @ Wx)
+
+
+def pack_cameras_points(H_list, registered, X3d, observations):
+    """What sfm.py:248-262 builds from the graph: ``observations`` iterates
+    (point_idx, cam_id, (x, y)) in ``Graph.pt3ds_pt2ds`` order; ``H_list[k]`` / ``registered[k]``
+    describe node k.  T is ``H[:3, 3]`` verbatim (the reference's convention)."""
+    data = list(observations)
+    pt_indices = np.array([d[0] for d in data])
+    cam_ids = [d[1] for d in data]
+    pt2ds = np.array([d[2] for d in data])
+    reg = [k for k, f in enumerate(registered) if f]
+    camera_map = {k: i for i, k in enumerate(reg)}
+    params = [np.hstack([_rotvec_from_matrix(np.asarray(H_list[k])[:3, :3]),
+                         np.asarray(H_list[k], dtype=np.float64)[:3, 3].flatten()]) for k in reg]
+    camera_indices = np.array([camera_map[c] for c in cam_ids])
+    X3d = np.asarray(X3d, dtype=np.float64)
+    x0 = np.hstack([np.hstack(params).ravel(), X3d.ravel()])
+    return x0, len(reg), len(X3d), camera_indices, pt_indices, pt2ds, camera_map
+
+
+def unpack_cameras_points(x, n_cam, n_points, camera_map, H_list):
+    """sfm.py:271-281: new 4x4 poses for the registered cameras and the (n_points, 3) cloud."""
+    cams = np.asarray(x[:n_cam * 6]).reshape((n_cam, 6))
+    H_out = [np.array(H, dtype=np.float64, copy=True) for H in H_list]
+    for cam_id, k in camera_map.items():
+        H = np.eye(4)
+        H[:3, :3] = _matrix_from_rotvec(cams[k, :3])
+        H[:3, 3] = cams[k, 3:]
+        H_out[cam_id] = H
+    return H_out, np.asarray(x[n_cam * 6:]).reshape((n_points, 3))
+
+
+def apply_bundle_adjustment(H_list, registered, X3d, observations, K, tol=1e-10, verbose=2, device=0):
+    """The whole of ``SFM._apply_bundle_adjustment`` (sfm.py:243-281) on plain arrays."""
+    x0, n_cam, n_points, ci, pi, uv, cmap = pack_cameras_points(H_list, registered, X3d, observations)
+    jac_sparsity = None    # the reference builds one (sfm.py:264); its content is implied by ci, pi
+    res = least_squares(compute_residuals, x0, jac_sparsity=jac_sparsity, verbose=verbose, x_scale="jac",
+                        ftol=tol, method="trf", args=(n_cam, n_points, ci, pi, uv, K), device=device)
+    return unpack_cameras_points(res.x, n_cam, n_points, cmap, H_list) + (res,)

@@ -1,0 +1,164 @@
+"""Handle wrapper around the C-ABI: owns one sfmba_handle (one GPU, one problem at a time)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+
+
+class BackendError(RuntimeError):
+    pass
+
+
+def _f64(a, shape=None, name="array"):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and a.shape != shape:
+        raise ValueError(f"{name} has shape {a.shape}, expected {shape}")
+    return a
+
+
+class Backend:
+    """One MI355X.  Not thread-safe; use one Backend per thread (include/sfmba.h, Threading)."""
+
+    def __init__(self, device: int = 0):
+        self._lib = _capi.load()
+        self._h = C.c_void_p()
+        rc = self._lib.sfmba_create(C.byref(self._h), int(device))
+        if rc != 0:
+            self._h = None
+            raise BackendError(
+                f"sfmba_create(device={device}) failed with code {rc}: no usable MI355X/HIP device. "
+                "The bundle-adjustment path has no CPU fallback.")
+        self.device = int(device)
+        self.n_cameras = self.n_points = self.n_obs = 0
+        self._keep = []          # arrays / callbacks the library borrows beyond one call
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.sfmba_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------------------------------
+    def _check(self, rc: int):
+        if rc == 0:
+            return
+        msg = self._lib.sfmba_last_error(self._h).decode("utf-8", "replace")
+        if rc in (-1, -2):
+            raise ValueError(msg)            # scipy raises ValueError for both (least_squares.py:844)
+        if rc == -4:
+            raise MemoryError(msg)
+        raise BackendError(f"sfmba error {rc}: {msg}")
+
+    def set_stream(self, hip_stream: int):
+        self._check(self._lib.sfmba_set_stream(self._h, C.c_void_p(int(hip_stream))))
+
+    def set_problem(self, n_cameras, n_points, camera_indices, point_indices, points_2d, K):
+        ci = np.ascontiguousarray(camera_indices, dtype=np.int64).ravel()
+        pi = np.ascontiguousarray(point_indices, dtype=np.int64).ravel()
+        if ci.shape != pi.shape:
+            raise ValueError("camera_indices and point_indices differ in length")
+        n_obs = ci.shape[0]
+        uv = _f64(points_2d, (n_obs, 2), "points_2d")        # int pixels promoted as bundle_adjustment.py:41
+        Kc = _f64(K, (3, 3), "K")
+        self._check(self._lib.sfmba_set_problem(self._h, int(n_cameras), int(n_points), n_obs,
+                                                _capi.ptr(ci), _capi.ptr(pi), _capi.ptr(uv),
+                                                _capi.ptr(Kc)))
+        self.n_cameras, self.n_points, self.n_obs = int(n_cameras), int(n_points), n_obs
+        self._keep = []
+
+    @property
+    def n_params(self):
+        return 6 * self.n_cameras + 3 * self.n_points
+
+    def exchange_doubles(self) -> int:
+        return int(self._lib.sfmba_exchange_doubles(self.n_cameras))
+
+    def set_exchange(self, arena_ptr: int, arena_doubles: int, callback, n_obs_total: int):
+        """callback(dev_ptr:int, count:int, op:int) -> None; op 0 sum, 1 max."""
+        if callback is None:
+            self._check(self._lib.sfmba_set_exchange(self._h, None, 0, _capi.ALLREDUCE_FN(), None, 0))
+            self._keep = []
+            return
+
+        def _tramp(ctx, dev_ptr, count, op):
+            try:
+                callback(int(dev_ptr), int(count), int(op))
+                return 0
+            except Exception as exc:                         # noqa: BLE001 -- reported through rc
+                import traceback
+                traceback.print_exc()
+                self._cb_error = exc
+                return 1
+
+        cfn = _capi.ALLREDUCE_FN(_tramp)
+        self._keep = [cfn, callback]
+        self._check(self._lib.sfmba_set_exchange(self._h, C.c_void_p(int(arena_ptr)),
+                                                 int(arena_doubles), cfn, None, int(n_obs_total)))
+
+    # ------------------------------------------------------------------------------------------
+    def residuals(self, x):
+        x = _f64(x, (self.n_params,), "x")
+        out = np.empty(2 * self.n_obs)
+        self._check(self._lib.sfmba_residuals(self._h, _capi.ptr(x), _capi.ptr(out)))
+        return out
+
+    def residual_jacobian(self, x):
+        x = _f64(x, (self.n_params,), "x")
+        r = np.empty(2 * self.n_obs)
+        Jc = np.empty((self.n_obs, 2, 6))
+        Jp = np.empty((self.n_obs, 2, 3))
+        self._check(self._lib.sfmba_residual_jacobian(self._h, _capi.ptr(x), _capi.ptr(r),
+                                                      _capi.ptr(Jc), _capi.ptr(Jp)))
+        return r, Jc, Jp
+
+    def normal_blocks(self, x):
+        x = _f64(x, (self.n_params,), "x")
+        U = np.empty((self.n_cameras, 21))
+        V = np.empty((self.n_points, 6))
+        gc = np.empty((self.n_cameras, 6))
+        gp = np.empty((self.n_points, 3))
+        self._check(self._lib.sfmba_normal_blocks(self._h, _capi.ptr(x), _capi.ptr(U), _capi.ptr(V),
+                                                  _capi.ptr(gc), _capi.ptr(gp)))
+        return U, V, gc, gp
+
+    def schur_matvec(self, x, dc, dp, v):
+        x = _f64(x, (self.n_params,), "x")
+        dc = _f64(dc).reshape(-1)
+        dp = _f64(dp).reshape(-1)
+        v = _f64(v).reshape(-1)
+        y = np.empty(6 * self.n_cameras)
+        self._check(self._lib.sfmba_schur_matvec(self._h, _capi.ptr(x), _capi.ptr(dc), _capi.ptr(dp),
+                                                 _capi.ptr(v), _capi.ptr(y)))
+        return y
+
+    def time_kernel(self, x, which: int, reps: int) -> float:
+        x = _f64(x, (self.n_params,), "x")
+        us = C.c_double()
+        self._check(self._lib.sfmba_time_kernel(self._h, _capi.ptr(x), int(which), int(reps),
+                                                C.byref(us)))
+        return us.value
+
+    def default_options(self) -> _capi.Options:
+        o = _capi.Options()
+        self._lib.sfmba_default_options(C.byref(o))
+        return o
+
+    def solve(self, x0, options: _capi.Options | None = None, want_fun=True, want_grad=True):
+        x = np.array(_f64(x0, (self.n_params,), "x0"), copy=True)
+        opt = options if options is not None else self.default_options()
+        res = _capi.Result()
+        self._check(self._lib.sfmba_solve(self._h, _capi.ptr(x), C.byref(opt), C.byref(res)))
+        fun = np.empty(2 * self.n_obs) if want_fun else None
+        grad = np.empty(self.n_params) if want_grad else None
+        if want_fun or want_grad:
+            self._check(self._lib.sfmba_get_fun_grad(self._h, _capi.ptr(fun) if want_fun else None,
+                                                     _capi.ptr(grad) if want_grad else None))
+        return x, res, fun, grad
