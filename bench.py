@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py -- BA iterations/sec of the MI355X bundle-adjustment path (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg4] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A *step* is one outer (trust-region) iteration of the solver that replaces the reference's
+``least_squares`` call (/root/reference/sfm_lite/sfm.py:266-268): Jacobian sweep, normal-equation
+blocks, Schur-complement PCG, trial residual sweep, accept/reject.  The K timed steps are produced by
+back-to-back solves from the same x0 with the reference's own tolerance (ftol=1e-10), the last solve
+capped so that exactly K iterations fall in the timed region.  Problem arrays are resident in HBM
+before the clock starts; only x0 (6C+3P doubles) crosses PCIe per solve.
+
+N = 1: the 1000-camera / 100k-point / 1M-observation synthetic (BASELINE.json: the problem the >=100x
+target is quoted on).  N > 1: weak scaling -- every rank owns a shard of that size (its own 100k points
+and 1M observations), all shards share the 1000 cameras, and the camera-side normal-equation blocks,
+reduced right-hand side and PCG products are all-reduced over RCCL; `value` counts shard-iterations
+summed over ranks per second (= iterations/s at N = 1).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "sfm-python_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def k1_bytes(C, P, N):
+    """Algorithmic bytes of one residual+Jacobian launch: per observation
+    read cam_idx 4 + pt_idx 4 + uv 16, write r 16 + Jc 96 + Jp 48 = 184 B; once per point 24 B, per
+    camera 48 B."""
+    return 184 * N + 24 * P + 48 * C
+
+
+def cpu_baseline(workload_dims, seconds_budget=25.0):
+    """scipy.optimize.least_squares with the reference's kwargs driving the oracle's per-observation
+    restatement of compute_residuals (baseline B1) on a bounded sample of the same
+    workload, scaled linearly in n_obs.  One Python thread (the loop is pure Python)."""
+    from scipy.optimize import least_squares
+    import sfmba
+    from oracle import ba_oracle as orc
+    C, P, N = workload_dims
+    # sample: same cameras, same mean track length, n_obs chosen for ~seconds_budget of CPU work:
+    # cost ~ 15.7 us/obs/eval x (2 Jacobians x ~30 colour groups + 2) evals
+    us_per_obs = 16e-6
+    n_s = int(max(2000, min(N, seconds_budget / (us_per_obs * 62))))
+    p_s = max(C // 4, int(round(n_s * P / N)))
+    pb = sfmba.make_problem(C, p_s, n_s, seed=1)
+    S = sfmba.create_sparsity_matrix(C, p_s, n_s, pb.camera_indices, pb.point_indices)
+    out = {}
+    for kind, fun in (("loop", orc.compute_residuals_loop), ("vectorized", orc.compute_residuals)):
+        t = time.time()
+        res = least_squares(fun, pb.x0, jac_sparsity=S, verbose=0, x_scale="jac", ftol=1e-10,
+                            method="trf", max_nfev=2, args=pb.args)
+        dt = time.time() - t
+        out[kind] = dict(seconds=dt, njev=int(res.njev), nfev=int(res.nfev),
+                         it_per_s_sample=res.njev / dt, it_per_s_scaled=res.njev / dt * n_s / N)
+    sample = (f"scipy least_squares(method='trf', x_scale='jac', jac_sparsity, max_nfev=2) on a "
+              f"{C}-camera/{p_s}-point/{n_s}-observation sample of the workload, njev/time scaled by "
+              f"n_obs ratio {n_s}/{N}; per-observation Python residual (oracle port of "
+              f"bundle_adjustment.py:20-42); {out['loop']['seconds']:.1f} s of CPU work")
+    return dict(value=out["loop"]["it_per_s_scaled"], unit="iterations/s", cores=1, kind="port",
+                sample=sample, host_cores=os.cpu_count(),
+                vectorized_numpy_value=out["vectorized"]["it_per_s_scaled"],
+                detail=out)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="cfg4", choices=["cfg2", "cfg3", "cfg4"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.gpus > 1 and world == 1:
+        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+
+    import torch
+    import sfmba
+    from sfmba import dist as sdist
+
+    torch.cuda.set_device(local_rank)
+    C, P, N = sfmba.synthetic.CONFIGS[a.workload]
+    stream = torch.cuda.Stream()
+    be = sfmba.Backend(local_rank)
+    if world > 1:
+        import torch.distributed as td
+        td.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        pb = sdist.make_sharded_problem(C, P, N, rank, world, seed=0)
+    else:
+        td = None
+        pb = sfmba.make_problem(C, P, N, seed=0)
+
+    with torch.cuda.stream(stream):
+        be.set_stream(stream.cuda_stream)
+        be.set_problem(*pb.args)
+        ex = sdist.Exchange(be, n_obs_local=N, group=None) if world > 1 else None
+
+        opt = be.default_options()
+        opt.ftol, opt.xtol, opt.gtol = 1e-10, 1e-8, 1e-8           # the reference's ftol, scipy defaults
+        opt.profile = 1
+
+        def run_iterations(k):
+            """exactly k outer iterations from back-to-back solves; returns per-solve results"""
+            results, left = [], k
+            while left > 0:
+                opt.max_iter = left
+                _, res, _, _ = be.solve(pb.x0, opt, want_fun=False, want_grad=False)
+                if res.iterations <= 0:
+                    raise RuntimeError("solver made no progress")
+                results.append((int(res.iterations), float(res.rmse), float(res.rmse0), float(res.resjac_avg_us),
+                                int(res.resjac_launches), int(res.pcg_iterations), int(res.status)))
+                left -= int(res.iterations)
+            return results
+
+        def barrier():
+            if td is not None:
+                td.barrier()
+            torch.cuda.synchronize()
+
+        run_iterations(max(1, a.warmup))
+        barrier()
+        t0 = time.perf_counter()
+        results = run_iterations(a.steps)
+        barrier()
+        elapsed = time.perf_counter() - t0
+
+    if td is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        td.all_reduce(tmax, op=td.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        steps = sum(r[0] for r in results)
+        k1_us = sum(r[3] * r[4] for r in results) / max(1, sum(r[4] for r in results))
+        achieved = k1_bytes(C, P, N) / (k1_us * 1e-6) / 1e9 if k1_us > 0 else None
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "k1_traffic.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if tj.get("workload") == a.workload:
+                traffic = tj.get("hbm_bytes_per_launch")
+        full = [r for r in results if r[6] != 0] or results
+        line = {
+            "metric": "BA iterations/sec",
+            "value": steps * world / elapsed,
+            "unit": "iterations/s (per 1M-observation shard, summed over GPUs)" if a.workload == "cfg4"
+                    else "iterations/s (per shard, summed over GPUs)",
+            "n_gpus": world, "steps": steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * elapsed / steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{a.workload}: {C} cameras / {P} points / {N} observations per GPU shard, "
+                                   f"shared cameras, seed 0 (SURVEY.md 8d generator)",
+                       "solver": "TRF (scipy trf_no_bounds restated) + analytic Jacobian + Schur PCG, ftol=1e-10",
+                       "n_obs_total": N * world, "n_points_total": P * world, "n_cameras": C,
+                       "solves_in_timed_region": len(results),
+                       "iterations_per_solve": [r[0] for r in results],
+                       "pcg_iterations_per_solve": [r[5] for r in results]},
+            "final_rmse_px": full[0][1], "initial_rmse_px": full[0][2],
+            "roofline": {"kernel": "k_resjac (residual + 2x6/2x3 Jacobian sweep)", "bound": "hbm",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                         "traffic": traffic, "avg_launch_us": k1_us,
+                         "algorithmic_bytes_per_launch": k1_bytes(C, P, N),
+                         "launches_timed": sum(r[4] for r in results)},
+        }
+        if not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline((C, P, N))
+            line["speedup_vs_cpu_baseline"] = (steps / elapsed) / line["cpu_baseline"]["value"]
+        print(json.dumps(line), flush=True)
+    if td is not None:
+        td.barrier()
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

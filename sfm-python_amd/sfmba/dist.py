@@ -1,0 +1,113 @@
+"""Observation sharding across GPUs (one process per GPU, torch.distributed for the exchange).
+
+The reference is single-process; this is new.  Observations are point-major, so a cut
+at a point boundary gives every rank whole points: V_p, g_p and the point's Schur contribution live on
+exactly one rank, camera parameters are replicated, and the only data-path collective is an all-reduce
+(sum) of camera-sized buffers -- the 27 C doubles of [U | g_c] once per outer iteration and the 6 C
+doubles of the implicit Schur product once per PCG iteration -- plus a few scalars.  The C++ solver
+calls back into :class:`Exchange` at those points; ``torch.distributed`` (backend "nccl" = RCCL over
+xGMI on ROCm, "gloo" in the CPU tests) performs the reduction in place on a torch tensor that the
+library uses as its exchange arena.
+"""
+from __future__ import annotations
+
+import dataclasses
+
+import numpy as np
+
+from .synthetic import BAProblem, make_problem
+
+
+@dataclasses.dataclass
+class Shard:
+    rank: int
+    world: int
+    point_begin: int          # global point range [point_begin, point_end)
+    point_end: int
+    obs_begin: int            # global observation range (point-major order)
+    obs_end: int
+
+
+def partition_points(point_indices, n_points: int, world: int) -> list[Shard]:
+    """Cut the point-major observation list into ``world`` contiguous shards at point boundaries,
+    balancing observations.  ``point_indices`` must be non-decreasing."""
+    pi = np.asarray(point_indices, dtype=np.int64)
+    if pi.size and np.any(np.diff(pi) < 0):
+        raise ValueError("point_indices must be point-major (non-decreasing) to shard")
+    ptr = np.zeros(n_points + 1, dtype=np.int64)
+    np.add.at(ptr, pi + 1, 1)
+    ptr = np.cumsum(ptr)
+    n_obs = int(pi.size)
+    shards, p0 = [], 0
+    for r in range(world):
+        if r == world - 1:
+            p1 = n_points
+        else:
+            target = (n_obs * (r + 1)) // world
+            p1 = int(np.searchsorted(ptr, target, side="left"))
+            p1 = min(max(p1, p0), n_points)
+        shards.append(Shard(r, world, p0, p1, int(ptr[p0]), int(ptr[p1])))
+        p0 = p1
+    return shards
+
+
+def shard_problem(pb: BAProblem, shard: Shard) -> BAProblem:
+    """Local problem of one rank: all cameras, its own points (re-indexed from 0) and observations."""
+    C = pb.n_cameras
+    o0, o1, p0, p1 = shard.obs_begin, shard.obs_end, shard.point_begin, shard.point_end
+    x0 = np.concatenate([pb.x0[:6 * C], pb.x0[6 * C + 3 * p0:6 * C + 3 * p1]])
+    xt = np.concatenate([pb.x_true[:6 * C], pb.x_true[6 * C + 3 * p0:6 * C + 3 * p1]])
+    return BAProblem(C, p1 - p0, pb.camera_indices[o0:o1].copy(), pb.point_indices[o0:o1] - p0,
+                     pb.points_2d[o0:o1].copy(), pb.K, x0, xt)
+
+
+def merge_solutions(x_locals, shards, n_cameras: int, n_points: int) -> np.ndarray:
+    """Inverse of :func:`shard_problem` for the parameter vector (cameras are identical on all ranks)."""
+    x = np.empty(6 * n_cameras + 3 * n_points)
+    x[:6 * n_cameras] = x_locals[0][:6 * n_cameras]
+    for xl, s in zip(x_locals, shards):
+        x[6 * n_cameras + 3 * s.point_begin:6 * n_cameras + 3 * s.point_end] = xl[6 * n_cameras:]
+    return x
+
+
+def make_sharded_problem(n_cameras, n_points_per_rank, n_obs_per_rank, rank, world, seed=0) -> BAProblem:
+    """Weak-scaling workload of bench.py: rank r generates its own points/observations (seeded by r),
+    all ranks the same cameras and the same perturbed camera start."""
+    return make_problem(n_cameras, n_points_per_rank, n_obs_per_rank, seed=1000 * (seed + 1) + rank,
+                        camera_seed=seed)
+
+
+class Exchange:
+    """Registers a torch tensor as the library's exchange arena and serves its all-reduce callback.
+
+    ``backend`` needs ``exchange_doubles()`` and ``set_exchange(ptr, n, callback, n_obs_total)``
+    (sfmba.Backend).  The reduction runs on torch's current stream; make it the stream the backend
+    launches on (``backend.set_stream(torch.cuda.current_stream().cuda_stream)``) so that kernels and
+    collectives are ordered without host synchronisation.
+    """
+
+    def __init__(self, backend, n_obs_local: int, group=None, device=None):
+        import torch
+        import torch.distributed as td
+        self._td, self._torch = td, torch
+        self.group = group
+        self.n_calls = 0
+        self.n_doubles = 0
+        if device is None:
+            device = "cuda" if td.get_backend(group) == "nccl" else "cpu"
+        n = int(backend.exchange_doubles())
+        self.arena = torch.zeros(n, dtype=torch.float64, device=device)
+        tot = torch.tensor([float(n_obs_local)], dtype=torch.float64, device=device)
+        td.all_reduce(tot, op=td.ReduceOp.SUM, group=group)
+        self.n_obs_total = int(round(float(tot.item())))
+        self._base = self.arena.data_ptr()
+        backend.set_exchange(self._base, n, self._callback, self.n_obs_total)
+
+    def _callback(self, dev_ptr: int, count: int, op: int) -> None:
+        off = (dev_ptr - self._base) // 8
+        if off < 0 or off + count > self.arena.numel() or (dev_ptr - self._base) % 8:
+            raise ValueError("all-reduce request outside the exchange arena")
+        rop = self._td.ReduceOp.SUM if op == 0 else self._td.ReduceOp.MAX
+        self._td.all_reduce(self.arena[off:off + count], op=rop, group=self.group)
+        self.n_calls += 1
+        self.n_doubles += count

@@ -246,11 +246,11 @@ def test_properties_at_full_size(be):
     gvec = np.concatenate([gc.ravel(), gp.ravel()])
     d = rng.normal(size=gvec.shape)
     d /= np.linalg.norm(d)
-    eps = 1e-6
+    eps = 1e-4                                # cost ~1e9: fd round-off ~1e-16*1e9/eps
     cp = 0.5 * np.sum(be.residuals(pb.x0 + eps * d) ** 2)
     cm = 0.5 * np.sum(be.residuals(pb.x0 - eps * d) ** 2)
     fd = (cp - cm) / (2 * eps)
-    assert abs(fd - gvec @ d) <= 1e-6 * abs(fd)
+    assert abs(fd - gvec @ d) <= 1e-5 * abs(fd)
     # (3) the implicit Schur complement is linear and symmetric
     dc = 1e-3 * U[:, [0, 6, 11, 15, 18, 20]] + 1e-6
     dp = 1e-3 * V[:, [0, 3, 5]] + 1e-6
