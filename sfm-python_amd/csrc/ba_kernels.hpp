@@ -29,9 +29,11 @@ struct KMat { double k[9]; };
 
 // device-resident control block of the PCG (lets the host enqueue iterations without reading back)
 struct PcgCtrl {
-    double rz;        // r^T M^-1 r of the current iterate
+    double rz;        // gamma_i = r^T M^-1 r of the current iterate
     double rz0;       // ... of the initial residual
     double tol2;      // (pcg_tol)^2
+    double rz_prev;   // gamma_{i-1}
+    double alpha_prev;
     int    iters;
     int    max_iters;
     int    done;      // 1 converged, 2 max_iters, 3 breakdown (pAp <= 0 or non-finite)
@@ -339,6 +341,135 @@ __global__ __launch_bounds__(kSweepThreads) void k_normal_blocks(
     }
 }
 
+// K2+K3, LDS form: the per-camera sums go to a workgroup-private LDS table [C][ncols] holding columns
+// [col0, col0+ncols) of the 27 (21 U + 6 g_c) with ds_add_f64, written once per workgroup to
+// partial[block][C*ncols] and summed over workgroups in fixed order by k_reduce_tables (no global
+// atomics: 27 same-address fp64 atomics per observation ran 30x slower than the sweep itself).
+// When 27 columns of C cameras exceed the 160 KiB LDS the host runs several column passes.
+__global__ __launch_bounds__(kSweepThreads) void k_normal_blocks_lds(
+    const int2* __restrict__ ranges, int n_ranges, ObsArrays o, const double* __restrict__ r,
+    double* __restrict__ V, double* __restrict__ gp, double* __restrict__ partial, int C, int col0,
+    int ncols, int do_points) {
+    extern __shared__ __align__(16) double smem[];
+    const int ntab = C * ncols;
+    for (int i = threadIdx.x; i < ntab; i += blockDim.x) smem[i] = 0.0;
+    __syncthreads();
+    const int wg = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    int pos = 0, end = 0;
+    if (wg < n_ranges) { const int2 rg = ranges[wg]; pos = rg.x; end = rg.y; }
+    const int col1 = col0 + ncols;
+
+    auto cam_accumulate = [&](int i, const double* jc, double rx, double ry) {
+        double* u = smem + (size_t)o.cam_idx[i] * ncols - col0;
+        int n = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = a; b < 6; ++b) {
+                if (n >= col0 && n < col1) unsafeAtomicAdd(u + n, jc[a] * jc[b] + jc[6 + a] * jc[6 + b]);
+                ++n;
+            }
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            if (21 + a >= col0 && 21 + a < col1) unsafeAtomicAdd(u + 21 + a, jc[a] * rx + jc[6 + a] * ry);
+        }
+    };
+    auto point_terms = [&](const double* jp, double rx, double ry, double* v) {
+        v[0] = jp[0] * jp[0] + jp[3] * jp[3]; v[1] = jp[0] * jp[1] + jp[3] * jp[4];
+        v[2] = jp[0] * jp[2] + jp[3] * jp[5]; v[3] = jp[1] * jp[1] + jp[4] * jp[4];
+        v[4] = jp[1] * jp[2] + jp[4] * jp[5]; v[5] = jp[2] * jp[2] + jp[5] * jp[5];
+        v[6] = jp[0] * rx + jp[3] * ry; v[7] = jp[1] * rx + jp[4] * ry; v[8] = jp[2] * rx + jp[5] * ry;
+    };
+
+    if (!do_points) {                               // later column passes: cameras only, no segments
+        for (int i = pos + lane; i < end; i += 64) {
+            double jc[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) jc[k] = o.Jc[k * o.ld + i];
+            cam_accumulate(i, jc, r[2 * (size_t)i], r[2 * (size_t)i + 1]);
+        }
+        pos = end;
+    }
+    while (pos < end) {
+        const int i = pos + lane;
+        const bool in = i < end;
+        const int p = in ? o.pt_idx[i] : o.pt_idx[pos];
+        const int sb = o.pt_ptr[p], se = o.pt_ptr[p + 1];
+        const bool complete = in && (se <= pos + 64);
+        const int n_take = __popcll(__ballot(complete));
+        double jc[12], jp[6], v[9];
+        if (n_take == 0) {
+            const int run_end = __shfl(se, 0);
+            const int pp = __shfl(p, 0);
+#pragma unroll
+            for (int q = 0; q < 9; ++q) v[q] = 0.0;
+            for (int j = pos + lane; j < run_end; j += 64) {
+                load_blocks(o, j, jc, jp);
+                const double rx = r[2 * (size_t)j], ry = r[2 * (size_t)j + 1];
+                cam_accumulate(j, jc, rx, ry);
+                double w[9];
+                point_terms(jp, rx, ry, w);
+#pragma unroll
+                for (int q = 0; q < 9; ++q) v[q] += w[q];
+            }
+#pragma unroll
+            for (int q = 0; q < 9; ++q) v[q] = wave_sum(v[q]);
+            if (lane == 0) {
+#pragma unroll
+                for (int q = 0; q < 6; ++q) V[(size_t)pp * 6 + q] = v[q];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) gp[(size_t)pp * 3 + q] = v[6 + q];
+            }
+            pos = run_end;
+            continue;
+        }
+        const bool act = lane < n_take;
+        if (act) {
+            load_blocks(o, i, jc, jp);
+            const double rx = r[2 * (size_t)i], ry = r[2 * (size_t)i + 1];
+            cam_accumulate(i, jc, rx, ry);
+            point_terms(jp, rx, ry, v);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) v[q] = 0.0;
+        }
+        seg_reduce<9>(v, act ? sb : -1 - lane, lane);
+        if (act && i == sb) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) V[(size_t)p * 6 + q] = v[q];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) gp[(size_t)p * 3 + q] = v[6 + q];
+        }
+        pos += n_take;
+    }
+    __syncthreads();
+    double* __restrict__ dst = partial + (size_t)blockIdx.x * ntab;
+    for (int i = threadIdx.x; i < ntab; i += blockDim.x) dst[i] = smem[i];
+}
+
+// Ugc[c][col0 + k] = sum over workgroup tables, fixed order.  Block = 64 entries x 16 slices of the
+// workgroup axis (independent loads in flight), combined through LDS in slice order.
+__global__ __launch_bounds__(1024) void k_reduce_tables(const double* __restrict__ partial, int nblocks,
+                                                        int C, int col0, int ncols,
+                                                        double* __restrict__ Ugc) {
+    __shared__ double sm[16][64];
+    const int ntab = C * ncols;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + tx;
+    double s = 0.0;
+    if (e < ntab)
+        for (int b = ty; b < nblocks; b += 16) s += partial[(size_t)b * ntab + e];
+    sm[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && e < ntab) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sm[k][tx];
+        Ugc[(size_t)(e / ncols) * 27 + col0 + (e % ncols)] = t;
+    }
+}
+
 // Column scale of x_scale='jac' (SCIPY common.py:598-610): si = |J col|_2 = sqrt(diag(J^T J)),
 // zeros -> 1 on the first call, running max afterwards; also sg = g / si^2 (= D^2 g).
 __global__ void k_update_scale(const double* __restrict__ Ugc, const double* __restrict__ V,
@@ -411,14 +542,20 @@ __global__ __launch_bounds__(256) void k_vec_reduce(const double* __restrict__ g
 }
 
 // out[k] = sum (k>=first_sum) or max (k<first_sum) over `nparts` partial rows of width nq.
+// One wave per quantity (launch with 64*nq threads); fixed lane->partial mapping, so deterministic.
 __global__ void k_finish(const double* __restrict__ part, int nparts, int nq, int first_sum,
                          double* __restrict__ out) {
-    const int k = threadIdx.x;
+    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (k >= nq) return;
     double s = 0.0;
-    if (k < first_sum) { for (int b = 0; b < nparts; ++b) s = fmax(s, part[(size_t)b * nq + k]); }
-    else               { for (int b = 0; b < nparts; ++b) s += part[(size_t)b * nq + k]; }
-    out[k] = s;
+    if (k < first_sum) {
+        for (int b = lane; b < nparts; b += 64) s = fmax(s, part[(size_t)b * nq + k]);
+        s = wave_max(s);
+    } else {
+        for (int b = lane; b < nparts; b += 64) s += part[(size_t)b * nq + k];
+        s = wave_sum(s);
+    }
+    if (lane == 0) out[k] = s;
 }
 
 // t1_i = J (D^2 g) per observation and sum |t1|^2 (the quadratic of the 1-D Cauchy problem,
@@ -691,37 +828,49 @@ __global__ __launch_bounds__(kSweepThreads) void k_schur_sweep(
     }
 }
 
-// PCG start on the reduced camera system S dc = rhs, rhs = -g_c - acc (acc = -sum W e from the
-// MODE 1 sweep).  Single workgroup.  x = 0, r = rhs, z = Minv r, p = z.
+// PCG on the reduced camera system S dc = rhs in the single-reduction (Chronopoulos-Gear) form, so
+// that one sweep (w = S u) and ONE small update kernel make an iteration and all loads of the update
+// are issued before its only blocking reduction:
+//     delta = (w,u); beta = gamma/gamma_prev; alpha = gamma / (delta - beta gamma / alpha_prev)
+//     p = u + beta p; s = w + beta s; x += alpha p; r -= alpha s; u = Minv r; gamma' = (r,u)
+// Single workgroup, one thread per camera (its 6-vectors and 6x6 block are thread private).
+// Start: rhs = -g_c - acc (acc = -sum W e from the MODE 1 sweep), x = 0, r = rhs, u = Minv r, p = s = 0.
 __global__ __launch_bounds__(1024) void k_pcg_init(const double* __restrict__ Ugc,
                                                    double* __restrict__ acc,
                                                    const double* __restrict__ Minv, int C,
                                                    double* __restrict__ xk, double* __restrict__ rk,
-                                                   double* __restrict__ pk, double tol,
+                                                   double* __restrict__ pk, double* __restrict__ sk,
+                                                   double* __restrict__ uk, double tol,
                                                    int max_iters, PcgCtrl* __restrict__ ctrl) {
     __shared__ double red[16];
-    const int n6 = 6 * C;
-    for (int e = threadIdx.x; e < n6; e += blockDim.x) {
-        rk[e] = -Ugc[(size_t)(e / 6) * 27 + 21 + (e % 6)] - acc[e];
-        acc[e] = 0.0;
-        xk[e] = 0.0;
-    }
-    __syncthreads();
     double s[1] = {0.0};
-    for (int e = threadIdx.x; e < n6; e += blockDim.x) {
-        const int c = e / 6, k = e % 6;
-        const double* m = Minv + (size_t)c * 36 + k * 6;
-        const double* rr = rk + 6 * c;
-        double z = 0.0;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        double rr[6];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) z += m[j] * rr[j];
-        pk[e] = z;
-        s[0] += z * rk[e];
+        for (int k = 0; k < 6; ++k) {
+            rr[k] = -Ugc[(size_t)c * 27 + 21 + k] - acc[6 * c + k];
+            acc[6 * c + k] = 0.0;
+            xk[6 * c + k] = 0.0;
+            pk[6 * c + k] = 0.0;
+            sk[6 * c + k] = 0.0;
+            rk[6 * c + k] = rr[k];
+        }
+        const double* m = Minv + (size_t)c * 36;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            double z = 0.0;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) z += m[6 * k + j] * rr[j];
+            uk[6 * c + k] = z;
+            s[0] += z * rr[k];
+        }
     }
     block_sum<1>(s, red);
     if (threadIdx.x == 0) {
         ctrl->rz = s[0];
         ctrl->rz0 = s[0];
+        ctrl->rz_prev = 1.0;
+        ctrl->alpha_prev = 1.0;
         ctrl->tol2 = tol * tol;
         ctrl->iters = 0;
         ctrl->max_iters = max_iters;
@@ -729,68 +878,129 @@ __global__ __launch_bounds__(1024) void k_pcg_init(const double* __restrict__ Ug
     }
 }
 
-// One PCG step after the sweep produced acc = (S - Dc) p.  Single workgroup; all scalars stay on
-// the device; a finished solve turns every later sweep/update into a no-op (ctrl->done).
+// One PCG step after the sweep produced acc = (S - Dc) u.  A finished solve turns every later
+// sweep/update into a no-op (ctrl->done), so the host may enqueue iterations without reading back.
 __global__ __launch_bounds__(1024) void k_pcg_update(double* __restrict__ acc,
                                                      const double* __restrict__ Dc,
                                                      const double* __restrict__ Minv, int C,
                                                      double* __restrict__ xk, double* __restrict__ rk,
-                                                     double* __restrict__ pk, double* __restrict__ zk,
+                                                     double* __restrict__ pk, double* __restrict__ sk,
+                                                     double* __restrict__ uk,
                                                      PcgCtrl* __restrict__ ctrl) {
     __shared__ double red[16];
     __shared__ double sh_alpha, sh_beta;
     __shared__ int sh_bad;
     if (ctrl->done != 0) return;
-    const int n6 = 6 * C;
-    double s[1] = {0.0};
-    for (int e = threadIdx.x; e < n6; e += blockDim.x) {
-        const double ap = acc[e] + Dc[e] * pk[e];
-        acc[e] = ap;                                    // keep A p for the residual update
-        s[0] += pk[e] * ap;
+    // C <= 1024: one camera per thread.  u, w, r and the Minv block stay in registers across the
+    // reduction; p, s, x (needed only after it) wait in LDS (18 doubles per thread, [k][thread]).
+    extern __shared__ __align__(16) double stage[];
+    const int c0 = threadIdx.x;
+    double w[6], u[6], r[6], m[21];    // m: upper triangle of the symmetric Minv block
+    double d[1] = {0.0};
+    const bool own = c0 < C;
+    if (own) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            u[k] = uk[6 * c0 + k];
+            w[k] = acc[6 * c0 + k] + Dc[6 * c0 + k] * u[k];
+            r[k] = rk[6 * c0 + k];
+            stage[(0 + k) * blockDim.x + c0] = pk[6 * c0 + k];
+            stage[(6 + k) * blockDim.x + c0] = sk[6 * c0 + k];
+            stage[(12 + k) * blockDim.x + c0] = xk[6 * c0 + k];
+            d[0] += w[k] * u[k];
+        }
+        int n = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = a; b < 6; ++b) m[n++] = Minv[(size_t)c0 * 36 + a * 6 + b];
     }
-    block_sum<1>(s, red);
+    for (int c = c0 + blockDim.x; c < C; c += blockDim.x) {     // C > 1024: extra cameras via memory
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const double ue = uk[6 * c + k];
+            const double we = acc[6 * c + k] + Dc[6 * c + k] * ue;
+            acc[6 * c + k] = we;
+            d[0] += we * ue;
+        }
+    }
+    block_sum<1>(d, red);
     if (threadIdx.x == 0) {
-        const double a = ctrl->rz / s[0];
-        sh_alpha = a;
-        sh_bad = (!(s[0] > 0.0) || !isfinite(a)) ? 1 : 0;      // p^T S p <= 0: S not SPD / NaN
+        const double gamma = ctrl->rz;
+        const double beta = ctrl->iters == 0 ? 0.0 : gamma / ctrl->rz_prev;
+        const double den = d[0] - (ctrl->iters == 0 ? 0.0 : beta * gamma / ctrl->alpha_prev);
+        const double alpha = gamma / den;
+        sh_alpha = alpha; sh_beta = beta;
+        sh_bad = (!(den > 0.0) || !isfinite(alpha)) ? 1 : 0;        // S not SPD / NaN
         if (sh_bad) ctrl->done = 3;
     }
     __syncthreads();
-    const double alpha = sh_alpha;
-    if (sh_bad) {                                            // block-uniform
-        for (int e = threadIdx.x; e < n6; e += blockDim.x) acc[e] = 0.0;
+    const double alpha = sh_alpha, beta = sh_beta;
+    if (sh_bad) {                                               // block-uniform
+        for (int e = threadIdx.x; e < 6 * C; e += blockDim.x) acc[e] = 0.0;
         return;
     }
-    for (int e = threadIdx.x; e < n6; e += blockDim.x) {
-        xk[e] += alpha * pk[e];
-        rk[e] -= alpha * acc[e];
-        acc[e] = 0.0;                                   // ready for the next sweep's atomics
-    }
-    __syncthreads();
     double t[1] = {0.0};
-    for (int e = threadIdx.x; e < n6; e += blockDim.x) {
-        const int c = e / 6, k = e % 6;
-        const double* m = Minv + (size_t)c * 36 + k * 6;
-        const double* rr = rk + 6 * c;
-        double z = 0.0;
+    if (own) {
+        double p[6], sv[6], x[6];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) z += m[j] * rr[j];
-        zk[e] = z;
-        t[0] += z * rk[e];
+        for (int k = 0; k < 6; ++k) {
+            p[k] = u[k] + beta * stage[(0 + k) * blockDim.x + c0];
+            sv[k] = w[k] + beta * stage[(6 + k) * blockDim.x + c0];
+            x[k] = stage[(12 + k) * blockDim.x + c0] + alpha * p[k];
+            r[k] -= alpha * sv[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            double z = 0.0;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int a = k < j ? k : j, b = k < j ? j : k;
+                z += m[a * 6 - a * (a - 1) / 2 + (b - a)] * r[j];     // packed upper index
+            }
+            u[k] = z;
+            t[0] += z * r[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            pk[6 * c0 + k] = p[k]; sk[6 * c0 + k] = sv[k]; xk[6 * c0 + k] = x[k];
+            rk[6 * c0 + k] = r[k]; uk[6 * c0 + k] = u[k];
+            acc[6 * c0 + k] = 0.0;                          // ready for the next sweep's atomics
+        }
+    }
+    for (int c = c0 + blockDim.x; c < C; c += blockDim.x) {
+        double rr[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const double pe = uk[6 * c + k] + beta * pk[6 * c + k];
+            const double se = acc[6 * c + k] + beta * sk[6 * c + k];
+            pk[6 * c + k] = pe; sk[6 * c + k] = se;
+            xk[6 * c + k] += alpha * pe;
+            rr[k] = rk[6 * c + k] - alpha * se;
+            rk[6 * c + k] = rr[k];
+            acc[6 * c + k] = 0.0;
+        }
+        const double* mm = Minv + (size_t)c * 36;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            double z = 0.0;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) z += mm[6 * k + j] * rr[j];
+            uk[6 * c + k] = z;
+            t[0] += z * rr[k];
+        }
     }
     block_sum<1>(t, red);
     if (threadIdx.x == 0) {
         const double rz_new = t[0];
-        sh_beta = rz_new / ctrl->rz;
+        ctrl->rz_prev = ctrl->rz;
+        ctrl->alpha_prev = alpha;
         ctrl->rz = rz_new;
         const int it = ctrl->iters + 1;
         ctrl->iters = it;
         if (!(rz_new > ctrl->tol2 * ctrl->rz0)) ctrl->done = 1;      // also catches NaN
         else if (it >= ctrl->max_iters) ctrl->done = 2;
     }
-    __syncthreads();
-    const double beta = sh_beta;
-    for (int e = threadIdx.x; e < n6; e += blockDim.x) pk[e] = zk[e] + beta * pk[e];
 }
 
 // Back-substitution dp = Vinv (-g_p - sum_i W_i^T dc) per point, fused with the products the 2-D

@@ -29,6 +29,8 @@ using namespace sfmba;
 namespace {
 
 constexpr size_t kLdsBytes = 160 * 1024;       // gfx950: 160 KiB LDS per workgroup
+constexpr size_t kLdsDynMax = kLdsBytes - 512; // dynamic part; every kernel here has <= 512 B static LDS
+constexpr size_t kPcgStageBytes = 18 * 1024 * sizeof(double);   // k_pcg_update: p, s, x staged in LDS
 constexpr int kScalSlots = 16;                  // exchange scalars: 0 cost, 1..8 q1..q8, 10 G11, 11 G12, 12 G22, 15 max|g|
 
 struct DevBuf {
@@ -68,13 +70,14 @@ struct sfmba_handle {
     std::vector<int64_t> order;              // sorted position -> caller's observation index
     int n_ranges = 0;
     bool lds_tab = true, lds_acc = true, lds_vec = true;
+    int nb_passes = 1;                       // column passes of the LDS normal-block tables; 0 = global atomics
 
     DevBuf cam_idx, pt_idx, pt_ptr, uv, ranges;
     DevBuf xa, xb, tabA, tabB, r, Jc, Jp, t1;
     DevBuf V, Vinv, gp, e;
     DevBuf g, si, sg, p;                     // n-vectors; p = [dc | dp]
-    DevBuf Dc, Minv, rk, pk, zk;
-    DevBuf part, scal_c, ctrl, tmp_out;
+    DevBuf Dc, Minv, rk, pk, sk, uk;
+    DevBuf part, scal_c, ctrl, tmp_out, tables;
     DevBuf arena_own;
     double* arena = nullptr;                 // [acc 6C | Ugc 27C | scal 16]
     int64_t arena_doubles = 0;
@@ -82,6 +85,8 @@ struct sfmba_handle {
     void* ar_ctx = nullptr;
     double* h_scal = nullptr;                // pinned
     bool solved = false;
+    std::vector<const void*> lds_ready;      // kernels already opted in to 160 KiB dynamic LDS
+    int last_pcg_iters = 0;
 
     double* x = nullptr;                     // current / trial parameter vectors (alias xa/xb)
     double* x_new = nullptr;
@@ -132,11 +137,15 @@ int exchange(sfmba_handle* h, double* ptr, int64_t count, int op) {
     return 0;
 }
 
+// Dynamic LDS above 64 KiB needs the per-kernel opt-in; it is set ONCE per kernel (to the full
+// 160 KiB) because hipFuncSetAttribute costs tens of microseconds to a millisecond per call.
 template <class Kern>
 int set_lds(sfmba_handle* h, Kern k, size_t bytes) {
-    if (bytes > 64 * 1024)
-        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    if (bytes <= 64 * 1024) return 0;
+    const void* fn = reinterpret_cast<const void*>(k);
+    if (std::find(h->lds_ready.begin(), h->lds_ready.end(), fn) != h->lds_ready.end()) return 0;
+    HIPCHK(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsDynMax));
+    h->lds_ready.push_back(fn);
     return 0;
 }
 
@@ -188,14 +197,33 @@ int launch_resjac(sfmba_handle* h, const double* x, const double* tab, int* npar
 }
 
 int launch_finish(sfmba_handle* h, const double* part, int nparts, int nq, int first_sum, double* out) {
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, h->stream, part, nparts, nq, first_sum, out);
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64 * nq), 0, h->stream, part, nparts, nq, first_sum, out);
     HIPCHK(h, hipGetLastError());
     return 0;
 }
 
 int launch_normal_blocks(sfmba_handle* h) {
-    HIPCHK(h, hipMemsetAsync(h->Ugc(), 0, sizeof(double) * 27 * h->C, h->stream));
     const int grid = (h->n_ranges + kWavesPerSweepBlock - 1) / kWavesPerSweepBlock;
+    if (h->nb_passes > 0) {
+        // LDS tables: columns of [U | g_c] split into nb_passes groups that fit 160 KiB
+        const int per = (27 + h->nb_passes - 1) / h->nb_passes;
+        for (int ps = 0; ps < h->nb_passes; ++ps) {
+            const int col0 = ps * per, ncols = std::min(per, 27 - col0);
+            const size_t lds = sizeof(double) * (size_t)h->C * ncols;
+            CHK(set_lds(h, k_normal_blocks_lds, lds));
+            hipLaunchKernelGGL(k_normal_blocks_lds, dim3(grid), dim3(kSweepThreads), lds, h->stream,
+                               h->ranges.as<int2>(), h->n_ranges, obs_arrays(h), h->r.as<double>(),
+                               h->V.as<double>(), h->gp.as<double>(), h->tables.as<double>(), (int)h->C,
+                               col0, ncols, ps == 0 ? 1 : 0);
+            HIPCHK(h, hipGetLastError());
+            const int ntab = (int)h->C * ncols;
+            hipLaunchKernelGGL(k_reduce_tables, dim3((ntab + 63) / 64), dim3(1024), 0, h->stream,
+                               h->tables.as<double>(), grid, (int)h->C, col0, ncols, h->Ugc());
+            HIPCHK(h, hipGetLastError());
+        }
+        return 0;
+    }
+    HIPCHK(h, hipMemsetAsync(h->Ugc(), 0, sizeof(double) * 27 * h->C, h->stream));
     hipLaunchKernelGGL(k_normal_blocks, dim3(grid), dim3(kSweepThreads), 0, h->stream,
                        h->ranges.as<int2>(), h->n_ranges, obs_arrays(h), h->r.as<double>(),
                        h->V.as<double>(), h->gp.as<double>(), h->Ugc());
@@ -323,24 +351,31 @@ int run_pcg(sfmba_handle* h, const sfmba_options& opt, int* iters, int* pstat) {
     double* dc = h->p.as<double>();
     PcgCtrl* ctrl = h->ctrl.as<PcgCtrl>();
     hipLaunchKernelGGL(k_pcg_init, dim3(1), dim3(1024), 0, h->stream, h->Ugc(), h->acc(), h->Minv.as<double>(),
-                       (int)h->C, dc, h->rk.as<double>(), h->pk.as<double>(), opt.pcg_tol, max_it, ctrl);
+                       (int)h->C, dc, h->rk.as<double>(), h->pk.as<double>(), h->sk.as<double>(),
+                       h->uk.as<double>(), opt.pcg_tol, max_it, ctrl);
     HIPCHK(h, hipGetLastError());
+    CHK(set_lds(h, k_pcg_update, kPcgStageBytes));
     PcgCtrl hc{};
     int launched = 0;
+    // first read-back when the previous solve's iteration count is reached (the device-side done
+    // flag turns surplus launches into no-ops), then every `every` iterations
+    int batch = h->last_pcg_iters > 0 ? std::max(every, h->last_pcg_iters) : every;
     for (;;) {
-        for (int k = 0; k < every; ++k) {
-            CHK(launch_schur_sweep<0>(h, h->pk.as<double>(), nullptr, ctrl));
+        for (int k = 0; k < batch; ++k) {
+            CHK(launch_schur_sweep<0>(h, h->uk.as<double>(), nullptr, ctrl));
             CHK(exchange(h, h->acc(), 6 * h->C, 0));
-            hipLaunchKernelGGL(k_pcg_update, dim3(1), dim3(1024), 0, h->stream, h->acc(), h->Dc.as<double>(),
+            hipLaunchKernelGGL(k_pcg_update, dim3(1), dim3(1024), kPcgStageBytes, h->stream, h->acc(), h->Dc.as<double>(),
                                h->Minv.as<double>(), (int)h->C, dc, h->rk.as<double>(), h->pk.as<double>(),
-                               h->zk.as<double>(), ctrl);
+                               h->sk.as<double>(), h->uk.as<double>(), ctrl);
             HIPCHK(h, hipGetLastError());
             ++launched;
         }
         HIPCHK(h, hipMemcpyAsync(&hc, ctrl, sizeof hc, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        if (hc.done != 0 || launched > max_it + every) break;
+        if (hc.done != 0 || launched > max_it + batch) break;
+        batch = every;
     }
+    h->last_pcg_iters = hc.iters;
     *iters = hc.iters;
     *pstat = hc.done;
     return 0;
@@ -504,9 +539,14 @@ int sfmba_set_problem(sfmba_handle* h, int64_t C, int64_t P, int64_t N, const in
         }
     }
     h->n_ranges = (int)ranges.size();
-    h->lds_tab = (size_t)C * kCamTab * sizeof(double) + 512 <= kLdsBytes;
-    h->lds_acc = (size_t)C * 12 * sizeof(double) + 512 <= kLdsBytes;
-    h->lds_vec = (size_t)C * 6 * sizeof(double) + 1024 <= kLdsBytes;
+    h->lds_tab = (size_t)C * kCamTab * sizeof(double) <= kLdsDynMax;
+    h->lds_acc = (size_t)C * 12 * sizeof(double) <= kLdsDynMax;
+    h->lds_vec = (size_t)C * 6 * sizeof(double) <= kLdsDynMax;
+    {   // normal-block LDS tables: up to 3 column passes, else global fp64 atomics
+        const size_t budget = kLdsDynMax;
+        const int max_cols = (int)std::min<size_t>(27, budget / (sizeof(double) * (size_t)C));
+        h->nb_passes = max_cols >= 9 ? (27 + max_cols - 1) / max_cols : 0;
+    }
 
     const size_t ld = (size_t)h->ld;
     HIPCHK(h, h->cam_idx.ensure(sizeof(int) * ld));
@@ -534,11 +574,17 @@ int sfmba_set_problem(sfmba_handle* h, int64_t C, int64_t P, int64_t N, const in
     HIPCHK(h, h->Minv.ensure(sizeof(double) * 36 * C));
     HIPCHK(h, h->rk.ensure(sizeof(double) * 6 * C));
     HIPCHK(h, h->pk.ensure(sizeof(double) * 6 * C));
-    HIPCHK(h, h->zk.ensure(sizeof(double) * 6 * C));
+    HIPCHK(h, h->sk.ensure(sizeof(double) * 6 * C));
+    HIPCHK(h, h->uk.ensure(sizeof(double) * 6 * C));
     HIPCHK(h, h->part.ensure(sizeof(double) * (size_t)(2048 * kNQ)));
     HIPCHK(h, h->scal_c.ensure(sizeof(double) * 16));
     HIPCHK(h, h->tmp_out.ensure(sizeof(double) * 16));
     HIPCHK(h, h->ctrl.ensure(sizeof(PcgCtrl)));
+    if (h->nb_passes > 0) {
+        const int per = (27 + h->nb_passes - 1) / h->nb_passes;
+        const size_t nblk = (ranges.size() + kWavesPerSweepBlock - 1) / kWavesPerSweepBlock;
+        HIPCHK(h, h->tables.ensure(sizeof(double) * std::max<size_t>(1, nblk) * (size_t)C * per));
+    }
     HIPCHK(h, h->arena_own.ensure(sizeof(double) * (size_t)sfmba_exchange_doubles(C)));
     h->arena = h->arena_own.as<double>();
     h->ar_fn = nullptr; h->ar_ctx = nullptr;

@@ -156,9 +156,10 @@ def test_long_tracks_and_ragged_runs(be, orc):
 
 
 def test_many_cameras_global_table_variants(be, orc):
-    """More cameras than fit the LDS tables: 1300 (camera table in L2) and 1800 (accumulators global)."""
+    """More cameras than fit the LDS tables: 1300 (camera table in L2, 2 normal-block column passes),
+    1800 (Schur accumulators global, 3 passes), 2600 (normal blocks by global atomics)."""
     from sfmba import make_problem
-    for C in (1300, 1800):
+    for C in (1300, 1800, 2600):
         pb = make_problem(C, 500, 6000, seed=C)
         be.set_problem(*pb.args)
         r, Jc, Jp = be.residual_jacobian(pb.x0)
