@@ -38,7 +38,16 @@ struct PcgCtrl {
     int    max_iters;
     int    done;      // 1 converged, 2 max_iters, 3 breakdown (pAp <= 0 or non-finite)
     int    pad;
+#ifdef SFMBA_STAMPS
+    unsigned long long stamp[16];   // diagnostic build only: s_memrealtime (100 MHz) at phase boundaries
+#endif
 };
+
+#ifdef SFMBA_STAMPS
+#define SFMBA_STAMP(ctrl, k) do { if (threadIdx.x == 0) (ctrl)->stamp[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SFMBA_STAMP(ctrl, k) do {} while (0)
+#endif
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -642,7 +651,9 @@ __global__ void k_point_prep(const double* __restrict__ V, const double* __restr
 }
 
 // Per camera: Minv = (U + diag(Dc))^-1 (6x6, Cholesky), the block-Jacobi preconditioner of the
-// reduced camera system; Dc = reg si_c^2 is also written out.
+// reduced camera system; Dc = reg si_c^2 is also written out.  Camera-sized PCG vectors (Dc, Minv,
+// acc, x, r, p, s, u) are stored plane-major, element k of camera c at [k*C + c], so that the
+// one-thread-per-camera PCG kernels read and write them fully coalesced.
 __global__ void k_cam_prep(const double* __restrict__ Ugc, const double* __restrict__ sic,
                            const double* __restrict__ dc_extra, int C, double reg,
                            double* __restrict__ Dc, double* __restrict__ Minv) {
@@ -660,7 +671,7 @@ __global__ void k_cam_prep(const double* __restrict__ Ugc, const double* __restr
     for (int a = 0; a < 6; ++a) {
         const double d = dc_extra ? dc_extra[6 * (size_t)c + a]
                                   : reg * sic[6 * (size_t)c + a] * sic[6 * (size_t)c + a];
-        Dc[6 * (size_t)c + a] = d;
+        Dc[(size_t)a * C + c] = d;                      // plane-major over cameras (coalesced in the PCG)
         A[a][a] += d;
     }
     double L[6][6];
@@ -692,14 +703,16 @@ __global__ void k_cam_prep(const double* __restrict__ Ugc, const double* __restr
             M[i][j] = t / L[i][i];
         }
     }
+    int n = 0;
 #pragma unroll
     for (int a = 0; a < 6; ++a)
 #pragma unroll
-        for (int b = 0; b < 6; ++b) {
+        for (int b = a; b < 6; ++b) {                    // packed upper triangle, plane n = [C]
             double t = 0.0;
 #pragma unroll
-            for (int k = (a > b ? a : b); k < 6; ++k) t += M[k][a] * M[k][b];
-            Minv[(size_t)c * 36 + a * 6 + b] = t;
+            for (int k = b; k < 6; ++k) t += M[k][a] * M[k][b];
+            Minv[(size_t)n * C + c] = t;
+            ++n;
         }
 }
 
@@ -720,14 +733,18 @@ __global__ __launch_bounds__(kSweepThreads) void k_schur_sweep(
     double* s_v = smem;
     double* s_acc = smem + n6;
     if (LDS_ACC) {
-        for (int i = threadIdx.x; i < n6; i += blockDim.x) {
-            s_v[i] = (MODE == 0) ? vin[i] : 0.0;
-            s_acc[i] = 0.0;
+        for (int i = threadIdx.x; i < n6; i += blockDim.x) {       // i = k*C + c (global, coalesced)
+            const int k = i / C, c = i - k * C;
+            s_v[6 * c + k] = (MODE == 0) ? vin[i] : 0.0;
+            s_acc[6 * c + k] = 0.0;
         }
         __syncthreads();
     }
     const double* __restrict__ vv = LDS_ACC ? s_v : vin;
     double* __restrict__ av = LDS_ACC ? s_acc : acc;
+    // element k of camera c: LDS tables are camera-major (one camera's 6 values adjacent), the
+    // global vectors plane-major
+    const int cs = LDS_ACC ? 6 : 1, ks = LDS_ACC ? 1 : C;
 
     const int wg = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -738,9 +755,9 @@ __global__ __launch_bounds__(kSweepThreads) void k_schur_sweep(
     auto jcv = [&](const double* jc, int c, double& t0, double& t1) {
         t0 = 0.0; t1 = 0.0;
         if (MODE == 0) {
-            const double* a = vv + 6 * c;
+            const double* a = vv + cs * c;
 #pragma unroll
-            for (int k = 0; k < 6; ++k) { t0 += jc[k] * a[k]; t1 += jc[6 + k] * a[k]; }
+            for (int k = 0; k < 6; ++k) { const double ak = a[ks * k]; t0 += jc[k] * ak; t1 += jc[6 + k] * ak; }
         }
     };
     auto scatter = [&](const double* jc, const double* jp, int c, double t0, double t1, double z0,
@@ -748,7 +765,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_schur_sweep(
         const double u0 = t0 - (jp[0] * z0 + jp[1] * z1 + jp[2] * z2);
         const double u1 = t1 - (jp[3] * z0 + jp[4] * z1 + jp[5] * z2);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) unsafeAtomicAdd(av + 6 * c + k, jc[k] * u0 + jc[6 + k] * u1);
+        for (int k = 0; k < 6; ++k) unsafeAtomicAdd(av + cs * c + ks * k, jc[k] * u0 + jc[6 + k] * u1);
     };
 
     while (pos < end) {
@@ -822,7 +839,8 @@ __global__ __launch_bounds__(kSweepThreads) void k_schur_sweep(
     if (LDS_ACC) {
         __syncthreads();
         for (int i = threadIdx.x; i < n6; i += blockDim.x) {
-            const double a = s_acc[i];
+            const int k = i / C, c = i - k * C;
+            const double a = s_acc[6 * c + k];
             if (a != 0.0) unsafeAtomicAdd(acc + i, a);
         }
     }
@@ -845,23 +863,25 @@ __global__ __launch_bounds__(1024) void k_pcg_init(const double* __restrict__ Ug
     __shared__ double red[16];
     double s[1] = {0.0};
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        double rr[6];
+        double rr[6], m[21];
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
-            rr[k] = -Ugc[(size_t)c * 27 + 21 + k] - acc[6 * c + k];
-            acc[6 * c + k] = 0.0;
-            xk[6 * c + k] = 0.0;
-            pk[6 * c + k] = 0.0;
-            sk[6 * c + k] = 0.0;
-            rk[6 * c + k] = rr[k];
+            const size_t e = (size_t)k * C + c;
+            rr[k] = -Ugc[(size_t)c * 27 + 21 + k] - acc[e];
+            acc[e] = 0.0; xk[e] = 0.0; pk[e] = 0.0; sk[e] = 0.0;
+            rk[e] = rr[k];
         }
-        const double* m = Minv + (size_t)c * 36;
+#pragma unroll
+        for (int n = 0; n < 21; ++n) m[n] = Minv[(size_t)n * C + c];
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
             double z = 0.0;
 #pragma unroll
-            for (int j = 0; j < 6; ++j) z += m[6 * k + j] * rr[j];
-            uk[6 * c + k] = z;
+            for (int j = 0; j < 6; ++j) {
+                const int a = k < j ? k : j, b = k < j ? j : k;
+                z += m[a * 6 - a * (a - 1) / 2 + (b - a)] * rr[j];
+            }
+            uk[(size_t)k * C + c] = z;
             s[0] += z * rr[k];
         }
     }
@@ -880,6 +900,8 @@ __global__ __launch_bounds__(1024) void k_pcg_init(const double* __restrict__ Ug
 
 // One PCG step after the sweep produced acc = (S - Dc) u.  A finished solve turns every later
 // sweep/update into a no-op (ctrl->done), so the host may enqueue iterations without reading back.
+// Cameras beyond the first 1024 are handled by the same threads in further rounds; w = S u is kept
+// in acc between the two phases for them.
 __global__ __launch_bounds__(1024) void k_pcg_update(double* __restrict__ acc,
                                                      const double* __restrict__ Dc,
                                                      const double* __restrict__ Minv, int C,
@@ -890,41 +912,23 @@ __global__ __launch_bounds__(1024) void k_pcg_update(double* __restrict__ acc,
     __shared__ double red[16];
     __shared__ double sh_alpha, sh_beta;
     __shared__ int sh_bad;
+    SFMBA_STAMP(ctrl, 0);
     if (ctrl->done != 0) return;
-    // C <= 1024: one camera per thread.  u, w, r and the Minv block stay in registers across the
-    // reduction; p, s, x (needed only after it) wait in LDS (18 doubles per thread, [k][thread]).
-    extern __shared__ __align__(16) double stage[];
-    const int c0 = threadIdx.x;
-    double w[6], u[6], r[6], m[21];    // m: upper triangle of the symmetric Minv block
+    SFMBA_STAMP(ctrl, 1);
     double d[1] = {0.0};
-    const bool own = c0 < C;
-    if (own) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
-            u[k] = uk[6 * c0 + k];
-            w[k] = acc[6 * c0 + k] + Dc[6 * c0 + k] * u[k];
-            r[k] = rk[6 * c0 + k];
-            stage[(0 + k) * blockDim.x + c0] = pk[6 * c0 + k];
-            stage[(6 + k) * blockDim.x + c0] = sk[6 * c0 + k];
-            stage[(12 + k) * blockDim.x + c0] = xk[6 * c0 + k];
-            d[0] += w[k] * u[k];
-        }
-        int n = 0;
-#pragma unroll
-        for (int a = 0; a < 6; ++a)
-#pragma unroll
-            for (int b = a; b < 6; ++b) m[n++] = Minv[(size_t)c0 * 36 + a * 6 + b];
-    }
-    for (int c = c0 + blockDim.x; c < C; c += blockDim.x) {     // C > 1024: extra cameras via memory
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const double ue = uk[6 * c + k];
-            const double we = acc[6 * c + k] + Dc[6 * c + k] * ue;
-            acc[6 * c + k] = we;
+            const size_t e = (size_t)k * C + c;
+            const double ue = uk[e];
+            const double we = acc[e] + Dc[e] * ue;
+            acc[e] = we;
             d[0] += we * ue;
         }
     }
+    SFMBA_STAMP(ctrl, 2);
     block_sum<1>(d, red);
+    SFMBA_STAMP(ctrl, 3);
     if (threadIdx.x == 0) {
         const double gamma = ctrl->rz;
         const double beta = ctrl->iters == 0 ? 0.0 : gamma / ctrl->rz_prev;
@@ -935,20 +939,27 @@ __global__ __launch_bounds__(1024) void k_pcg_update(double* __restrict__ acc,
         if (sh_bad) ctrl->done = 3;
     }
     __syncthreads();
+    SFMBA_STAMP(ctrl, 4);
     const double alpha = sh_alpha, beta = sh_beta;
     if (sh_bad) {                                               // block-uniform
         for (int e = threadIdx.x; e < 6 * C; e += blockDim.x) acc[e] = 0.0;
         return;
     }
     double t[1] = {0.0};
-    if (own) {
-        double p[6], sv[6], x[6];
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        double rr[6], m[21];
+#pragma unroll
+        for (int n = 0; n < 21; ++n) m[n] = Minv[(size_t)n * C + c];
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
-            p[k] = u[k] + beta * stage[(0 + k) * blockDim.x + c0];
-            sv[k] = w[k] + beta * stage[(6 + k) * blockDim.x + c0];
-            x[k] = stage[(12 + k) * blockDim.x + c0] + alpha * p[k];
-            r[k] -= alpha * sv[k];
+            const size_t e = (size_t)k * C + c;
+            const double pe = uk[e] + beta * pk[e];
+            const double se = acc[e] + beta * sk[e];
+            pk[e] = pe; sk[e] = se;
+            xk[e] += alpha * pe;
+            rr[k] = rk[e] - alpha * se;
+            rk[e] = rr[k];
+            acc[e] = 0.0;                                   // ready for the next sweep's atomics
         }
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
@@ -956,41 +967,15 @@ __global__ __launch_bounds__(1024) void k_pcg_update(double* __restrict__ acc,
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
                 const int a = k < j ? k : j, b = k < j ? j : k;
-                z += m[a * 6 - a * (a - 1) / 2 + (b - a)] * r[j];     // packed upper index
+                z += m[a * 6 - a * (a - 1) / 2 + (b - a)] * rr[j];
             }
-            u[k] = z;
-            t[0] += z * r[k];
-        }
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            pk[6 * c0 + k] = p[k]; sk[6 * c0 + k] = sv[k]; xk[6 * c0 + k] = x[k];
-            rk[6 * c0 + k] = r[k]; uk[6 * c0 + k] = u[k];
-            acc[6 * c0 + k] = 0.0;                          // ready for the next sweep's atomics
-        }
-    }
-    for (int c = c0 + blockDim.x; c < C; c += blockDim.x) {
-        double rr[6];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const double pe = uk[6 * c + k] + beta * pk[6 * c + k];
-            const double se = acc[6 * c + k] + beta * sk[6 * c + k];
-            pk[6 * c + k] = pe; sk[6 * c + k] = se;
-            xk[6 * c + k] += alpha * pe;
-            rr[k] = rk[6 * c + k] - alpha * se;
-            rk[6 * c + k] = rr[k];
-            acc[6 * c + k] = 0.0;
-        }
-        const double* mm = Minv + (size_t)c * 36;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            double z = 0.0;
-#pragma unroll
-            for (int j = 0; j < 6; ++j) z += mm[6 * k + j] * rr[j];
-            uk[6 * c + k] = z;
+            uk[(size_t)k * C + c] = z;
             t[0] += z * rr[k];
         }
     }
+    SFMBA_STAMP(ctrl, 5);
     block_sum<1>(t, red);
+    SFMBA_STAMP(ctrl, 6);
     if (threadIdx.x == 0) {
         const double rz_new = t[0];
         ctrl->rz_prev = ctrl->rz;
@@ -1001,6 +986,7 @@ __global__ __launch_bounds__(1024) void k_pcg_update(double* __restrict__ acc,
         if (!(rz_new > ctrl->tol2 * ctrl->rz0)) ctrl->done = 1;      // also catches NaN
         else if (it >= ctrl->max_iters) ctrl->done = 2;
     }
+    SFMBA_STAMP(ctrl, 7);
 }
 
 // Back-substitution dp = Vinv (-g_p - sum_i W_i^T dc) per point, fused with the products the 2-D
@@ -1008,13 +994,20 @@ __global__ __launch_bounds__(1024) void k_pcg_update(double* __restrict__ acc,
 // part[block] = (sum t1.t2, sum t2.t2) with t1 = J D^2 g from k_jdot.
 template <bool LDS_VEC>
 __global__ __launch_bounds__(kSweepThreads) void k_backsub(
-    const int2* __restrict__ ranges, int n_ranges, ObsArrays o, const double* __restrict__ dc,
-    const double* __restrict__ Vinv, const double* __restrict__ gp, const double* __restrict__ t1,
-    double* __restrict__ dp, double* __restrict__ part, int C) {
+    const int2* __restrict__ ranges, int n_ranges, ObsArrays o, const double* __restrict__ dc_planes,
+    double* __restrict__ dc, const double* __restrict__ Vinv, const double* __restrict__ gp,
+    const double* __restrict__ t1, double* __restrict__ dp, double* __restrict__ part, int C) {
     extern __shared__ __align__(16) double smem[];
     __shared__ double red[2 * kWavesPerSweepBlock];
+    // dc_planes: PCG solution, plane-major [6][C]; dc: camera-major [C][6] copy (already written by
+    // k_transpose6 when the LDS table is not used)
     if (LDS_VEC) {
-        for (int i = threadIdx.x; i < 6 * C; i += blockDim.x) smem[i] = dc[i];
+        for (int i = threadIdx.x; i < 6 * C; i += blockDim.x) {
+            const int k = i / C, c = i - k * C;
+            const double val = dc_planes[i];
+            smem[6 * c + k] = val;
+            if (blockIdx.x == 0) dc[6 * c + k] = val;
+        }
         __syncthreads();
     }
     const double* __restrict__ vv = LDS_VEC ? smem : dc;
@@ -1104,6 +1097,14 @@ __global__ __launch_bounds__(kSweepThreads) void k_backsub(
         part[2 * (size_t)blockIdx.x] = a;
         part[2 * (size_t)blockIdx.x + 1] = b;
     }
+}
+
+// camera-major [C][6] <- plane-major [6][C]
+__global__ void k_transpose6(const double* __restrict__ planes, int C, double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 6 * C) return;
+    const int k = i / C, c = i - k * C;
+    out[6 * c + k] = planes[i];
 }
 
 // x_new = x + c1 (g / si^2) + c2 p     (step = D step_h, SCIPY trf.py:495-497)

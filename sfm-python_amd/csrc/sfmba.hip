@@ -30,7 +30,6 @@ namespace {
 
 constexpr size_t kLdsBytes = 160 * 1024;       // gfx950: 160 KiB LDS per workgroup
 constexpr size_t kLdsDynMax = kLdsBytes - 512; // dynamic part; every kernel here has <= 512 B static LDS
-constexpr size_t kPcgStageBytes = 18 * 1024 * sizeof(double);   // k_pcg_update: p, s, x staged in LDS
 constexpr int kScalSlots = 16;                  // exchange scalars: 0 cost, 1..8 q1..q8, 10 G11, 11 G12, 12 G22, 15 max|g|
 
 struct DevBuf {
@@ -76,7 +75,7 @@ struct sfmba_handle {
     DevBuf xa, xb, tabA, tabB, r, Jc, Jp, t1;
     DevBuf V, Vinv, gp, e;
     DevBuf g, si, sg, p;                     // n-vectors; p = [dc | dp]
-    DevBuf Dc, Minv, rk, pk, sk, uk;
+    DevBuf Dc, Minv, xk, rk, pk, sk, uk;       // camera-sized PCG vectors, plane-major [k][C]
     DevBuf part, scal_c, ctrl, tmp_out, tables;
     DevBuf arena_own;
     double* arena = nullptr;                 // [acc 6C | Ugc 27C | scal 16]
@@ -279,12 +278,15 @@ int launch_backsub(sfmba_handle* h, int* nparts) {
         auto kern = k_backsub<true>;
         CHK(set_lds(h, kern, lds));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), lds, h->stream, h->ranges.as<int2>(),
-                           h->n_ranges, obs_arrays(h), dc, h->Vinv.as<double>(), h->gp.as<double>(),
-                           h->t1.as<double>(), dp, h->part.as<double>(), (int)h->C);
-    } else {
-        hipLaunchKernelGGL(k_backsub<false>, dim3(grid), dim3(kSweepThreads), 0, h->stream,
-                           h->ranges.as<int2>(), h->n_ranges, obs_arrays(h), dc, h->Vinv.as<double>(),
+                           h->n_ranges, obs_arrays(h), h->xk.as<double>(), dc, h->Vinv.as<double>(),
                            h->gp.as<double>(), h->t1.as<double>(), dp, h->part.as<double>(), (int)h->C);
+    } else {
+        hipLaunchKernelGGL(k_transpose6, dim3((6 * h->C + 255) / 256), dim3(256), 0, h->stream,
+                           h->xk.as<double>(), (int)h->C, dc);
+        hipLaunchKernelGGL(k_backsub<false>, dim3(grid), dim3(kSweepThreads), 0, h->stream,
+                           h->ranges.as<int2>(), h->n_ranges, obs_arrays(h), h->xk.as<double>(), dc,
+                           h->Vinv.as<double>(), h->gp.as<double>(), h->t1.as<double>(), dp,
+                           h->part.as<double>(), (int)h->C);
     }
     HIPCHK(h, hipGetLastError());
     *nparts = grid;
@@ -348,13 +350,12 @@ int check_ready(sfmba_handle* h, const void* x) {
 int run_pcg(sfmba_handle* h, const sfmba_options& opt, int* iters, int* pstat) {
     const int max_it = opt.pcg_max_iter > 0 ? opt.pcg_max_iter : (int)std::max<int64_t>(20, 2 * 6 * h->C);
     const int every = std::max(1, opt.pcg_check_every);
-    double* dc = h->p.as<double>();
+    double* dc = h->xk.as<double>();
     PcgCtrl* ctrl = h->ctrl.as<PcgCtrl>();
     hipLaunchKernelGGL(k_pcg_init, dim3(1), dim3(1024), 0, h->stream, h->Ugc(), h->acc(), h->Minv.as<double>(),
                        (int)h->C, dc, h->rk.as<double>(), h->pk.as<double>(), h->sk.as<double>(),
                        h->uk.as<double>(), opt.pcg_tol, max_it, ctrl);
     HIPCHK(h, hipGetLastError());
-    CHK(set_lds(h, k_pcg_update, kPcgStageBytes));
     PcgCtrl hc{};
     int launched = 0;
     // first read-back when the previous solve's iteration count is reached (the device-side done
@@ -364,7 +365,7 @@ int run_pcg(sfmba_handle* h, const sfmba_options& opt, int* iters, int* pstat) {
         for (int k = 0; k < batch; ++k) {
             CHK(launch_schur_sweep<0>(h, h->uk.as<double>(), nullptr, ctrl));
             CHK(exchange(h, h->acc(), 6 * h->C, 0));
-            hipLaunchKernelGGL(k_pcg_update, dim3(1), dim3(1024), kPcgStageBytes, h->stream, h->acc(), h->Dc.as<double>(),
+            hipLaunchKernelGGL(k_pcg_update, dim3(1), dim3(1024), 0, h->stream, h->acc(), h->Dc.as<double>(),
                                h->Minv.as<double>(), (int)h->C, dc, h->rk.as<double>(), h->pk.as<double>(),
                                h->sk.as<double>(), h->uk.as<double>(), ctrl);
             HIPCHK(h, hipGetLastError());
@@ -375,6 +376,11 @@ int run_pcg(sfmba_handle* h, const sfmba_options& opt, int* iters, int* pstat) {
         if (hc.done != 0 || launched > max_it + batch) break;
         batch = every;
     }
+#ifdef SFMBA_STAMPS
+    fprintf(stderr, "[stamps] k_pcg_update phases (us):");
+    for (int k = 1; k < 8; ++k) fprintf(stderr, " %.2f", (double)(hc.stamp[k] - hc.stamp[k - 1]) * 0.01);
+    fprintf(stderr, "  total %.2f\n", (double)(hc.stamp[7] - hc.stamp[0]) * 0.01);
+#endif
     h->last_pcg_iters = hc.iters;
     *iters = hc.iters;
     *pstat = hc.done;
@@ -571,7 +577,8 @@ int sfmba_set_problem(sfmba_handle* h, int64_t C, int64_t P, int64_t N, const in
     HIPCHK(h, h->sg.ensure(sizeof(double) * h->n));
     HIPCHK(h, h->p.ensure(sizeof(double) * h->n));
     HIPCHK(h, h->Dc.ensure(sizeof(double) * 6 * C));
-    HIPCHK(h, h->Minv.ensure(sizeof(double) * 36 * C));
+    HIPCHK(h, h->Minv.ensure(sizeof(double) * 21 * C));
+    HIPCHK(h, h->xk.ensure(sizeof(double) * 6 * C));
     HIPCHK(h, h->rk.ensure(sizeof(double) * 6 * C));
     HIPCHK(h, h->pk.ensure(sizeof(double) * 6 * C));
     HIPCHK(h, h->sk.ensure(sizeof(double) * 6 * C));
@@ -686,22 +693,26 @@ int sfmba_schur_matvec(sfmba_handle* h, const double* x, const double* dc, const
     CHK((launch_resjac<true, true>(h, h->x, h->tab, &np)));
     CHK(launch_normal_blocks(h));
     CHK(exchange(h, h->Ugc(), 27 * h->C, 0));
-    // stage dp in e, dc in Dc, v in pk
+    // stage dp in e (as explicit diagonal), v in pk -- camera vectors are plane-major on the device
+    const int64_t C = h->C;
+    std::vector<double> vp(6 * C);
+    for (int64_t c = 0; c < C; ++c)
+        for (int k = 0; k < 6; ++k) vp[k * C + c] = v[6 * c + k];
     HIPCHK(h, hipMemcpyAsync(h->e.p, dp, sizeof(double) * 3 * h->P, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->Dc.p, dc, sizeof(double) * 6 * h->C, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->pk.p, v, sizeof(double) * 6 * h->C, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->pk.p, vp.data(), sizeof(double) * 6 * C, hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(k_point_prep, dim3((h->P + 255) / 256), dim3(256), 0, h->stream, h->V.as<double>(),
                        h->gp.as<double>(), (const double*)nullptr, h->e.as<double>(), (int)h->P, 0.0,
                        h->Vinv.as<double>(), (double*)nullptr);
     HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipMemsetAsync(h->acc(), 0, sizeof(double) * 6 * h->C, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->acc(), 0, sizeof(double) * 6 * C, h->stream));
     CHK(launch_schur_sweep<0>(h, h->pk.as<double>(), nullptr, nullptr));
-    CHK(exchange(h, h->acc(), 6 * h->C, 0));
-    std::vector<double> a(6 * h->C);
-    HIPCHK(h, hipMemcpyAsync(a.data(), h->acc(), sizeof(double) * 6 * h->C, hipMemcpyDeviceToHost, h->stream));
+    CHK(exchange(h, h->acc(), 6 * C, 0));
+    std::vector<double> a(6 * C);
+    HIPCHK(h, hipMemcpyAsync(a.data(), h->acc(), sizeof(double) * 6 * C, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    for (int64_t e = 0; e < 6 * h->C; ++e) y[e] = a[e] + dc[e] * v[e];
-    HIPCHK(h, hipMemsetAsync(h->acc(), 0, sizeof(double) * 6 * h->C, h->stream));
+    for (int64_t c = 0; c < C; ++c)
+        for (int k = 0; k < 6; ++k) y[6 * c + k] = a[k * C + c] + dc[6 * c + k] * v[6 * c + k];
+    HIPCHK(h, hipMemsetAsync(h->acc(), 0, sizeof(double) * 6 * C, h->stream));
     return 0;
 }
 

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsfmba.so")
+LIB_PATH = os.environ.get("SFMBA_LIB") or os.path.join(_HERE, "libsfmba.so")   # SFMBA_LIB: diagnostic builds
 
 # every symbol include/sfmba.h declares (tests check the library exports each of them)
 SYMBOLS = (
