@@ -30,7 +30,13 @@ namespace {
 
 constexpr size_t kLdsBytes = 160 * 1024;       // gfx950: 160 KiB LDS per workgroup
 constexpr size_t kLdsDynMax = kLdsBytes - 512; // dynamic part; every kernel here has <= 512 B static LDS
-constexpr int kScalSlots = 16;                  // exchange scalars: 0 cost, 1..8 q1..q8, 10 G11, 11 G12, 12 G22, 15 max|g|
+// Scalars at the end of the exchange arena (32 doubles):
+//   summed over ranks [0..11]: 0 sum r^2 | 1 G11 | 2 G12 | 3 G22 | 4..11 q1..q8 of the point slice
+//   max over ranks    [12]   : q0 = max|g| of the point slice
+//   device-local      [13]   : regularisation term of this iteration (k_reg)
+//   never exchanged   [16..24]: q0..q8 of the camera slice (replicated on every rank)
+constexpr int kScalSlots = 32;
+constexpr int kSumSlots = 12, kMaxSlot = 12, kRegSlot = 13, kCamSlot = 16;
 
 struct DevBuf {
     void* p = nullptr;
@@ -72,11 +78,13 @@ struct sfmba_handle {
     int nb_passes = 1;                       // column passes of the LDS normal-block tables; 0 = global atomics
 
     DevBuf cam_idx, pt_idx, pt_ptr, uv, ranges;
-    DevBuf xa, xb, tabA, tabB, r, Jc, Jp, t1;
+    DevBuf xa, xb, tabA, tabB, r[2], Jc[2], Jp[2], t1;   // J and r double-buffered: a trial step is
+                                                       // evaluated into the spare set and swapped in on accept
+    int jcur = 0;
     DevBuf V, Vinv, gp, e;
     DevBuf g, si, sg, p;                     // n-vectors; p = [dc | dp]
     DevBuf Dc, Minv, xk, rk, pk, sk, uk;       // camera-sized PCG vectors, plane-major [k][C]
-    DevBuf part, scal_c, ctrl, tmp_out, tables;
+    DevBuf part, ctrl, tables;
     DevBuf arena_own;
     double* arena = nullptr;                 // [acc 6C | Ugc 27C | scal 16]
     int64_t arena_doubles = 0;
@@ -95,6 +103,7 @@ struct sfmba_handle {
     double* acc() const { return arena; }
     double* Ugc() const { return arena + 6 * C; }
     double* scal() const { return arena + 33 * C; }
+    int red_bc = 1, red_grid = 2;            // block split of the parameter-vector reductions
 };
 
 namespace {
@@ -150,7 +159,7 @@ int set_lds(sfmba_handle* h, Kern k, size_t bytes) {
 
 ObsArrays obs_arrays(const sfmba_handle* h) {
     return ObsArrays{h->cam_idx.as<int>(), h->pt_idx.as<int>(), h->pt_ptr.as<int>(),
-                     h->Jc.as<double>(), h->Jp.as<double>(), h->ld};
+                     h->Jc[h->jcur].as<double>(), h->Jp[h->jcur].as<double>(), h->ld};
 }
 
 int grid_1d(int64_t n, int block, int cap) {
@@ -168,10 +177,10 @@ int launch_cam_table(sfmba_handle* h, const double* x, double* tab) {
     return 0;
 }
 
-// residual (+Jacobian) sweep at x (camera table must be current); leaves sum r^2 partials in `part`
-// and returns the number of partials.
+// residual (+Jacobian) sweep at x (camera table must be current) into buffer set `js`; leaves the
+// sum r^2 partials in `part` and returns the number of partials.
 template <bool JAC, bool STORE_R>
-int launch_resjac(sfmba_handle* h, const double* x, const double* tab, int* nparts) {
+int launch_resjac(sfmba_handle* h, const double* x, const double* tab, int js, int* nparts) {
     const int npair = (int)((h->N + 1) / 2);
     const int grid = grid_1d(npair, kSweepThreads, h->n_cu);
     const double* pts = x + 6 * h->C;
@@ -181,22 +190,35 @@ int launch_resjac(sfmba_handle* h, const double* x, const double* tab, int* npar
         CHK(set_lds(h, kern, lds));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), lds, h->stream, tab, pts,
                            h->cam_idx.as<int>(), h->pt_idx.as<int>(), h->uv.as<double>(),
-                           h->r.as<double>(), h->Jc.as<double>(), h->Jp.as<double>(), (int)h->N, h->ld,
-                           (int)h->C, h->K, h->part.as<double>());
+                           h->r[js].as<double>(), h->Jc[js].as<double>(), h->Jp[js].as<double>(), (int)h->N,
+                           h->ld, (int)h->C, h->K, h->part.as<double>());
     } else {
         auto kern = k_resjac<false, JAC, STORE_R>;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), 0, h->stream, tab, pts,
                            h->cam_idx.as<int>(), h->pt_idx.as<int>(), h->uv.as<double>(),
-                           h->r.as<double>(), h->Jc.as<double>(), h->Jp.as<double>(), (int)h->N, h->ld,
-                           (int)h->C, h->K, h->part.as<double>());
+                           h->r[js].as<double>(), h->Jc[js].as<double>(), h->Jp[js].as<double>(), (int)h->N,
+                           h->ld, (int)h->C, h->K, h->part.as<double>());
     }
     HIPCHK(h, hipGetLastError());
     *nparts = grid;
     return 0;
 }
 
-int launch_finish(sfmba_handle* h, const double* part, int nparts, int nq, int first_sum, double* out) {
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64 * nq), 0, h->stream, part, nparts, nq, first_sum, out);
+// sum of `nparts` partial rows of width nq into the exchange scalars starting at slot `slot`
+int launch_finish(sfmba_handle* h, const double* part, int nparts, int nq, int slot) {
+    FinishJob job{};
+    job.row0[0] = 0; job.nrows[0] = nparts; job.max_off[0] = slot; job.sum_off[0] = slot;
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64 * nq), 0, h->stream, part, job, nq, 0, h->scal());
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+// the two-slice (cameras | points) reductions of k_update_scale / k_vec_reduce
+int launch_finish_slices(sfmba_handle* h) {
+    FinishJob job{};
+    job.row0[0] = 0;         job.nrows[0] = h->red_bc;               job.max_off[0] = kCamSlot; job.sum_off[0] = kCamSlot;
+    job.row0[1] = h->red_bc; job.nrows[1] = h->red_grid - h->red_bc; job.max_off[1] = kMaxSlot; job.sum_off[1] = 3;
+    hipLaunchKernelGGL(k_finish, dim3(2), dim3(64 * kNQ), 0, h->stream, h->part.as<double>(), job, kNQ, 1, h->scal());
     HIPCHK(h, hipGetLastError());
     return 0;
 }
@@ -211,7 +233,7 @@ int launch_normal_blocks(sfmba_handle* h) {
             const size_t lds = sizeof(double) * (size_t)h->C * ncols;
             CHK(set_lds(h, k_normal_blocks_lds, lds));
             hipLaunchKernelGGL(k_normal_blocks_lds, dim3(grid), dim3(kSweepThreads), lds, h->stream,
-                               h->ranges.as<int2>(), h->n_ranges, obs_arrays(h), h->r.as<double>(),
+                               h->ranges.as<int2>(), h->n_ranges, obs_arrays(h), h->r[h->jcur].as<double>(),
                                h->V.as<double>(), h->gp.as<double>(), h->tables.as<double>(), (int)h->C,
                                col0, ncols, ps == 0 ? 1 : 0);
             HIPCHK(h, hipGetLastError());
@@ -224,7 +246,7 @@ int launch_normal_blocks(sfmba_handle* h) {
     }
     HIPCHK(h, hipMemsetAsync(h->Ugc(), 0, sizeof(double) * 27 * h->C, h->stream));
     hipLaunchKernelGGL(k_normal_blocks, dim3(grid), dim3(kSweepThreads), 0, h->stream,
-                       h->ranges.as<int2>(), h->n_ranges, obs_arrays(h), h->r.as<double>(),
+                       h->ranges.as<int2>(), h->n_ranges, obs_arrays(h), h->r[h->jcur].as<double>(),
                        h->V.as<double>(), h->gp.as<double>(), h->Ugc());
     HIPCHK(h, hipGetLastError());
     return 0;
@@ -293,46 +315,41 @@ int launch_backsub(sfmba_handle* h, int* nparts) {
     return 0;
 }
 
-// reductions over the camera slice (-> scal_c) and the point slice (-> arena scalars 1..8, 15)
-int launch_vec_reduce(sfmba_handle* h, bool with_p) {
-    const double* p = with_p ? h->p.as<double>() : nullptr;
-    const int64_t n6 = 6 * h->C;
-    {   // cameras: replicated on every rank, never exchanged
-        const int grid = grid_1d(n6, 256, 64);
-        double* part = h->part.as<double>();
-        hipLaunchKernelGGL(k_vec_reduce, dim3(grid), dim3(256), 0, h->stream, h->g.as<double>(),
-                           h->si.as<double>(), h->x, h->sg.as<double>(), p, (int64_t)0, n6, part);
-        HIPCHK(h, hipGetLastError());
-        CHK(launch_finish(h, part, grid, kNQ, 1, h->scal_c.as<double>()));
-    }
-    {   // points: local to the shard, summed over ranks
-        const int grid = grid_1d(3 * h->P, 256, 1024);
-        double* part = h->part.as<double>() + 64 * kNQ;
-        hipLaunchKernelGGL(k_vec_reduce, dim3(grid), dim3(256), 0, h->stream, h->g.as<double>(),
-                           h->si.as<double>(), h->x, h->sg.as<double>(), p, n6, h->n, part);
-        HIPCHK(h, hipGetLastError());
-        // q0 (max) -> slot 15, q1..q8 -> slots 1..8; slot 9 unused
-        double* tmp = h->tmp_out.as<double>();
-        CHK(launch_finish(h, part, grid, kNQ, 1, tmp));
-        HIPCHK(h, hipMemcpyAsync(h->scal() + 1, tmp + 1, sizeof(double) * 8, hipMemcpyDeviceToDevice, h->stream));
-        HIPCHK(h, hipMemcpyAsync(h->scal() + 15, tmp, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    }
+// column scale + gradient + q0..q4 of the new iterate (after the normal blocks are complete)
+int launch_update_scale(sfmba_handle* h, int first) {
+    hipLaunchKernelGGL(k_update_scale, dim3(h->red_grid), dim3(256), 0, h->stream, h->Ugc(), h->V.as<double>(),
+                       h->gp.as<double>(), h->x, (int)h->C, (int)h->P, first, h->red_bc, h->si.as<double>(),
+                       h->g.as<double>(), h->sg.as<double>(), h->part.as<double>());
+    HIPCHK(h, hipGetLastError());
+    return launch_finish_slices(h);
+}
+
+// q0..q8 with the step vector p
+int launch_vec_reduce(sfmba_handle* h) {
+    hipLaunchKernelGGL(k_vec_reduce, dim3(h->red_grid), dim3(256), 0, h->stream, h->g.as<double>(),
+                       h->si.as<double>(), h->x, h->sg.as<double>(), h->p.as<double>(), (int)h->C, (int)h->P,
+                       h->red_bc, h->part.as<double>());
+    HIPCHK(h, hipGetLastError());
+    return launch_finish_slices(h);
+}
+
+// all-reduce freshly written exchange scalars [first_sum_slot, 12) and the max slot over ranks (no-op
+// on one GPU); stays on the stream.  Only slots written since their last reduction may be included.
+int exchange_scalars(sfmba_handle* h, int first_sum_slot) {
+    CHK(exchange(h, h->scal() + first_sum_slot, kSumSlots - first_sum_slot, 0));
+    CHK(exchange(h, h->scal() + kMaxSlot, 1, 1));
     return 0;
 }
 
-// all-reduce the exchange scalars (multi-GPU) and bring them plus the camera-slice sums to the host:
-// h_scal[0..15] = exchange scalars, h_scal[16..24] = camera-slice q0..q8
+// bring all 32 scalars to the host (h_scal) and wait
 int fetch_scalars(sfmba_handle* h) {
-    CHK(exchange(h, h->scal(), 15, 0));
-    CHK(exchange(h, h->scal() + 15, 1, 1));
     HIPCHK(h, hipMemcpyAsync(h->h_scal, h->scal(), sizeof(double) * kScalSlots, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->h_scal + kScalSlots, h->scal_c.as<double>(), sizeof(double) * kNQ,
-                             hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return 0;
 }
 
-double qsum(const sfmba_handle* h, int q) { return h->h_scal[q] + h->h_scal[kScalSlots + q]; }
+// q_k summed over the camera slice and the (rank-reduced) point slice
+double qsum(const sfmba_handle* h, int q) { return h->h_scal[3 + q] + h->h_scal[kCamSlot + q]; }
 
 int upload_x(sfmba_handle* h, const double* x_host) {
     HIPCHK(h, hipMemcpyAsync(h->x, x_host, sizeof(double) * h->n, hipMemcpyHostToDevice, h->stream));
@@ -345,46 +362,56 @@ int check_ready(sfmba_handle* h, const void* x) {
     return 0;
 }
 
-// (U + diag(Dc)) etc. for the test entry and the solver: Vinv/e, reduced rhs, PCG.  Returns the
-// number of PCG iterations in *iters and the PCG status in *pstat.
-int run_pcg(sfmba_handle* h, const sfmba_options& opt, int* iters, int* pstat) {
-    const int max_it = opt.pcg_max_iter > 0 ? opt.pcg_max_iter : (int)std::max<int64_t>(20, 2 * 6 * h->C);
-    const int every = std::max(1, opt.pcg_check_every);
-    double* dc = h->xk.as<double>();
-    PcgCtrl* ctrl = h->ctrl.as<PcgCtrl>();
+int pcg_max_iters(const sfmba_handle* h, const sfmba_options& opt) {
+    return opt.pcg_max_iter > 0 ? opt.pcg_max_iter : (int)std::max<int64_t>(20, 2 * 6 * h->C);
+}
+
+// x = 0, r = rhs, u = Minv r (acc holds the reduced right-hand side term of the MODE 1 sweep)
+int pcg_start(sfmba_handle* h, const sfmba_options& opt) {
     hipLaunchKernelGGL(k_pcg_init, dim3(1), dim3(1024), 0, h->stream, h->Ugc(), h->acc(), h->Minv.as<double>(),
-                       (int)h->C, dc, h->rk.as<double>(), h->pk.as<double>(), h->sk.as<double>(),
-                       h->uk.as<double>(), opt.pcg_tol, max_it, ctrl);
+                       (int)h->C, h->xk.as<double>(), h->rk.as<double>(), h->pk.as<double>(), h->sk.as<double>(),
+                       h->uk.as<double>(), opt.pcg_tol, pcg_max_iters(h, opt), h->ctrl.as<PcgCtrl>());
     HIPCHK(h, hipGetLastError());
-    PcgCtrl hc{};
-    int launched = 0;
-    // first read-back when the previous solve's iteration count is reached (the device-side done
-    // flag turns surplus launches into no-ops), then every `every` iterations
-    int batch = h->last_pcg_iters > 0 ? std::max(every, h->last_pcg_iters) : every;
-    for (;;) {
-        for (int k = 0; k < batch; ++k) {
-            CHK(launch_schur_sweep<0>(h, h->uk.as<double>(), nullptr, ctrl));
-            CHK(exchange(h, h->acc(), 6 * h->C, 0));
-            hipLaunchKernelGGL(k_pcg_update, dim3(1), dim3(1024), 0, h->stream, h->acc(), h->Dc.as<double>(),
-                               h->Minv.as<double>(), (int)h->C, dc, h->rk.as<double>(), h->pk.as<double>(),
-                               h->sk.as<double>(), h->uk.as<double>(), ctrl);
-            HIPCHK(h, hipGetLastError());
-            ++launched;
-        }
-        HIPCHK(h, hipMemcpyAsync(&hc, ctrl, sizeof hc, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        if (hc.done != 0 || launched > max_it + batch) break;
-        batch = every;
+    return 0;
+}
+
+// enqueue `count` PCG iterations (sweep + all-reduce + update); iterations after convergence are
+// device-side no-ops, so over-enqueueing is harmless and deterministic
+int pcg_enqueue(sfmba_handle* h, int count) {
+    PcgCtrl* ctrl = h->ctrl.as<PcgCtrl>();
+    for (int k = 0; k < count; ++k) {
+        CHK(launch_schur_sweep<0>(h, h->uk.as<double>(), nullptr, ctrl));
+        CHK(exchange(h, h->acc(), 6 * h->C, 0));
+        hipLaunchKernelGGL(k_pcg_update, dim3(1), dim3(1024), 0, h->stream, h->acc(), h->Dc.as<double>(),
+                           h->Minv.as<double>(), (int)h->C, h->xk.as<double>(), h->rk.as<double>(),
+                           h->pk.as<double>(), h->sk.as<double>(), h->uk.as<double>(), ctrl);
+        HIPCHK(h, hipGetLastError());
     }
+    return 0;
+}
+
+int pcg_read(sfmba_handle* h, PcgCtrl* hc) {
+    HIPCHK(h, hipMemcpyAsync(hc, h->ctrl.p, sizeof *hc, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
 #ifdef SFMBA_STAMPS
     fprintf(stderr, "[stamps] k_pcg_update phases (us):");
-    for (int k = 1; k < 8; ++k) fprintf(stderr, " %.2f", (double)(hc.stamp[k] - hc.stamp[k - 1]) * 0.01);
-    fprintf(stderr, "  total %.2f\n", (double)(hc.stamp[7] - hc.stamp[0]) * 0.01);
+    for (int k = 1; k < 8; ++k) fprintf(stderr, " %.2f", (double)(hc->stamp[k] - hc->stamp[k - 1]) * 0.01);
+    fprintf(stderr, "  total %.2f\n", (double)(hc->stamp[7] - hc->stamp[0]) * 0.01);
 #endif
-    h->last_pcg_iters = hc.iters;
-    *iters = hc.iters;
-    *pstat = hc.done;
     return 0;
+}
+
+// poll until the device reports the PCG finished
+int pcg_finish_polling(sfmba_handle* h, const sfmba_options& opt, PcgCtrl* hc) {
+    const int every = std::max(1, opt.pcg_check_every);
+    const int cap = pcg_max_iters(h, opt) + every;
+    int launched = 0;
+    for (;;) {
+        CHK(pcg_enqueue(h, every));
+        launched += every;
+        CHK(pcg_read(h, hc));
+        if (hc->done != 0 || launched > cap) return 0;
+    }
 }
 
 void print_center(const char* s) {
@@ -470,7 +497,7 @@ int sfmba_set_stream(sfmba_handle* h, void* hip_stream) {
     return 0;
 }
 
-int64_t sfmba_exchange_doubles(int64_t n_cameras) { return 33 * n_cameras + kScalSlots; }
+int64_t sfmba_exchange_doubles(int64_t n_cameras) { return 33 * n_cameras + kScalSlots; }   // kScalSlots = 32
 
 int sfmba_set_exchange(sfmba_handle* h, void* arena, int64_t arena_doubles, sfmba_allreduce_fn fn,
                        void* ctx, int64_t n_obs_total) {
@@ -564,9 +591,12 @@ int sfmba_set_problem(sfmba_handle* h, int64_t C, int64_t P, int64_t N, const in
     HIPCHK(h, h->xb.ensure(sizeof(double) * h->n));
     HIPCHK(h, h->tabA.ensure(sizeof(double) * kCamTab * C));
     HIPCHK(h, h->tabB.ensure(sizeof(double) * kCamTab * C));
-    HIPCHK(h, h->r.ensure(sizeof(double) * 2 * ld));
-    HIPCHK(h, h->Jc.ensure(sizeof(double) * 12 * ld));
-    HIPCHK(h, h->Jp.ensure(sizeof(double) * 6 * ld));
+    for (int js = 0; js < 2; ++js) {
+        HIPCHK(h, h->r[js].ensure(sizeof(double) * 2 * ld));
+        HIPCHK(h, h->Jc[js].ensure(sizeof(double) * 12 * ld));
+        HIPCHK(h, h->Jp[js].ensure(sizeof(double) * 6 * ld));
+    }
+    h->jcur = 0;
     HIPCHK(h, h->t1.ensure(sizeof(double) * 2 * ld));
     HIPCHK(h, h->V.ensure(sizeof(double) * 6 * P));
     HIPCHK(h, h->Vinv.ensure(sizeof(double) * 6 * P));
@@ -583,9 +613,9 @@ int sfmba_set_problem(sfmba_handle* h, int64_t C, int64_t P, int64_t N, const in
     HIPCHK(h, h->pk.ensure(sizeof(double) * 6 * C));
     HIPCHK(h, h->sk.ensure(sizeof(double) * 6 * C));
     HIPCHK(h, h->uk.ensure(sizeof(double) * 6 * C));
+    h->red_bc = grid_1d(6 * C, 256, 32);
+    h->red_grid = h->red_bc + grid_1d(3 * P, 256, 992);
     HIPCHK(h, h->part.ensure(sizeof(double) * (size_t)(2048 * kNQ)));
-    HIPCHK(h, h->scal_c.ensure(sizeof(double) * 16));
-    HIPCHK(h, h->tmp_out.ensure(sizeof(double) * 16));
     HIPCHK(h, h->ctrl.ensure(sizeof(PcgCtrl)));
     if (h->nb_passes > 0) {
         const int per = (27 + h->nb_passes - 1) / h->nb_passes;
@@ -605,7 +635,8 @@ int sfmba_set_problem(sfmba_handle* h, int64_t C, int64_t P, int64_t N, const in
     if (!ranges.empty())
         HIPCHK(h, hipMemcpyAsync(h->ranges.p, ranges.data(), sizeof(int2) * ranges.size(), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemsetAsync(h->arena, 0, sizeof(double) * (size_t)sfmba_exchange_doubles(C), h->stream));
-    HIPCHK(h, hipMemsetAsync(h->r.p, 0, sizeof(double) * 2 * ld, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->r[0].p, 0, sizeof(double) * 2 * ld, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->r[1].p, 0, sizeof(double) * 2 * ld, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));     // host staging vectors go out of scope
     h->have_problem = true;
     return 0;
@@ -618,13 +649,13 @@ int sfmba_residuals(sfmba_handle* h, const double* x, double* r_out) {
     CHK(upload_x(h, x));
     CHK(launch_cam_table(h, h->x, h->tab));
     int np = 0;
-    CHK((launch_resjac<false, true>(h, h->x, h->tab, &np)));
+    CHK((launch_resjac<false, true>(h, h->x, h->tab, h->jcur, &np)));
     if (!h->permuted) {
-        HIPCHK(h, hipMemcpyAsync(r_out, h->r.p, sizeof(double) * 2 * h->N, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(r_out, h->r[h->jcur].p, sizeof(double) * 2 * h->N, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
     } else {
         std::vector<double> tmp(2 * h->N);
-        HIPCHK(h, hipMemcpyAsync(tmp.data(), h->r.p, sizeof(double) * 2 * h->N, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(tmp.data(), h->r[h->jcur].p, sizeof(double) * 2 * h->N, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
         for (int64_t k = 0; k < h->N; ++k) {
             r_out[2 * h->order[k]] = tmp[2 * k];
@@ -641,15 +672,15 @@ int sfmba_residual_jacobian(sfmba_handle* h, const double* x, double* r_out, dou
     CHK(upload_x(h, x));
     CHK(launch_cam_table(h, h->x, h->tab));
     int np = 0;
-    CHK((launch_resjac<true, true>(h, h->x, h->tab, &np)));
+    CHK((launch_resjac<true, true>(h, h->x, h->tab, h->jcur, &np)));
     DevBuf jc_rm, jp_rm;
     HIPCHK(h, jc_rm.ensure(sizeof(double) * 12 * h->N));
     HIPCHK(h, jp_rm.ensure(sizeof(double) * 6 * h->N));
-    hipLaunchKernelGGL(k_unpack_jac, dim3((h->N + 255) / 256), dim3(256), 0, h->stream, h->Jc.as<double>(),
-                       h->Jp.as<double>(), (int)h->N, h->ld, jc_rm.as<double>(), jp_rm.as<double>());
+    hipLaunchKernelGGL(k_unpack_jac, dim3((h->N + 255) / 256), dim3(256), 0, h->stream, h->Jc[h->jcur].as<double>(),
+                       h->Jp[h->jcur].as<double>(), (int)h->N, h->ld, jc_rm.as<double>(), jp_rm.as<double>());
     HIPCHK(h, hipGetLastError());
     std::vector<double> tr(2 * h->N), tc(12 * h->N), tp(6 * h->N);
-    HIPCHK(h, hipMemcpyAsync(tr.data(), h->r.p, sizeof(double) * 2 * h->N, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(tr.data(), h->r[h->jcur].p, sizeof(double) * 2 * h->N, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(tc.data(), jc_rm.p, sizeof(double) * 12 * h->N, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(tp.data(), jp_rm.p, sizeof(double) * 6 * h->N, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -668,7 +699,7 @@ int sfmba_normal_blocks(sfmba_handle* h, const double* x, double* U, double* V, 
     CHK(upload_x(h, x));
     CHK(launch_cam_table(h, h->x, h->tab));
     int np = 0;
-    CHK((launch_resjac<true, true>(h, h->x, h->tab, &np)));
+    CHK((launch_resjac<true, true>(h, h->x, h->tab, h->jcur, &np)));
     CHK(launch_normal_blocks(h));
     CHK(exchange(h, h->Ugc(), 27 * h->C, 0));
     std::vector<double> ugc(27 * h->C);
@@ -690,7 +721,7 @@ int sfmba_schur_matvec(sfmba_handle* h, const double* x, const double* dc, const
     CHK(upload_x(h, x));
     CHK(launch_cam_table(h, h->x, h->tab));
     int np = 0;
-    CHK((launch_resjac<true, true>(h, h->x, h->tab, &np)));
+    CHK((launch_resjac<true, true>(h, h->x, h->tab, h->jcur, &np)));
     CHK(launch_normal_blocks(h));
     CHK(exchange(h, h->Ugc(), 27 * h->C, 0));
     // stage dp in e (as explicit diagonal), v in pk -- camera vectors are plane-major on the device
@@ -702,7 +733,7 @@ int sfmba_schur_matvec(sfmba_handle* h, const double* x, const double* dc, const
     HIPCHK(h, hipMemcpyAsync(h->pk.p, vp.data(), sizeof(double) * 6 * C, hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(k_point_prep, dim3((h->P + 255) / 256), dim3(256), 0, h->stream, h->V.as<double>(),
                        h->gp.as<double>(), (const double*)nullptr, h->e.as<double>(), (int)h->P, 0.0,
-                       h->Vinv.as<double>(), (double*)nullptr);
+                       (const double*)nullptr, h->Vinv.as<double>(), (double*)nullptr);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemsetAsync(h->acc(), 0, sizeof(double) * 6 * C, h->stream));
     CHK(launch_schur_sweep<0>(h, h->pk.as<double>(), nullptr, nullptr));
@@ -723,15 +754,13 @@ int sfmba_time_kernel(sfmba_handle* h, const double* x, int32_t which, int32_t r
     CHK(upload_x(h, x));
     CHK(launch_cam_table(h, h->x, h->tab));
     int np = 0;
-    CHK((launch_resjac<true, true>(h, h->x, h->tab, &np)));
+    CHK((launch_resjac<true, true>(h, h->x, h->tab, h->jcur, &np)));
     if (which >= 2) {
         CHK(launch_normal_blocks(h));
-        hipLaunchKernelGGL(k_update_scale, dim3(grid_1d(h->n, 256, 2048)), dim3(256), 0, h->stream, h->Ugc(),
-                           h->V.as<double>(), h->gp.as<double>(), (int)h->C, (int)h->P, 1, h->si.as<double>(),
-                           h->g.as<double>(), h->sg.as<double>());
+        CHK(launch_update_scale(h, 1));
         hipLaunchKernelGGL(k_point_prep, dim3((h->P + 255) / 256), dim3(256), 0, h->stream, h->V.as<double>(),
                            h->gp.as<double>(), h->si.as<double>() + 6 * h->C, (const double*)nullptr, (int)h->P,
-                           1e-6, h->Vinv.as<double>(), h->e.as<double>());
+                           1e-6, (const double*)nullptr, h->Vinv.as<double>(), h->e.as<double>());
         HIPCHK(h, hipMemsetAsync(h->acc(), 0, sizeof(double) * 6 * h->C, h->stream));
         HIPCHK(h, hipMemcpyAsync(h->pk.p, h->g.p, sizeof(double) * 6 * h->C, hipMemcpyDeviceToDevice, h->stream));
     }
@@ -742,8 +771,8 @@ int sfmba_time_kernel(sfmba_handle* h, const double* x, int32_t which, int32_t r
     HIPCHK(h, hipEventRecord(e0, h->stream));
     for (int k = 0; k < reps; ++k) {
         switch (which) {
-            case 0: CHK((launch_resjac<true, true>(h, h->x, h->tab, &np))); break;
-            case 1: CHK((launch_resjac<false, false>(h, h->x, h->tab, &np))); break;
+            case 0: CHK((launch_resjac<true, true>(h, h->x, h->tab, h->jcur, &np))); break;
+            case 1: CHK((launch_resjac<false, false>(h, h->x, h->tab, h->jcur, &np))); break;
             case 2: CHK(launch_normal_blocks(h)); break;
             case 3: CHK(launch_schur_sweep<0>(h, h->pk.as<double>(), nullptr, nullptr)); break;
             default: return fail(h, -1, "unknown kernel id %d", which);
@@ -773,39 +802,47 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
     const int64_t C = h->C, P = h->P, n = h->n;
     const int64_t max_nfev = opt.max_nfev > 0 ? opt.max_nfev : 100 * (6 * C + 3 * P);
     const double m_total = 2.0 * (double)h->N_total;
+    double* sc = h->scal();
 
     h->x = h->xa.as<double>(); h->x_new = h->xb.as<double>();
     h->tab = h->tabA.as<double>(); h->tab_new = h->tabB.as<double>();
+    h->jcur = 0;
     CHK(upload_x(h, x_inout));
     const double t_dev0 = now_s();
 
+    // Host/device hand-offs per outer iteration: ONE read-back after the whole linear phase
+    // (Cauchy product, Schur PCG, back-substitution, Gram/dot reductions are enqueued without the
+    // host seeing intermediate values: the regularisation term is computed by k_reg on the device
+    // and the PCG stops itself through its device-side control block) and ONE per trial step.
     std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
-    auto eval_jac = [&]() -> int {            // K0 + K1 at h->x, cost partials -> scal[0]
-        CHK(launch_cam_table(h, h->x, h->tab));
+    auto eval_jac = [&](const double* x, double* tab, int js) -> int {   // K0 + K1, sum r^2 -> scalar 0
+        CHK(launch_cam_table(h, x, tab));
         int np = 0;
         if (opt.profile) {
             hipEvent_t a, b;
             HIPCHK(h, hipEventCreate(&a)); HIPCHK(h, hipEventCreate(&b));
             HIPCHK(h, hipEventRecord(a, h->stream));
-            CHK((launch_resjac<true, true>(h, h->x, h->tab, &np)));
+            CHK((launch_resjac<true, true>(h, x, tab, js, &np)));
             HIPCHK(h, hipEventRecord(b, h->stream));
             evs.emplace_back(a, b);
         } else {
-            CHK((launch_resjac<true, true>(h, h->x, h->tab, &np)));
+            CHK((launch_resjac<true, true>(h, x, tab, js, &np)));
         }
-        CHK(launch_finish(h, h->part.as<double>(), np, 1, 0, h->scal()));
+        CHK(launch_finish(h, h->part.as<double>(), np, 1, 0));
+        return 0;
+    };
+    auto linearise = [&](int first) -> int {      // normal blocks, scale, gradient, q0..q4 at h->x
+        CHK(launch_normal_blocks(h));
+        CHK(exchange(h, h->Ugc(), 27 * C, 0));
+        CHK(launch_update_scale(h, first));
+        CHK(exchange_scalars(h, 4));                 // q1..q8 and max|g| of the point slice
         return 0;
     };
 
     // f0, J0 (least_squares.py:838, 903-912)
-    CHK(eval_jac());
-    CHK(launch_normal_blocks(h));
-    CHK(exchange(h, h->Ugc(), 27 * C, 0));
-    hipLaunchKernelGGL(k_update_scale, dim3(grid_1d(n, 256, 2048)), dim3(256), 0, h->stream, h->Ugc(),
-                       h->V.as<double>(), h->gp.as<double>(), (int)C, (int)P, 1, h->si.as<double>(),
-                       h->g.as<double>(), h->sg.as<double>());
-    HIPCHK(h, hipGetLastError());
-    CHK(launch_vec_reduce(h, false));
+    CHK(eval_jac(h->x, h->tab, h->jcur));
+    CHK(exchange(h, sc, 1, 0));                      // sum r^2
+    CHK(linearise(1));
     CHK(fetch_scalars(h));
     double cost = 0.5 * h->h_scal[0];
     if (!std::isfinite(cost)) return fail(h, -2, "Residuals are not finite in the initial point.");
@@ -817,61 +854,72 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
     int status = -1;
     double step_norm = 0.0, actual_reduction = 0.0, g_norm = 0.0, reg_term = 0.0;
     bool have_red = false;
+    int pcg_guess = 0;                                          // iterations the previous solve needed
     if (opt.verbose >= 2) print_header();
 
     for (;;) {                                                  // trf.py:450
-        g_norm = std::max(h->h_scal[15], h->h_scal[kScalSlots + 0]);
+        // ---- enqueue the whole linear phase ---------------------------------------------------
+        int np = 0;
+        CHK(launch_jdot(h, &np));                               // t1 = J D^2 g, G11 = |t1|^2
+        CHK(launch_finish(h, h->part.as<double>(), np, 1, 1));
+        CHK(exchange(h, sc + 1, 1, 0));
+        hipLaunchKernelGGL(k_reg, dim3(1), dim3(64), 0, h->stream, sc, Delta, opt.reg_min);   // trf.py:471-475
+        hipLaunchKernelGGL(k_point_prep, dim3((P + 255) / 256), dim3(256), 0, h->stream, h->V.as<double>(),
+                           h->gp.as<double>(), h->si.as<double>() + 6 * C, (const double*)nullptr, (int)P,
+                           0.0, sc + kRegSlot, h->Vinv.as<double>(), h->e.as<double>());
+        hipLaunchKernelGGL(k_cam_prep, dim3((C + 63) / 64), dim3(64), 0, h->stream, h->Ugc(), h->si.as<double>(),
+                           (const double*)nullptr, (int)C, 0.0, sc + kRegSlot, h->Dc.as<double>(),
+                           h->Minv.as<double>());
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipMemsetAsync(h->acc(), 0, sizeof(double) * 6 * C, h->stream));
+        CHK(launch_schur_sweep<1>(h, nullptr, h->e.as<double>(), nullptr));      // reduced rhs
+        CHK(exchange(h, h->acc(), 6 * C, 0));
+        CHK(pcg_start(h, opt));                                 // replaces lsmr, trf.py:477-480
+        PcgCtrl hc{};
+        if (pcg_guess > 0) {
+            CHK(pcg_enqueue(h, pcg_guess + 2));                 // speculative: no read-back
+        } else {
+            CHK(pcg_finish_polling(h, opt, &hc));
+        }
+        auto tail = [&]() -> int {                              // back-substitution + model products
+            CHK(launch_backsub(h, &np));
+            CHK(launch_finish(h, h->part.as<double>(), np, 2, 2));
+            CHK(launch_vec_reduce(h));
+            CHK(exchange_scalars(h, 2));             // G12, G22, q1..q8, max|g|
+            return 0;
+        };
+        CHK(tail());
+        if (pcg_guess > 0) {
+            HIPCHK(h, hipMemcpyAsync(&hc, h->ctrl.p, sizeof hc, hipMemcpyDeviceToHost, h->stream));
+            CHK(fetch_scalars(h));                              // hand-off 1
+            if (hc.done == 0) {                                 // guess too small: finish and redo the tail
+                CHK(pcg_finish_polling(h, opt, &hc));
+                CHK(tail());
+                CHK(fetch_scalars(h));
+            }
+        } else {
+            CHK(fetch_scalars(h));
+        }
+        if (hc.done == 3) return fail(h, -3, "PCG breakdown: reduced camera system is not positive definite");
+
+        // ---- loop head of trf.py:450-459, evaluated now that the scalars are on the host -----------
+        g_norm = std::max(h->h_scal[kMaxSlot], h->h_scal[kCamSlot + 0]);
         if (g_norm < opt.gtol) status = 1;
         if (opt.verbose >= 2) print_iter(iteration, nfev, cost, have_red, actual_reduction, step_norm, g_norm);
         if (status != -1 || nfev >= max_nfev || (opt.max_iter > 0 && iteration >= opt.max_iter)) break;
+        pcg_total += hc.iters;
+        pcg_guess = hc.iters;
+        reg_term = h->h_scal[kRegSlot];
 
         const double a11 = qsum(h, 1);                          // |g_h|^2
         const double x_norm = std::sqrt(qsum(h, 3));
         const double b11 = qsum(h, 4);                          // |D^2 g|^2
-        // 1-D Cauchy problem along -g_h -> regularisation, trf.py:471-475
-        int np = 0;
-        CHK(launch_jdot(h, &np));
-        CHK(launch_finish(h, h->part.as<double>(), np, 1, 0, h->scal() + 10));
-        CHK(exchange(h, h->scal() + 10, 1, 0));
-        HIPCHK(h, hipMemcpyAsync(h->h_scal + 10, h->scal() + 10, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        const double G11 = h->h_scal[10];
-        {
-            const double a = 0.5 * G11, b = -a11;
-            const double to_tr = Delta / std::sqrt(a11);
-            double best = 0.0;                                  // t = 0
-            const double y_ub = to_tr * (a * to_tr + b);
-            if (y_ub < best) best = y_ub;
-            if (a != 0.0) {
-                const double ext = -0.5 * b / a;
-                if (ext > 0.0 && ext < to_tr) { const double y = ext * (a * ext + b); if (y < best) best = y; }
-            }
-            reg_term = std::max(-best / (Delta * Delta), opt.reg_min);
-        }
-        // damped Gauss-Newton step through the Schur complement (replaces lsmr, trf.py:477-480)
-        hipLaunchKernelGGL(k_point_prep, dim3((P + 255) / 256), dim3(256), 0, h->stream, h->V.as<double>(),
-                           h->gp.as<double>(), h->si.as<double>() + 6 * C, (const double*)nullptr, (int)P,
-                           reg_term, h->Vinv.as<double>(), h->e.as<double>());
-        hipLaunchKernelGGL(k_cam_prep, dim3((C + 63) / 64), dim3(64), 0, h->stream, h->Ugc(), h->si.as<double>(),
-                           (const double*)nullptr, (int)C, reg_term, h->Dc.as<double>(), h->Minv.as<double>());
-        HIPCHK(h, hipGetLastError());
-        HIPCHK(h, hipMemsetAsync(h->acc(), 0, sizeof(double) * 6 * C, h->stream));
-        CHK(launch_schur_sweep<1>(h, nullptr, h->e.as<double>(), nullptr));
-        CHK(exchange(h, h->acc(), 6 * C, 0));
-        int pcg_it = 0, pcg_stat = 0;
-        CHK(run_pcg(h, opt, &pcg_it, &pcg_stat));
-        pcg_total += pcg_it;
-        if (pcg_stat == 3) return fail(h, -3, "PCG breakdown: reduced camera system is not positive definite");
-        CHK(launch_backsub(h, &np));
-        CHK(launch_finish(h, h->part.as<double>(), np, 2, 0, h->scal() + 11));
-        CHK(launch_vec_reduce(h, true));
-        CHK(fetch_scalars(h));
-        const double G12 = h->h_scal[11], G22 = h->h_scal[12];
+        const double G11 = h->h_scal[1], G12 = h->h_scal[2], G22 = h->h_scal[3];
         const double a12 = qsum(h, 5), a22 = qsum(h, 6), b12 = qsum(h, 7), b22 = qsum(h, 8);
         // 2-D subspace span(g_h, gn_h), orthonormalised by Gram-Schmidt (trf.py:481-485)
         const double s11 = std::sqrt(a11);
         const double r12 = a12 / s11;
-        double r22sq = a22 - r12 * r12;
+        const double r22sq = a22 - r12 * r12;
         const bool two_d = r22sq > 1e-28 * a22 && r22sq > 0.0;
         const double r22 = two_d ? std::sqrt(r22sq) : 1.0;
         double B[3], gS[2] = {s11, 0.0};
@@ -885,7 +933,7 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
 
         actual_reduction = -1.0;
         double cost_new = cost;
-        bool terminated = false;
+        const int jalt = h->jcur ^ 1;
         while (actual_reduction <= 0.0 && nfev < max_nfev) {    // trf.py:488
             double pS[2];
             solve_trust_region_2d(B, gS, Delta, pS);
@@ -899,13 +947,12 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
             hipLaunchKernelGGL(k_step, dim3(grid_1d(n, 256, 2048)), dim3(256), 0, h->stream, h->x,
                                h->sg.as<double>(), h->p.as<double>(), c1, c2, n, h->x_new);
             HIPCHK(h, hipGetLastError());
-            CHK(launch_cam_table(h, h->x_new, h->tab_new));
-            int npr = 0;
-            CHK((launch_resjac<false, false>(h, h->x_new, h->tab_new, &npr)));
-            CHK(launch_finish(h, h->part.as<double>(), npr, 1, 0, h->scal()));
-            CHK(exchange(h, h->scal(), 1, 0));
-            HIPCHK(h, hipMemcpyAsync(h->h_scal, h->scal(), sizeof(double), hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(h, hipStreamSynchronize(h->stream));
+            // the trial point is evaluated WITH its Jacobian into the spare buffer set: when the step is
+            // accepted (the common case) nothing has to be recomputed
+            CHK(eval_jac(h->x_new, h->tab_new, jalt));
+            CHK(exchange(h, sc, 1, 0));
+            HIPCHK(h, hipMemcpyAsync(h->h_scal, sc, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));         // hand-off 2
             ++nfev;
             cost_new = 0.5 * h->h_scal[0];
             if (!std::isfinite(cost_new)) {                     // trf.py:504-506
@@ -918,30 +965,28 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
                                                       step_h_norm > 0.95 * Delta, &ratio);
             step_norm = std::sqrt(std::max(0.0, c1 * c1 * b11 + 2.0 * c1 * c2 * b12 + c2 * c2 * b22));
             const int term = check_termination(actual_reduction, cost, step_norm, x_norm, ratio, opt.ftol, opt.xtol);
-            if (term != 0) { status = term; terminated = true; break; }
+            if (term != 0) { status = term; break; }
             Delta = Delta_new;
         }
         have_red = true;
         if (actual_reduction > 0.0) {                           // trf.py:528
             std::swap(h->x, h->x_new);
             std::swap(h->tab, h->tab_new);
+            h->jcur = jalt;                                     // J, f of the accepted point are already there
             cost = cost_new;
-            CHK(eval_jac());
             ++njev;
-            CHK(launch_normal_blocks(h));
-            CHK(exchange(h, h->Ugc(), 27 * C, 0));
-            hipLaunchKernelGGL(k_update_scale, dim3(grid_1d(n, 256, 2048)), dim3(256), 0, h->stream, h->Ugc(),
-                               h->V.as<double>(), h->gp.as<double>(), (int)C, (int)P, 0, h->si.as<double>(),
-                               h->g.as<double>(), h->sg.as<double>());
-            HIPCHK(h, hipGetLastError());
-            CHK(launch_vec_reduce(h, false));
-            CHK(fetch_scalars(h));
+            CHK(linearise(0));                                  // enqueued only; read with the next hand-off
         } else {
             step_norm = 0.0;
             actual_reduction = 0.0;
         }
-        (void)terminated;
         ++iteration;
+        if (status != -1) {                                     // terminated inside the step loop
+            CHK(fetch_scalars(h));
+            g_norm = std::max(h->h_scal[kMaxSlot], h->h_scal[kCamSlot + 0]);
+            if (opt.verbose >= 2) print_iter(iteration, nfev, cost, have_red, actual_reduction, step_norm, g_norm);
+            break;
+        }
     }
     if (status == -1) status = 0;
 
@@ -977,7 +1022,7 @@ int sfmba_get_fun_grad(sfmba_handle* h, double* fun_out, double* grad_out) {
     if (!h->have_problem || !h->solved) return fail(h, -1, "no completed sfmba_solve on this handle");
     if (fun_out) {
         std::vector<double> tmp(2 * h->N);
-        HIPCHK(h, hipMemcpyAsync(tmp.data(), h->r.p, sizeof(double) * 2 * h->N, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(tmp.data(), h->r[h->jcur].p, sizeof(double) * 2 * h->N, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
         for (int64_t k = 0; k < h->N; ++k) {
             const int64_t d = h->permuted ? h->order[k] : k;
