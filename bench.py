@@ -82,6 +82,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg4", choices=["cfg2", "cfg3", "cfg4"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="use the collective path even at world size 1 (plumbing check)")
+    ap.add_argument("--exchange", default="native", choices=["native", "torch"],
+                    help="native: RCCL called from C++ on the solver stream; torch: torch.distributed callback")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -100,10 +104,12 @@ def main():
     C, P, N = sfmba.synthetic.CONFIGS[a.workload]
     stream = torch.cuda.Stream()
     be = sfmba.Backend(local_rank)
-    if world > 1:
+    if world > 1 or a.force_exchange:
         import torch.distributed as td
+        if world == 1 and "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         td.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        pb = sdist.make_sharded_problem(C, P, N, rank, world, seed=0)
+        pb = sdist.make_sharded_problem(C, P, N, rank, world, seed=0) if world > 1 else sfmba.make_problem(C, P, N, seed=0)
     else:
         td = None
         pb = sfmba.make_problem(C, P, N, seed=0)
@@ -111,7 +117,9 @@ def main():
     with torch.cuda.stream(stream):
         be.set_stream(stream.cuda_stream)
         be.set_problem(*pb.args)
-        ex = sdist.Exchange(be, n_obs_local=N, group=None) if world > 1 else None
+        ex = None
+        if td is not None:
+            ex = (sdist.NativeComm if a.exchange == "native" else sdist.Exchange)(be, n_obs_local=N)
 
         opt = be.default_options()
         opt.ftol, opt.xtol, opt.gtol = 1e-10, 1e-8, 1e-8           # the reference's ftol, scipy defaults
@@ -126,7 +134,8 @@ def main():
                 if res.iterations <= 0:
                     raise RuntimeError("solver made no progress")
                 results.append((int(res.iterations), float(res.rmse), float(res.rmse0), float(res.resjac_avg_us),
-                                int(res.resjac_launches), int(res.pcg_iterations), int(res.status)))
+                                int(res.resjac_launches), int(res.pcg_iterations), int(res.status),
+                                float(res.seconds_total)))
                 left -= int(res.iterations)
             return results
 
@@ -135,6 +144,10 @@ def main():
                 td.barrier()
             torch.cuda.synchronize()
 
+        # prime clocks, code objects and the host launch path (set-up, not steps): 50 launches of each
+        # of the four sweep kernels
+        primed = {name: be.time_kernel(pb.x0, which, 50) for which, name in
+                  ((0, "resjac"), (1, "residual"), (2, "normal_blocks"), (3, "schur_sweep"))}
         run_iterations(max(1, a.warmup))
         barrier()
         t0 = time.perf_counter()
@@ -173,7 +186,9 @@ def main():
                        "n_obs_total": N * world, "n_points_total": P * world, "n_cameras": C,
                        "solves_in_timed_region": len(results),
                        "iterations_per_solve": [r[0] for r in results],
-                       "pcg_iterations_per_solve": [r[5] for r in results]},
+                       "pcg_iterations_per_solve": [r[5] for r in results],
+                       "ms_per_solve": [round(1e3 * r[7], 3) for r in results],
+                       "back_to_back_kernel_us": {k: round(v, 2) for k, v in primed.items()}},
             "final_rmse_px": full[0][1], "initial_rmse_px": full[0][2],
             "roofline": {"kernel": "k_resjac (residual + 2x6/2x3 Jacobian sweep)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -106,6 +106,16 @@ int64_t sfmba_exchange_doubles(int64_t n_cameras);
 int  sfmba_set_exchange(sfmba_handle* h, void* arena, int64_t arena_doubles,
                         sfmba_allreduce_fn fn, void* ctx, int64_t n_obs_total);
 
+/* Native collective path: the library all-reduces its exchange arena itself with RCCL over xGMI
+ * (librccl.so.1 is opened at run time; ncclAllReduce is enqueued on the handle's stream, so there is
+ * no host synchronisation and no interpreter on the data path).  Rank 0 obtains the 128-byte id,
+ * the host shim distributes it to all ranks (torch.distributed broadcast in sfmba.dist), every rank
+ * calls sfmba_comm_init.  world == 1 is valid.  sfmba_comm_destroy returns to single-process mode. */
+int  sfmba_comm_get_unique_id(void* id128_out);
+int  sfmba_comm_init(sfmba_handle* h, const void* id128, int32_t rank, int32_t world,
+                     int64_t n_obs_total);
+int  sfmba_comm_destroy(sfmba_handle* h);
+
 /* ---- compute_residuals (bundle_adjustment.py:35-42) ----------------------------------------- */
 /* x: (6C+3P) float64 -> r_out: (2N) float64, interleaved x,y in the caller's observation order. */
 int  sfmba_residuals(sfmba_handle* h, const double* x, double* r_out);

@@ -7,8 +7,11 @@
 //
 // HBM layout (fp64):
 //   cam_idx, pt_idx   int32  [ld]          uv, r   double2 [ld]   (ld = N rounded up to 256)
-//   Jc                double [12][ld]      plane k = 6*row + col  (row: x/y residual; col: w0 w1 w2 T0 T1 T2)
-//   Jp                double [6][ld]       plane k = 3*row + col
+//   Jc                double2 [6][ld]      pair-plane m holds entries (2m, 2m+1) of the row-major 2x6 block
+//                                          (entry 6*row + col; row: x/y residual; col: w0 w1 w2 T0 T1 T2)
+//   Jp                double2 [3][ld]      pair-plane m holds entries (2m, 2m+1) of the row-major 2x3 block
+//                     -> every stream moves 16 B per lane (global_load/store_dwordx4, 1 KiB per wave
+//                        instruction) with ONE observation per lane
 //   camtab            double [C][17]       R(9) T(3) w(3) b c   -- staged in LDS by the sweeps
 //   per point         V[P][6] (upper), Vinv[P][6], gp[P][3], dp[P][3] ...
 //   per camera        Ugc[C][27] = U upper (21) | gc (6)
@@ -176,10 +179,26 @@ __device__ __forceinline__ void observe(const double* __restrict__ t, double X, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// K1 / K1r: residual (+ Jacobian) sweep.  One lane owns two consecutive observations so that every
-// stream is moved 16 B per lane (global_load/store_dwordx4, 1 KiB per wave instruction); the camera
-// table sits in LDS (LDS_TAB) or, past 160 KiB, in L2.  cost_part[block] = sum r^2 of the block.
+// K1 / K1r: residual (+ Jacobian) sweep.  One lane per observation, one wavefront per 64-observation
+// batch, persistent 1024-thread workgroups (one per CU) that stage the camera table in LDS (LDS_TAB;
+// past 160 KiB it stays in L2) and grid-stride over the observations.  All streams are coalesced
+// 16 B/lane except the two int32 index streams; points are gathered (point-major order: neighbouring
+// lanes share a point).  The loop is software pipelined by hand: indices are fetched two batches
+// ahead and uv/point one batch ahead, so the loads of the next batch are in flight while the 9+1
+// dwordx4 stores of the current one issue (the kernel is store-issue/HBM-write bound: 160 of its
+// 184 B per observation are writes).  cost_part[block] = sum r^2 of the block.
 // ---------------------------------------------------------------------------------------------
+// 16-byte streaming store of two doubles (one global_store_dwordx4)
+__device__ __forceinline__ void st16(double* __restrict__ p, double a, double b) {
+#if defined(SFMBA_K1_NT)
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    v2d v = {a, b};
+    __builtin_nontemporal_store(v, reinterpret_cast<v2d*>(p));
+#else
+    *reinterpret_cast<double2*>(p) = make_double2(a, b);
+#endif
+}
+
 template <bool LDS_TAB, bool JAC, bool STORE_R>
 __global__ __launch_bounds__(kSweepThreads) void k_resjac(
     const double* __restrict__ camtab, const double* __restrict__ pts, const int* __restrict__ cam_idx,
@@ -188,42 +207,66 @@ __global__ __launch_bounds__(kSweepThreads) void k_resjac(
     double* __restrict__ cost_part) {
     extern __shared__ __align__(16) double smem[];
     __shared__ double red[kWavesPerSweepBlock];
-    if (LDS_TAB) {
-        const int n = C * kCamTab;
-        for (int i = threadIdx.x; i < n; i += blockDim.x) smem[i] = camtab[i];
+    const int stride = gridDim.x * blockDim.x;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // pipeline registers: batch i (uv, X ready), batch i+stride (indices ready)
+    int c0 = 0, p0 = 0, c1 = 0, p1 = 0;
+    double2 uv0 = make_double2(0.0, 0.0);
+    double X0 = 0.0, Y0 = 0.0, Z0 = 0.0;
+    if (i < N) { c0 = cam_idx[i]; p0 = pt_idx[i]; uv0 = *reinterpret_cast<const double2*>(uv + 2 * (size_t)i); }
+    if (i + stride < N) { c1 = cam_idx[i + stride]; p1 = pt_idx[i + stride]; }
+    if (i < N) { const double* __restrict__ Xp = pts + 3 * (size_t)p0; X0 = Xp[0]; Y0 = Xp[1]; Z0 = Xp[2]; }
+    if (LDS_TAB) {                               // stage the camera table while those loads fly
+        const int n2 = (C * kCamTab) >> 1;
+        const double2* __restrict__ src = reinterpret_cast<const double2*>(camtab);
+        double2* __restrict__ dst = reinterpret_cast<double2*>(smem);
+        for (int k = threadIdx.x; k < n2; k += blockDim.x) dst[k] = src[k];
+        if (((C * kCamTab) & 1) && threadIdx.x == 0) smem[C * kCamTab - 1] = camtab[C * kCamTab - 1];
         __syncthreads();
     }
     const double* __restrict__ tab = LDS_TAB ? smem : camtab;
     double acc = 0.0;
-    const int npair = (N + 1) >> 1;
-    for (int pr = blockIdx.x * blockDim.x + threadIdx.x; pr < npair; pr += gridDim.x * blockDim.x) {
-        const int i0 = 2 * pr;
-        const int2 c2 = *reinterpret_cast<const int2*>(cam_idx + i0);
-        const int2 p2 = *reinterpret_cast<const int2*>(pt_idx + i0);
-        const double2 uva = *reinterpret_cast<const double2*>(uv + 2 * (size_t)i0);
-        const double2 uvb = *reinterpret_cast<const double2*>(uv + 2 * (size_t)i0 + 2);
-        const double* __restrict__ Xa = pts + 3 * (size_t)p2.x;
-        const double* __restrict__ Xb = pts + 3 * (size_t)p2.y;
-        const double ax = Xa[0], ay = Xa[1], az = Xa[2];
-        const double bx = Xb[0], by = Xb[1], bz = Xb[2];
-        double jca[12], jpa[6], jcb[12], jpb[6];
-        double rax, ray, rbx, rby;
-        observe<JAC>(tab + c2.x * kCamTab, ax, ay, az, uva.x, uva.y, K, rax, ray, jca, jpa);
-        observe<JAC>(tab + c2.y * kCamTab, bx, by, bz, uvb.x, uvb.y, K, rbx, rby, jcb, jpb);
-        acc += rax * rax + ray * ray;
-        if (i0 + 1 < N) acc += rbx * rbx + rby * rby;
-        if (STORE_R) {
-            *reinterpret_cast<double2*>(r + 2 * (size_t)i0) = make_double2(rax, ray);
-            *reinterpret_cast<double2*>(r + 2 * (size_t)i0 + 2) = make_double2(rbx, rby);
+    while (i < N) {
+        // issue the next batch's loads first
+        const int in = i + stride, in2 = in + stride;
+        int c2 = 0, p2 = 0;
+        double2 uv1 = make_double2(0.0, 0.0);
+        double X1 = 0.0, Y1 = 0.0, Z1 = 0.0;
+        if (in2 < N) { c2 = cam_idx[in2]; p2 = pt_idx[in2]; }
+        if (in < N) {
+            uv1 = *reinterpret_cast<const double2*>(uv + 2 * (size_t)in);
+            const double* __restrict__ Xp = pts + 3 * (size_t)p1;
+            X1 = Xp[0]; Y1 = Xp[1]; Z1 = Xp[2];
         }
+        double jc[12], jp[6], rx, ry;
+#if defined(SFMBA_ABLATE_K1_COMPUTE)     // timing-only ablation: loads + stores, no arithmetic
+        rx = X0 + uv0.x; ry = Y0 + uv0.y;
+        for (int k = 0; k < 12; ++k) jc[k] = Z0 + k + c0;
+        for (int k = 0; k < 6; ++k) jp[k] = Z0 - k;
+#else
+        observe<JAC>(tab + c0 * kCamTab, X0, Y0, Z0, uv0.x, uv0.y, K, rx, ry, jc, jp);
+#endif
+        acc += rx * rx + ry * ry;
+#if defined(SFMBA_ABLATE_K1_STORES)      // timing-only ablation: everything but the Jacobian stores
+        if (STORE_R) st16(r + 2 * (size_t)i, rx, ry);
+        if (JAC) {
+            double sacc = 0.0;
+            for (int k = 0; k < 12; ++k) sacc += jc[k];
+            for (int k = 0; k < 6; ++k) sacc += jp[k];
+            if (sacc == 123.456) Jc[i] = sacc;
+        }
+#else
+        if (STORE_R) st16(r + 2 * (size_t)i, rx, ry);
         if (JAC) {
 #pragma unroll
-            for (int k = 0; k < 12; ++k)
-                *reinterpret_cast<double2*>(Jc + k * ld + i0) = make_double2(jca[k], jcb[k]);
+            for (int m = 0; m < 6; ++m) st16(Jc + 2 * ((size_t)m * ld + i), jc[2 * m], jc[2 * m + 1]);
 #pragma unroll
-            for (int k = 0; k < 6; ++k)
-                *reinterpret_cast<double2*>(Jp + k * ld + i0) = make_double2(jpa[k], jpb[k]);
+            for (int m = 0; m < 3; ++m) st16(Jp + 2 * ((size_t)m * ld + i), jp[2 * m], jp[2 * m + 1]);
         }
+#endif
+        i = in;
+        c0 = c1; p0 = p1; c1 = c2; p1 = p2;
+        uv0 = uv1; X0 = X1; Y0 = Y1; Z0 = Z1;
     }
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
@@ -235,13 +278,19 @@ __global__ __launch_bounds__(kSweepThreads) void k_resjac(
     }
 }
 
-// Unpack the SoA Jacobian planes into the row-major (N,2,6)/(N,2,3) blocks of the C-ABI (test entry).
+// Unpack the Jacobian pair-planes into the row-major (N,2,6)/(N,2,3) blocks of the C-ABI (test entry).
 __global__ void k_unpack_jac(const double* __restrict__ Jc, const double* __restrict__ Jp, int N,
                              int64_t ld, double* __restrict__ jc_out, double* __restrict__ jp_out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
-    for (int k = 0; k < 12; ++k) jc_out[(size_t)i * 12 + k] = Jc[k * ld + i];
-    for (int k = 0; k < 6; ++k) jp_out[(size_t)i * 6 + k] = Jp[k * ld + i];
+    for (int m = 0; m < 6; ++m) {
+        const double2 v = *reinterpret_cast<const double2*>(Jc + 2 * ((size_t)m * ld + i));
+        jc_out[(size_t)i * 12 + 2 * m] = v.x; jc_out[(size_t)i * 12 + 2 * m + 1] = v.y;
+    }
+    for (int m = 0; m < 3; ++m) {
+        const double2 v = *reinterpret_cast<const double2*>(Jp + 2 * ((size_t)m * ld + i));
+        jp_out[(size_t)i * 6 + 2 * m] = v.x; jp_out[(size_t)i * 6 + 2 * m + 1] = v.y;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -260,11 +309,20 @@ struct ObsArrays {
     int64_t ld;
 };
 
+__device__ __forceinline__ void load_jc(const ObsArrays& o, int i, double* jc) {
+#pragma unroll
+    for (int m = 0; m < 6; ++m) {
+        const double2 v = *reinterpret_cast<const double2*>(o.Jc + 2 * ((size_t)m * o.ld + i));
+        jc[2 * m] = v.x; jc[2 * m + 1] = v.y;
+    }
+}
 __device__ __forceinline__ void load_blocks(const ObsArrays& o, int i, double* jc, double* jp) {
+    load_jc(o, i, jc);
 #pragma unroll
-    for (int k = 0; k < 12; ++k) jc[k] = o.Jc[k * o.ld + i];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) jp[k] = o.Jp[k * o.ld + i];
+    for (int m = 0; m < 3; ++m) {
+        const double2 v = *reinterpret_cast<const double2*>(o.Jp + 2 * ((size_t)m * o.ld + i));
+        jp[2 * m] = v.x; jp[2 * m + 1] = v.y;
+    }
 }
 
 // K2+K3: V_p = sum Jp^T Jp (6), g_p = sum Jp^T r (3) by segmented reduction;
@@ -394,8 +452,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_normal_blocks_lds(
     if (!do_points) {                               // later column passes: cameras only, no segments
         for (int i = pos + lane; i < end; i += 64) {
             double jc[12];
-#pragma unroll
-            for (int k = 0; k < 12; ++k) jc[k] = o.Jc[k * o.ld + i];
+            load_jc(o, i, jc);
             cam_accumulate(i, jc, r[2 * (size_t)i], r[2 * (size_t)i + 1]);
         }
         pos = end;
@@ -1188,6 +1245,12 @@ __global__ void k_step(const double* __restrict__ x, const double* __restrict__ 
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n;
          e += (int64_t)gridDim.x * blockDim.x)
         x_new[e] = x[e] + c1 * sg[e] + c2 * p[e];
+}
+
+// streaming-store ceiling probe: 16 B per lane, grid-stride
+__global__ __launch_bounds__(1024) void k_fill16(double* __restrict__ a, int64_t n2, double v) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n2; e += (int64_t)gridDim.x * blockDim.x)
+        *reinterpret_cast<double2*>(a + 2 * e) = make_double2(v, v + 1.0);
 }
 
 __global__ void k_fill(double* __restrict__ a, int64_t n, double v) {

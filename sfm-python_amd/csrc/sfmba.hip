@@ -10,6 +10,9 @@
 #include "../../include/sfmba.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include <rccl/rccl.h>   // types only: librccl.so.1 is dlopen()ed by sfmba_comm_init
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -53,6 +56,36 @@ struct DevBuf {
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
+// RCCL entry points, resolved at run time so that libsfmba.so has no load-time dependency on RCCL
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi* rccl_api() {
+    static RcclApi api;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (lib) {
+            api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+            api.CommInitRank = (decltype(api.CommInitRank))dlsym(lib, "ncclCommInitRank");
+            api.AllReduce = (decltype(api.AllReduce))dlsym(lib, "ncclAllReduce");
+            api.CommDestroy = (decltype(api.CommDestroy))dlsym(lib, "ncclCommDestroy");
+            api.GetErrorString = (decltype(api.GetErrorString))dlsym(lib, "ncclGetErrorString");
+            if (api.GetUniqueId && api.CommInitRank && api.AllReduce && api.CommDestroy && api.GetErrorString)
+                api.lib = lib;
+        }
+    }
+    return api.lib ? &api : nullptr;
+}
+
 double now_s() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -90,6 +123,8 @@ struct sfmba_handle {
     int64_t arena_doubles = 0;
     sfmba_allreduce_fn ar_fn = nullptr;
     void* ar_ctx = nullptr;
+    ncclComm_t comm = nullptr;               // native RCCL communicator (sfmba_comm_init)
+    int64_t n_collectives = 0;
     double* h_scal = nullptr;                // pinned
     bool solved = false;
     std::vector<const void*> lds_ready;      // kernels already opted in to 160 KiB dynamic LDS
@@ -139,9 +174,20 @@ int enter(sfmba_handle* h) {
     return 0;
 }
 
+// All-reduce `count` doubles of the exchange arena in place over the ranks, on the handle's stream:
+// natively with RCCL when a communicator is set, else through the host callback, else a no-op.
 int exchange(sfmba_handle* h, double* ptr, int64_t count, int op) {
+    if (h->comm) {
+        RcclApi* api = rccl_api();
+        const ncclResult_t rc = api->AllReduce(ptr, ptr, (size_t)count, ncclDouble, op == 0 ? ncclSum : ncclMax,
+                                               h->comm, h->stream);
+        if (rc != ncclSuccess) return fail(h, -5, "ncclAllReduce failed: %s", api->GetErrorString(rc));
+        ++h->n_collectives;
+        return 0;
+    }
     if (!h->ar_fn) return 0;
     if (h->ar_fn(h->ar_ctx, ptr, count, op) != 0) return fail(h, -5, "all-reduce callback failed");
+    ++h->n_collectives;
     return 0;
 }
 
@@ -169,6 +215,21 @@ int grid_1d(int64_t n, int block, int cap) {
     return (int)g;
 }
 
+// Host/device hand-off: poll the stream instead of sleeping in hipStreamSynchronize.  The solver
+// hands control back to the host two to three times per outer iteration for ~30 us of GPU work each;
+// a blocking wait that parks the thread costs up to a millisecond per wake-up on an idle host.
+int wait_stream(sfmba_handle* h) {
+    const double t0 = now_s();
+    for (;;) {
+        const hipError_t e = hipStreamQuery(h->stream);
+        if (e == hipSuccess) return 0;
+        if (e != hipErrorNotReady) return fail(h, -3, "hipStreamQuery failed: %s", hipGetErrorString(e));
+        if (now_s() - t0 > 0.05) break;          // long wait: stop burning the core
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
 // ---- kernel launch wrappers --------------------------------------------------------------------
 
 int launch_cam_table(sfmba_handle* h, const double* x, double* tab) {
@@ -178,30 +239,38 @@ int launch_cam_table(sfmba_handle* h, const double* x, double* tab) {
 }
 
 // residual (+Jacobian) sweep at x (camera table must be current) into buffer set `js`; leaves the
-// sum r^2 partials in `part` and returns the number of partials.
-template <bool JAC, bool STORE_R>
-int launch_resjac(sfmba_handle* h, const double* x, const double* tab, int js, int* nparts) {
-    const int npair = (int)((h->N + 1) / 2);
-    const int grid = grid_1d(npair, kSweepThreads, h->n_cu);
+// sum r^2 partials in `part` and returns the number of partials.  With ev0/ev1 the dispatch itself
+// is bracketed (hipExtLaunchKernelGGL: start/stop taken from the kernel's own dispatch, as rocprofv3
+// does), so the measured duration is the kernel's and not host launch latency.
+template <bool LDS, bool JAC, bool STORE_R>
+int launch_resjac_v(sfmba_handle* h, const double* x, const double* tab, int js, int grid, size_t lds,
+                    hipEvent_t ev0, hipEvent_t ev1) {
     const double* pts = x + 6 * h->C;
-    if (h->lds_tab) {
-        const size_t lds = (size_t)h->C * kCamTab * sizeof(double);
-        auto kern = k_resjac<true, JAC, STORE_R>;
-        CHK(set_lds(h, kern, lds));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), lds, h->stream, tab, pts,
-                           h->cam_idx.as<int>(), h->pt_idx.as<int>(), h->uv.as<double>(),
-                           h->r[js].as<double>(), h->Jc[js].as<double>(), h->Jp[js].as<double>(), (int)h->N,
-                           h->ld, (int)h->C, h->K, h->part.as<double>());
+    auto kern = k_resjac<LDS, JAC, STORE_R>;
+    CHK(set_lds(h, kern, lds));
+    if (ev0) {
+        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), (uint32_t)lds, h->stream, ev0, ev1, 0u, tab, pts,
+                              (const int*)h->cam_idx.as<int>(), (const int*)h->pt_idx.as<int>(),
+                              (const double*)h->uv.as<double>(), h->r[js].as<double>(), h->Jc[js].as<double>(),
+                              h->Jp[js].as<double>(), (int)h->N, h->ld, (int)h->C, h->K, h->part.as<double>());
     } else {
-        auto kern = k_resjac<false, JAC, STORE_R>;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), 0, h->stream, tab, pts,
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), lds, h->stream, tab, pts,
                            h->cam_idx.as<int>(), h->pt_idx.as<int>(), h->uv.as<double>(),
                            h->r[js].as<double>(), h->Jc[js].as<double>(), h->Jp[js].as<double>(), (int)h->N,
                            h->ld, (int)h->C, h->K, h->part.as<double>());
     }
     HIPCHK(h, hipGetLastError());
-    *nparts = grid;
     return 0;
+}
+
+template <bool JAC, bool STORE_R>
+int launch_resjac(sfmba_handle* h, const double* x, const double* tab, int js, int* nparts,
+                  hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
+    const int grid = grid_1d(h->N, kSweepThreads, h->n_cu);
+    *nparts = grid;
+    if (h->lds_tab)
+        return launch_resjac_v<true, JAC, STORE_R>(h, x, tab, js, grid, (size_t)h->C * kCamTab * sizeof(double), ev0, ev1);
+    return launch_resjac_v<false, JAC, STORE_R>(h, x, tab, js, grid, 0, ev0, ev1);
 }
 
 // sum of `nparts` partial rows of width nq into the exchange scalars starting at slot `slot`
@@ -344,8 +413,7 @@ int exchange_scalars(sfmba_handle* h, int first_sum_slot) {
 // bring all 32 scalars to the host (h_scal) and wait
 int fetch_scalars(sfmba_handle* h) {
     HIPCHK(h, hipMemcpyAsync(h->h_scal, h->scal(), sizeof(double) * kScalSlots, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    return 0;
+    return wait_stream(h);
 }
 
 // q_k summed over the camera slice and the (rank-reduced) point slice
@@ -391,8 +459,10 @@ int pcg_enqueue(sfmba_handle* h, int count) {
 }
 
 int pcg_read(sfmba_handle* h, PcgCtrl* hc) {
-    HIPCHK(h, hipMemcpyAsync(hc, h->ctrl.p, sizeof *hc, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    static_assert(sizeof(PcgCtrl) <= 24 * sizeof(double), "PcgCtrl fits the pinned tail");
+    HIPCHK(h, hipMemcpyAsync(h->h_scal + 40, h->ctrl.p, sizeof *hc, hipMemcpyDeviceToHost, h->stream));
+    CHK(wait_stream(h));
+    memcpy(hc, h->h_scal + 40, sizeof *hc);
 #ifdef SFMBA_STAMPS
     fprintf(stderr, "[stamps] k_pcg_update phases (us):");
     for (int k = 1; k < 8; ++k) fprintf(stderr, " %.2f", (double)(hc->stamp[k] - hc->stamp[k - 1]) * 0.01);
@@ -481,6 +551,7 @@ void sfmba_destroy(sfmba_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->comm) { if (RcclApi* api = rccl_api()) (void)api->CommDestroy(h->comm); h->comm = nullptr; }
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     if (h->h_scal) (void)hipHostFree(h->h_scal);
     delete h;
@@ -516,6 +587,45 @@ int sfmba_set_exchange(sfmba_handle* h, void* arena, int64_t arena_doubles, sfmb
     h->arena_doubles = arena_doubles;
     h->ar_fn = fn; h->ar_ctx = ctx;
     h->N_total = n_obs_total;
+    return 0;
+}
+
+int sfmba_comm_get_unique_id(void* id128_out) {
+    RcclApi* api = rccl_api();
+    if (!api || !id128_out) return -5;
+    ncclUniqueId id;
+    if (api->GetUniqueId(&id) != ncclSuccess) return -5;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    memcpy(id128_out, &id, sizeof id);
+    return 0;
+}
+
+int sfmba_comm_init(sfmba_handle* h, const void* id128, int32_t rank, int32_t world, int64_t n_obs_total) {
+    CHK(enter(h));
+    if (!h->have_problem) return fail(h, -1, "call sfmba_set_problem before sfmba_comm_init");
+    if (!id128 || world < 1 || rank < 0 || rank >= world) return fail(h, -1, "bad communicator arguments");
+    if (n_obs_total < h->N) return fail(h, -1, "n_obs_total is smaller than the local shard");
+    RcclApi* api = rccl_api();
+    if (!api) return fail(h, -5, "librccl.so.1 could not be loaded: %s", dlerror());
+    if (h->comm) { (void)api->CommDestroy(h->comm); h->comm = nullptr; }
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    const ncclResult_t rc = api->CommInitRank(&h->comm, world, id, rank);
+    if (rc != ncclSuccess) { h->comm = nullptr; return fail(h, -5, "ncclCommInitRank failed: %s", api->GetErrorString(rc)); }
+    h->ar_fn = nullptr; h->ar_ctx = nullptr;
+    h->arena = h->arena_own.as<double>();
+    h->N_total = n_obs_total;
+    return 0;
+}
+
+int sfmba_comm_destroy(sfmba_handle* h) {
+    CHK(enter(h));
+    if (h->comm) {
+        if (h->stream) HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (RcclApi* api = rccl_api()) (void)api->CommDestroy(h->comm);
+        h->comm = nullptr;
+    }
+    h->N_total = h->N;
     return 0;
 }
 
@@ -775,6 +885,23 @@ int sfmba_time_kernel(sfmba_handle* h, const double* x, int32_t which, int32_t r
             case 1: CHK((launch_resjac<false, false>(h, h->x, h->tab, h->jcur, &np))); break;
             case 2: CHK(launch_normal_blocks(h)); break;
             case 3: CHK(launch_schur_sweep<0>(h, h->pk.as<double>(), nullptr, nullptr)); break;
+            case 10:   // streaming-store ceiling: fill the 12 Jc planes, 16 B per lane, one stream
+                hipLaunchKernelGGL(k_fill16, dim3(h->n_cu * 2), dim3(1024), 0, h->stream, h->Jc[h->jcur].as<double>(),
+                                   (int64_t)(6 * h->ld), 1.0);
+                break;
+            case 11:   // same bytes, 2048 workgroups
+                hipLaunchKernelGGL(k_fill16, dim3(2048), dim3(1024), 0, h->stream, h->Jc[h->jcur].as<double>(),
+                                   (int64_t)(6 * h->ld), 1.0);
+                break;
+            case 13:   // cold streaming-store ceiling: 144 MB per rep, alternating buffer sets (288 MB cycle > 256 MiB Infinity Cache)
+                hipLaunchKernelGGL(k_fill16, dim3(2048), dim3(1024), 0, h->stream, h->Jc[k & 1].as<double>(),
+                                   (int64_t)(6 * h->ld), 1.0);
+                hipLaunchKernelGGL(k_fill16, dim3(2048), dim3(1024), 0, h->stream, h->Jp[k & 1].as<double>(),
+                                   (int64_t)(3 * h->ld), 1.0);
+                break;
+            case 12:   // alternate between the two Jacobian buffer sets (defeats Infinity-Cache write hits)
+                CHK((launch_resjac<true, true>(h, h->x, h->tab, k & 1, &np)));
+                break;
             default: return fail(h, -1, "unknown kernel id %d", which);
         }
     }
@@ -821,9 +948,7 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
         if (opt.profile) {
             hipEvent_t a, b;
             HIPCHK(h, hipEventCreate(&a)); HIPCHK(h, hipEventCreate(&b));
-            HIPCHK(h, hipEventRecord(a, h->stream));
-            CHK((launch_resjac<true, true>(h, x, tab, js, &np)));
-            HIPCHK(h, hipEventRecord(b, h->stream));
+            CHK((launch_resjac<true, true>(h, x, tab, js, &np, a, b)));
             evs.emplace_back(a, b);
         } else {
             CHK((launch_resjac<true, true>(h, x, tab, js, &np)));
@@ -890,8 +1015,9 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
         };
         CHK(tail());
         if (pcg_guess > 0) {
-            HIPCHK(h, hipMemcpyAsync(&hc, h->ctrl.p, sizeof hc, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipMemcpyAsync(h->h_scal + 40, h->ctrl.p, sizeof hc, hipMemcpyDeviceToHost, h->stream));
             CHK(fetch_scalars(h));                              // hand-off 1
+            memcpy(&hc, h->h_scal + 40, sizeof hc);
             if (hc.done == 0) {                                 // guess too small: finish and redo the tail
                 CHK(pcg_finish_polling(h, opt, &hc));
                 CHK(tail());
@@ -952,7 +1078,7 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
             CHK(eval_jac(h->x_new, h->tab_new, jalt));
             CHK(exchange(h, sc, 1, 0));
             HIPCHK(h, hipMemcpyAsync(h->h_scal, sc, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(h, hipStreamSynchronize(h->stream));         // hand-off 2
+            CHK(wait_stream(h));                                // hand-off 2
             ++nfev;
             cost_new = 0.5 * h->h_scal[0];
             if (!std::isfinite(cost_new)) {                     // trf.py:504-506

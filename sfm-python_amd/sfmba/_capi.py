@@ -17,7 +17,8 @@ SYMBOLS = (
     "sfmba_create", "sfmba_destroy", "sfmba_last_error", "sfmba_default_options", "sfmba_set_stream",
     "sfmba_set_problem", "sfmba_exchange_doubles", "sfmba_set_exchange", "sfmba_residuals",
     "sfmba_residual_jacobian", "sfmba_solve", "sfmba_get_fun_grad", "sfmba_time_kernel",
-    "sfmba_normal_blocks", "sfmba_schur_matvec",
+    "sfmba_normal_blocks", "sfmba_schur_matvec", "sfmba_comm_get_unique_id", "sfmba_comm_init",
+    "sfmba_comm_destroy",
 )
 
 
@@ -74,9 +75,13 @@ def load():
     lib.sfmba_normal_blocks.argtypes = [P, P, P, P, P, P]
     lib.sfmba_schur_matvec.argtypes = [P, P, P, P, P, P]
     lib.sfmba_tr2d_solve.argtypes = [P, P, C.c_double, P]
+    lib.sfmba_comm_get_unique_id.argtypes = [P]
+    lib.sfmba_comm_init.argtypes = [P, P, C.c_int32, C.c_int32, C.c_int64]
+    lib.sfmba_comm_destroy.argtypes = [P]
     for name in ("sfmba_set_stream", "sfmba_set_problem", "sfmba_set_exchange", "sfmba_residuals",
                  "sfmba_residual_jacobian", "sfmba_solve", "sfmba_get_fun_grad", "sfmba_time_kernel",
-                 "sfmba_normal_blocks", "sfmba_schur_matvec", "sfmba_tr2d_solve"):
+                 "sfmba_normal_blocks", "sfmba_schur_matvec", "sfmba_tr2d_solve", "sfmba_comm_get_unique_id",
+                 "sfmba_comm_init", "sfmba_comm_destroy"):
         getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib

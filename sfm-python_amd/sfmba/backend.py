@@ -103,6 +103,24 @@ class Backend:
         self._check(self._lib.sfmba_set_exchange(self._h, C.c_void_p(int(arena_ptr)),
                                                  int(arena_doubles), cfn, None, int(n_obs_total)))
 
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """128-byte RCCL id; call on rank 0 and broadcast (sfmba.dist.NativeComm does)."""
+        buf = C.create_string_buffer(128)
+        rc = _capi.load().sfmba_comm_get_unique_id(buf)
+        if rc != 0:
+            raise BackendError("sfmba_comm_get_unique_id failed: librccl.so.1 not loadable")
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int, n_obs_total: int):
+        if len(unique_id) != 128:
+            raise ValueError("unique_id must be 128 bytes")
+        buf = C.create_string_buffer(unique_id, 128)
+        self._check(self._lib.sfmba_comm_init(self._h, buf, int(rank), int(world), int(n_obs_total)))
+
+    def comm_destroy(self):
+        self._check(self._lib.sfmba_comm_destroy(self._h))
+
     # ------------------------------------------------------------------------------------------
     def residuals(self, x):
         x = _f64(x, (self.n_params,), "x")

@@ -111,3 +111,25 @@ class Exchange:
         self._td.all_reduce(self.arena[off:off + count], op=rop, group=self.group)
         self.n_calls += 1
         self.n_doubles += count
+
+
+class NativeComm:
+    """The fast path: libsfmba.so all-reduces its own arena with RCCL (ncclAllReduce enqueued on the
+    solver's stream from C++), so no Python and no host synchronisation sit between a sweep and its
+    collective.  ``torch.distributed`` is only the bootstrap channel for the 128-byte RCCL id and the
+    observation count (any backend)."""
+
+    def __init__(self, backend, n_obs_local: int, group=None):
+        import torch
+        import torch.distributed as td
+        rank, world = td.get_rank(group), td.get_world_size(group)
+        dev = "cuda" if td.get_backend(group) == "nccl" else "cpu"
+        uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            uid = torch.frombuffer(bytearray(backend.comm_unique_id()), dtype=torch.uint8).to(dev)
+        td.broadcast(uid, src=0, group=group)
+        tot = torch.tensor([float(n_obs_local)], dtype=torch.float64, device=dev)
+        td.all_reduce(tot, op=td.ReduceOp.SUM, group=group)
+        self.n_obs_total = int(round(float(tot.item())))
+        self.rank, self.world = rank, world
+        backend.comm_init(bytes(uid.cpu().numpy().tobytes()), rank, world, self.n_obs_total)

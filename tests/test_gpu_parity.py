@@ -268,3 +268,56 @@ def test_properties_at_full_size(be):
     assert 0.3 < res.rmse < 0.7            # sqrt(0.5^2 + truncation variance) ~ 0.58 px minus fitted dof
     r_fin = be.residuals(res.x)
     assert abs(0.5 * np.sum(r_fin ** 2) - res.cost) <= 1e-9 * res.cost
+
+
+# ---- the N>1 code path on one GPU: world_size-1 RCCL through the same Exchange / callback plumbing -------
+
+def test_exchange_path_world1_nccl():
+    """Runs a solve with the all-reduce callback active (torch.distributed backend nccl = RCCL, world
+    size 1, exchange arena = a torch CUDA tensor, kernels and collectives on one torch stream) and
+    checks that it reproduces the single-process result exactly."""
+    import socket
+    import torch
+    import torch.distributed as td
+    import sfmba
+    from sfmba import dist as sdist
+    pb = sfmba.make_problem(11, 3000, 10000, seed=0)
+    ref = sfmba.least_squares(sfmba.compute_residuals, pb.x0, x_scale="jac", ftol=1e-10, method="trf",
+                              args=pb.args)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    torch.cuda.set_device(0)
+    td.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                          device_id=torch.device("cuda", 0))
+    try:
+        be = sfmba.Backend(0)
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            be.set_stream(stream.cuda_stream)
+            be.set_problem(*pb.args)
+            ex = sdist.Exchange(be, n_obs_local=pb.n_obs)
+            assert ex.n_obs_total == pb.n_obs
+            opt = be.default_options()
+            opt.ftol = 1e-10
+            x, res, fun, grad = be.solve(pb.x0, opt)
+            torch.cuda.synchronize()
+        assert ex.n_calls > 20                      # the callback really was on the path
+        assert res.status == ref.status and int(res.nfev) == ref.nfev
+        assert abs(res.cost - ref.cost) <= 1e-12 * ref.cost
+        # atomics make the summation order (hence the last bits of a step) vary from run to run
+        assert np.abs(x - ref.x).max() <= 1e-6 * max(1.0, np.abs(ref.x).max())
+        be.close()
+        # the native path: RCCL called from C++ on the solver's stream
+        be2 = sfmba.Backend(0)
+        be2.set_problem(*pb.args)
+        nc = sdist.NativeComm(be2, n_obs_local=pb.n_obs)
+        assert nc.world == 1 and nc.n_obs_total == pb.n_obs
+        x2, res2, _, _ = be2.solve(pb.x0, opt)
+        assert res2.status == ref.status and int(res2.nfev) == ref.nfev
+        assert abs(res2.cost - ref.cost) <= 1e-12 * ref.cost
+        assert np.abs(x2 - ref.x).max() <= 1e-6 * max(1.0, np.abs(ref.x).max())
+        be2.comm_destroy()
+        be2.close()
+    finally:
+        td.destroy_process_group()
