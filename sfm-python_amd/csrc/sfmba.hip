@@ -522,7 +522,7 @@ void sfmba_default_options(sfmba_options* o) {
     memset(o, 0, sizeof *o);
     o->ftol = 1e-8; o->xtol = 1e-8; o->gtol = 1e-8;
     o->max_nfev = 0; o->verbose = 0; o->max_iter = 0;
-    o->pcg_tol = 1e-6; o->pcg_max_iter = 0; o->pcg_check_every = 2;
+    o->pcg_tol = 1e-3; o->pcg_max_iter = 0; o->pcg_check_every = 2;
     o->reg_min = 1e-10; o->profile = 0;
 }
 

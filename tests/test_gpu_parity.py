@@ -192,8 +192,8 @@ def test_solve_matches_scipy_on_tiny_problems(orc):
         assert res.cost <= cost * (1 + 1e-9)
         assert np.abs(res.fun - g[pre + "fun"]).max() < 5e-2
         # and against the oracle's restatement of the same algorithm
-        o = orc.trf_schur(pb.x0, *pb.args, ftol=1e-10, linear="pcg", pcg_tol=1e-6)
-        assert abs(res.cost - o.cost) <= 1e-9 * o.cost
+        o = orc.trf_schur(pb.x0, *pb.args, ftol=1e-10, linear="pcg", pcg_tol=1e-3)
+        assert abs(res.cost - o.cost) <= 1e-8 * o.cost
         # result.fun / result.grad are consistent with result.x
         r = orc.compute_residuals(res.x, *pb.args)
         assert np.abs(r - res.fun).max() < 1e-8
