@@ -31,6 +31,13 @@ constexpr int kWavesPerSweepBlock = kSweepThreads / 64;
 struct KMat { double k[9]; };
 
 // device-resident control block of the PCG (lets the host enqueue iterations without reading back)
+// The PCG keeps two sets of its five camera-sized vectors and two accumulators and alternates between
+// them every iteration (set = iters & 1), so that the update kernel can run on several workgroups that
+// all read the old set completely while each writes its slice of the new one.
+constexpr int kPcgVecs = 5;     // x r p s u
+constexpr int kPcgX = 0, kPcgR = 1, kPcgP = 2, kPcgS = 3, kPcgU = 4;
+constexpr int kPcgUpdateBlocks = 8;
+
 struct PcgCtrl {
     double rz;        // gamma_i = r^T M^-1 r of the current iterate
     double rz0;       // ... of the initial residual
@@ -846,10 +853,18 @@ template <bool LDS_ACC, int MODE>
 __global__ __launch_bounds__(kSweepThreads) void k_schur_sweep(
     const int2* __restrict__ ranges, int n_ranges, ObsArrays o, const double* __restrict__ vin,
     const double* __restrict__ Vinv, const double* __restrict__ zin, double* __restrict__ acc, int C,
-    const PcgCtrl* __restrict__ ctrl) {
+    const PcgCtrl* __restrict__ ctrl2, int L) {
     extern __shared__ __align__(16) double smem[];
-    if (ctrl != nullptr && ctrl->done != 0) return;          // grid-uniform: written by a prior kernel
     const int n6 = 6 * C;
+    if (ctrl2 != nullptr) {
+        // inside the PCG: `vin` is the base of the ping-pong vector sets, `acc` the base of the two
+        // accumulators; the control block of this launch (written by the previous kernel) says which
+        const PcgCtrl* __restrict__ ctrl = ctrl2 + (L & 1);
+        if (ctrl->done != 0) return;                         // grid-uniform
+        const int set = ctrl->iters & 1;
+        vin += (size_t)(set * kPcgVecs + kPcgU) * n6;
+        acc += (size_t)set * n6;
+    }
     double* s_v = smem;
     double* s_acc = smem + n6;
     if (LDS_ACC) {
@@ -978,20 +993,41 @@ __global__ __launch_bounds__(kSweepThreads) void k_schur_sweep(
 }
 
 // PCG on the reduced camera system S dc = rhs in the single-reduction (Chronopoulos-Gear) form, so
-// that one sweep (w = S u) and ONE small update kernel make an iteration and all loads of the update
-// are issued before its only blocking reduction:
+// that one sweep (w = S u) and ONE small update kernel make an iteration:
 //     delta = (w,u); beta = gamma/gamma_prev; alpha = gamma / (delta - beta gamma / alpha_prev)
 //     p = u + beta p; s = w + beta s; x += alpha p; r -= alpha s; u = Minv r; gamma' = (r,u)
-// Single workgroup, one thread per camera (its 6-vectors and 6x6 block are thread private).
-// Start: rhs = -g_c - acc (acc = -sum W e from the MODE 1 sweep), x = 0, r = rhs, u = Minv r, p = s = 0.
+// One thread per camera (its 6-vectors and 6x6 block are thread private).
+//
+// A single workgroup doing this is bound by one CU's store issue rate (240 KB of stores: 8 of 16 us,
+// measured with in-kernel stamps), so the update runs on kPcgUpdateBlocks workgroups WITHOUT any
+// inter-workgroup synchronisation: every workgroup computes both dot products redundantly from the
+// complete old vector set, and stores only its own slice of the cameras into the other set.  Control
+// blocks alternate as well (read ctrl2[L&1], written ctrl2[(L+1)&1] by block 0 only), so no workgroup
+// can observe a value written during its own launch.
+__device__ __forceinline__ double minv_row(const double* m, const double* r, int k) {
+    double z = 0.0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int a = k < j ? k : j, b = k < j ? j : k;
+        z += m[a * 6 - a * (a - 1) / 2 + (b - a)] * r[j];       // packed upper triangle
+    }
+    return z;
+}
+
+// Start: rhs = -g_c - acc0 (acc0 = -sum W e from the MODE 1 sweep), x = 0, r = rhs, u = Minv r,
+// p = s = 0 in set 0; both accumulators zeroed; ctrl2[0] initialised.  Single workgroup.
 __global__ __launch_bounds__(1024) void k_pcg_init(const double* __restrict__ Ugc,
                                                    double* __restrict__ acc,
                                                    const double* __restrict__ Minv, int C,
-                                                   double* __restrict__ xk, double* __restrict__ rk,
-                                                   double* __restrict__ pk, double* __restrict__ sk,
-                                                   double* __restrict__ uk, double tol,
-                                                   int max_iters, PcgCtrl* __restrict__ ctrl) {
+                                                   double* __restrict__ vecs, double tol,
+                                                   int max_iters, PcgCtrl* __restrict__ ctrl2) {
     __shared__ double red[16];
+    const size_t n6 = 6 * (size_t)C;
+    double* __restrict__ xk = vecs + kPcgX * n6;
+    double* __restrict__ rk = vecs + kPcgR * n6;
+    double* __restrict__ pk = vecs + kPcgP * n6;
+    double* __restrict__ sk = vecs + kPcgS * n6;
+    double* __restrict__ uk = vecs + kPcgU * n6;
     double s[1] = {0.0};
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         double rr[6], m[21];
@@ -999,125 +1035,124 @@ __global__ __launch_bounds__(1024) void k_pcg_init(const double* __restrict__ Ug
         for (int k = 0; k < 6; ++k) {
             const size_t e = (size_t)k * C + c;
             rr[k] = -Ugc[(size_t)c * 27 + 21 + k] - acc[e];
-            acc[e] = 0.0; xk[e] = 0.0; pk[e] = 0.0; sk[e] = 0.0;
+            acc[e] = 0.0; acc[n6 + e] = 0.0;
+            xk[e] = 0.0; pk[e] = 0.0; sk[e] = 0.0;
             rk[e] = rr[k];
         }
 #pragma unroll
         for (int n = 0; n < 21; ++n) m[n] = Minv[(size_t)n * C + c];
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
-            double z = 0.0;
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const int a = k < j ? k : j, b = k < j ? j : k;
-                z += m[a * 6 - a * (a - 1) / 2 + (b - a)] * rr[j];
-            }
+            const double z = minv_row(m, rr, k);
             uk[(size_t)k * C + c] = z;
             s[0] += z * rr[k];
         }
     }
     block_sum<1>(s, red);
     if (threadIdx.x == 0) {
-        ctrl->rz = s[0];
-        ctrl->rz0 = s[0];
-        ctrl->rz_prev = 1.0;
-        ctrl->alpha_prev = 1.0;
-        ctrl->tol2 = tol * tol;
-        ctrl->iters = 0;
-        ctrl->max_iters = max_iters;
-        ctrl->done = (s[0] > 0.0) ? 0 : (s[0] == 0.0 ? 1 : 3);
+        PcgCtrl c0;
+        c0.rz = s[0]; c0.rz0 = s[0]; c0.tol2 = tol * tol; c0.rz_prev = 1.0; c0.alpha_prev = 1.0;
+        c0.iters = 0; c0.max_iters = max_iters;
+        c0.done = (s[0] > 0.0) ? 0 : (s[0] == 0.0 ? 1 : 3);
+        c0.pad = 0;
+#ifdef SFMBA_STAMPS
+        for (int k = 0; k < 16; ++k) c0.stamp[k] = 0;
+#endif
+        ctrl2[0] = c0;
     }
 }
 
-// One PCG step after the sweep produced acc = (S - Dc) u.  A finished solve turns every later
-// sweep/update into a no-op (ctrl->done), so the host may enqueue iterations without reading back.
-// Cameras beyond the first 1024 are handled by the same threads in further rounds; w = S u is kept
-// in acc between the two phases for them.
+// One PCG step after the sweep of launch L produced acc[set] = (S - Dc) u.  A finished solve turns every
+// later sweep/update into a no-op (done is copied forward), so the host may enqueue iterations without
+// reading back.
 __global__ __launch_bounds__(1024) void k_pcg_update(double* __restrict__ acc,
                                                      const double* __restrict__ Dc,
                                                      const double* __restrict__ Minv, int C,
-                                                     double* __restrict__ xk, double* __restrict__ rk,
-                                                     double* __restrict__ pk, double* __restrict__ sk,
-                                                     double* __restrict__ uk,
-                                                     PcgCtrl* __restrict__ ctrl) {
+                                                     double* __restrict__ vecs,
+                                                     PcgCtrl* __restrict__ ctrl2, int L) {
     __shared__ double red[16];
-    __shared__ double sh_alpha, sh_beta;
-    __shared__ int sh_bad;
-    SFMBA_STAMP(ctrl, 0);
-    if (ctrl->done != 0) return;
-    SFMBA_STAMP(ctrl, 1);
+    __shared__ double sh_bcast[2];
+    const PcgCtrl* __restrict__ cin = ctrl2 + (L & 1);
+    PcgCtrl* __restrict__ cout = ctrl2 + ((L + 1) & 1);
+    const PcgCtrl ci = *cin;
+    if (ci.done != 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) *cout = ci;
+        return;
+    }
+    const size_t n6 = 6 * (size_t)C;
+    const int set = ci.iters & 1;
+    const double* __restrict__ vin = vecs + (size_t)set * kPcgVecs * n6;
+    double* __restrict__ vout = vecs + (size_t)(set ^ 1) * kPcgVecs * n6;
+    const double* __restrict__ acc_in = acc + (size_t)set * n6;
+    double* __restrict__ acc_out = acc + (size_t)(set ^ 1) * n6;
+    const double* __restrict__ u_in = vin + kPcgU * n6;
+    // cameras whose results this workgroup stores
+    const int slice = ((C + (int)gridDim.x - 1) / (int)gridDim.x + 63) & ~63;
+    const int own_lo = (int)blockIdx.x * slice, own_hi = own_lo + slice;
+
     double d[1] = {0.0};
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
             const size_t e = (size_t)k * C + c;
-            const double ue = uk[e];
-            const double we = acc[e] + Dc[e] * ue;
-            acc[e] = we;
-            d[0] += we * ue;
+            const double ue = u_in[e];
+            d[0] += (acc_in[e] + Dc[e] * ue) * ue;
         }
     }
-    SFMBA_STAMP(ctrl, 2);
     block_sum<1>(d, red);
-    SFMBA_STAMP(ctrl, 3);
-    if (threadIdx.x == 0) {
-        const double gamma = ctrl->rz;
-        const double beta = ctrl->iters == 0 ? 0.0 : gamma / ctrl->rz_prev;
-        const double den = d[0] - (ctrl->iters == 0 ? 0.0 : beta * gamma / ctrl->alpha_prev);
-        const double alpha = gamma / den;
-        sh_alpha = alpha; sh_beta = beta;
-        sh_bad = (!(den > 0.0) || !isfinite(alpha)) ? 1 : 0;        // S not SPD / NaN
-        if (sh_bad) ctrl->done = 3;
-    }
+    if (threadIdx.x == 0) sh_bcast[0] = d[0];
     __syncthreads();
-    SFMBA_STAMP(ctrl, 4);
-    const double alpha = sh_alpha, beta = sh_beta;
-    if (sh_bad) {                                               // block-uniform
-        for (int e = threadIdx.x; e < 6 * C; e += blockDim.x) acc[e] = 0.0;
+    const double delta = sh_bcast[0];
+    const double gamma = ci.rz;
+    const double beta = ci.iters == 0 ? 0.0 : gamma / ci.rz_prev;
+    const double den = delta - (ci.iters == 0 ? 0.0 : beta * gamma / ci.alpha_prev);
+    const double alpha = gamma / den;
+    if (!(den > 0.0) || !isfinite(alpha)) {                      // S not SPD / NaN: uniform in the grid
+        if (blockIdx.x == 0 && threadIdx.x == 0) { PcgCtrl co = ci; co.done = 3; *cout = co; }
         return;
     }
     double t[1] = {0.0};
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        double rr[6], m[21];
+        double rr[6], uu[6], pp[6], ss[6], xx[6], m[21];
 #pragma unroll
         for (int n = 0; n < 21; ++n) m[n] = Minv[(size_t)n * C + c];
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
             const size_t e = (size_t)k * C + c;
-            const double pe = uk[e] + beta * pk[e];
-            const double se = acc[e] + beta * sk[e];
-            pk[e] = pe; sk[e] = se;
-            xk[e] += alpha * pe;
-            rr[k] = rk[e] - alpha * se;
-            rk[e] = rr[k];
-            acc[e] = 0.0;                                   // ready for the next sweep's atomics
+            const double ue = u_in[e];
+            const double we = acc_in[e] + Dc[e] * ue;
+            pp[k] = ue + beta * vin[kPcgP * n6 + e];
+            ss[k] = we + beta * vin[kPcgS * n6 + e];
+            xx[k] = vin[kPcgX * n6 + e] + alpha * pp[k];
+            rr[k] = vin[kPcgR * n6 + e] - alpha * ss[k];
         }
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
-            double z = 0.0;
+            uu[k] = minv_row(m, rr, k);
+            t[0] += uu[k] * rr[k];
+        }
+        if (c >= own_lo && c < own_hi) {
 #pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const int a = k < j ? k : j, b = k < j ? j : k;
-                z += m[a * 6 - a * (a - 1) / 2 + (b - a)] * rr[j];
+            for (int k = 0; k < 6; ++k) {
+                const size_t e = (size_t)k * C + c;
+                vout[kPcgX * n6 + e] = xx[k]; vout[kPcgR * n6 + e] = rr[k];
+                vout[kPcgP * n6 + e] = pp[k]; vout[kPcgS * n6 + e] = ss[k];
+                vout[kPcgU * n6 + e] = uu[k];
+                acc_out[e] = 0.0;                        // the sweep after next accumulates here
             }
-            uk[(size_t)k * C + c] = z;
-            t[0] += z * rr[k];
         }
     }
-    SFMBA_STAMP(ctrl, 5);
     block_sum<1>(t, red);
-    SFMBA_STAMP(ctrl, 6);
-    if (threadIdx.x == 0) {
-        const double rz_new = t[0];
-        ctrl->rz_prev = ctrl->rz;
-        ctrl->alpha_prev = alpha;
-        ctrl->rz = rz_new;
-        const int it = ctrl->iters + 1;
-        ctrl->iters = it;
-        if (!(rz_new > ctrl->tol2 * ctrl->rz0)) ctrl->done = 1;      // also catches NaN
-        else if (it >= ctrl->max_iters) ctrl->done = 2;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        PcgCtrl co = ci;
+        co.rz_prev = ci.rz;
+        co.alpha_prev = alpha;
+        co.rz = t[0];
+        co.iters = ci.iters + 1;
+        if (!(t[0] > ci.tol2 * ci.rz0)) co.done = 1;         // also catches NaN
+        else if (co.iters >= ci.max_iters) co.done = 2;
+        *cout = co;
     }
-    SFMBA_STAMP(ctrl, 7);
 }
 
 // Back-substitution dp = Vinv (-g_p - sum_i W_i^T dc) per point, fused with the products the 2-D
@@ -1127,9 +1162,12 @@ template <bool LDS_VEC>
 __global__ __launch_bounds__(kSweepThreads) void k_backsub(
     const int2* __restrict__ ranges, int n_ranges, ObsArrays o, const double* __restrict__ dc_planes,
     double* __restrict__ dc, const double* __restrict__ Vinv, const double* __restrict__ gp,
-    const double* __restrict__ t1, double* __restrict__ dp, double* __restrict__ part, int C) {
+    const double* __restrict__ t1, double* __restrict__ dp, double* __restrict__ part, int C,
+    const PcgCtrl* __restrict__ ctrl2, int L) {
     extern __shared__ __align__(16) double smem[];
     __shared__ double red[2 * kWavesPerSweepBlock];
+    if (ctrl2 != nullptr)                      // dc_planes = base of the PCG vector sets: take x of the final set
+        dc_planes += (size_t)((ctrl2[L & 1].iters & 1) * kPcgVecs + kPcgX) * 6 * C;
     // dc_planes: PCG solution, plane-major [6][C]; dc: camera-major [C][6] copy (already written by
     // k_transpose6 when the LDS table is not used)
     if (LDS_VEC) {
@@ -1231,9 +1269,11 @@ __global__ __launch_bounds__(kSweepThreads) void k_backsub(
 }
 
 // camera-major [C][6] <- plane-major [6][C]
-__global__ void k_transpose6(const double* __restrict__ planes, int C, double* __restrict__ out) {
+__global__ void k_transpose6(const double* __restrict__ planes, int C, double* __restrict__ out,
+                             const PcgCtrl* __restrict__ ctrl2, int L) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 6 * C) return;
+    if (ctrl2 != nullptr) planes += (size_t)((ctrl2[L & 1].iters & 1) * kPcgVecs + kPcgX) * 6 * C;
     const int k = i / C, c = i - k * C;
     out[6 * c + k] = planes[i];
 }

@@ -116,10 +116,10 @@ struct sfmba_handle {
     int jcur = 0;
     DevBuf V, Vinv, gp, e;
     DevBuf g, si, sg, p;                     // n-vectors; p = [dc | dp]
-    DevBuf Dc, Minv, xk, rk, pk, sk, uk;       // camera-sized PCG vectors, plane-major [k][C]
+    DevBuf Dc, Minv, vecs, vtmp;               // camera-sized, plane-major [k][C]; vecs = 2 sets x (x r p s u)
     DevBuf part, ctrl, tables;
     DevBuf arena_own;
-    double* arena = nullptr;                 // [acc 6C | Ugc 27C | scal 16]
+    double* arena = nullptr;                 // [acc0 6C | acc1 6C | Ugc 27C | 32 scalars]
     int64_t arena_doubles = 0;
     sfmba_allreduce_fn ar_fn = nullptr;
     void* ar_ctx = nullptr;
@@ -135,9 +135,10 @@ struct sfmba_handle {
     double* tab = nullptr;
     double* tab_new = nullptr;
 
-    double* acc() const { return arena; }
-    double* Ugc() const { return arena + 6 * C; }
-    double* scal() const { return arena + 33 * C; }
+    double* acc() const { return arena; }    // two accumulators (PCG ping-pong); [0] also serves the rhs sweep
+    double* Ugc() const { return arena + 12 * C; }
+    double* scal() const { return arena + 39 * C; }
+    int pcg_L = 0;                           // launches (sweep+update pairs) since pcg_start
     int red_bc = 1, red_grid = 2;            // block split of the parameter-vector reductions
 };
 
@@ -321,8 +322,10 @@ int launch_normal_blocks(sfmba_handle* h) {
     return 0;
 }
 
+// MODE 0 inside the PCG: vin = base of the vector sets, ctrl2/L select set and accumulator on the
+// device; MODE 0 standalone (test entry): vin = the vector itself, ctrl2 = nullptr; MODE 1: zin = e.
 template <int MODE>
-int launch_schur_sweep(sfmba_handle* h, const double* vin, const double* zin, const PcgCtrl* ctrl) {
+int launch_schur_sweep(sfmba_handle* h, const double* vin, const double* zin, const PcgCtrl* ctrl2, int L) {
     const int grid = (h->n_ranges + kWavesPerSweepBlock - 1) / kWavesPerSweepBlock;
     if (h->lds_acc) {
         const size_t lds = sizeof(double) * 12 * h->C;
@@ -330,12 +333,12 @@ int launch_schur_sweep(sfmba_handle* h, const double* vin, const double* zin, co
         CHK(set_lds(h, kern, lds));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), lds, h->stream, h->ranges.as<int2>(),
                            h->n_ranges, obs_arrays(h), vin, h->Vinv.as<double>(), zin, h->acc(),
-                           (int)h->C, ctrl);
+                           (int)h->C, ctrl2, L);
     } else {
         auto kern = k_schur_sweep<false, MODE>;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), 0, h->stream, h->ranges.as<int2>(),
                            h->n_ranges, obs_arrays(h), vin, h->Vinv.as<double>(), zin, h->acc(),
-                           (int)h->C, ctrl);
+                           (int)h->C, ctrl2, L);
     }
     HIPCHK(h, hipGetLastError());
     return 0;
@@ -364,20 +367,22 @@ int launch_backsub(sfmba_handle* h, int* nparts) {
     const int grid = (h->n_ranges + kWavesPerSweepBlock - 1) / kWavesPerSweepBlock;
     double* dc = h->p.as<double>();
     double* dp = dc + 6 * h->C;
+    const PcgCtrl* ctrl2 = h->ctrl.as<PcgCtrl>();
     if (h->lds_vec) {
         const size_t lds = sizeof(double) * 6 * h->C;
         auto kern = k_backsub<true>;
         CHK(set_lds(h, kern, lds));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), lds, h->stream, h->ranges.as<int2>(),
-                           h->n_ranges, obs_arrays(h), h->xk.as<double>(), dc, h->Vinv.as<double>(),
-                           h->gp.as<double>(), h->t1.as<double>(), dp, h->part.as<double>(), (int)h->C);
+                           h->n_ranges, obs_arrays(h), h->vecs.as<double>(), dc, h->Vinv.as<double>(),
+                           h->gp.as<double>(), h->t1.as<double>(), dp, h->part.as<double>(), (int)h->C,
+                           ctrl2, h->pcg_L);
     } else {
         hipLaunchKernelGGL(k_transpose6, dim3((6 * h->C + 255) / 256), dim3(256), 0, h->stream,
-                           h->xk.as<double>(), (int)h->C, dc);
+                           h->vecs.as<double>(), (int)h->C, dc, ctrl2, h->pcg_L);
         hipLaunchKernelGGL(k_backsub<false>, dim3(grid), dim3(kSweepThreads), 0, h->stream,
-                           h->ranges.as<int2>(), h->n_ranges, obs_arrays(h), h->xk.as<double>(), dc,
+                           h->ranges.as<int2>(), h->n_ranges, obs_arrays(h), h->vecs.as<double>(), dc,
                            h->Vinv.as<double>(), h->gp.as<double>(), h->t1.as<double>(), dp,
-                           h->part.as<double>(), (int)h->C);
+                           h->part.as<double>(), (int)h->C, (const PcgCtrl*)nullptr, 0);
     }
     HIPCHK(h, hipGetLastError());
     *nparts = grid;
@@ -434,40 +439,37 @@ int pcg_max_iters(const sfmba_handle* h, const sfmba_options& opt) {
     return opt.pcg_max_iter > 0 ? opt.pcg_max_iter : (int)std::max<int64_t>(20, 2 * 6 * h->C);
 }
 
-// x = 0, r = rhs, u = Minv r (acc holds the reduced right-hand side term of the MODE 1 sweep)
+// x = 0, r = rhs, u = Minv r (acc0 holds the reduced right-hand side term of the MODE 1 sweep)
 int pcg_start(sfmba_handle* h, const sfmba_options& opt) {
     hipLaunchKernelGGL(k_pcg_init, dim3(1), dim3(1024), 0, h->stream, h->Ugc(), h->acc(), h->Minv.as<double>(),
-                       (int)h->C, h->xk.as<double>(), h->rk.as<double>(), h->pk.as<double>(), h->sk.as<double>(),
-                       h->uk.as<double>(), opt.pcg_tol, pcg_max_iters(h, opt), h->ctrl.as<PcgCtrl>());
+                       (int)h->C, h->vecs.as<double>(), opt.pcg_tol, pcg_max_iters(h, opt), h->ctrl.as<PcgCtrl>());
     HIPCHK(h, hipGetLastError());
+    h->pcg_L = 0;
     return 0;
 }
 
 // enqueue `count` PCG iterations (sweep + all-reduce + update); iterations after convergence are
 // device-side no-ops, so over-enqueueing is harmless and deterministic
 int pcg_enqueue(sfmba_handle* h, int count) {
-    PcgCtrl* ctrl = h->ctrl.as<PcgCtrl>();
+    PcgCtrl* ctrl2 = h->ctrl.as<PcgCtrl>();
     for (int k = 0; k < count; ++k) {
-        CHK(launch_schur_sweep<0>(h, h->uk.as<double>(), nullptr, ctrl));
-        CHK(exchange(h, h->acc(), 6 * h->C, 0));
-        hipLaunchKernelGGL(k_pcg_update, dim3(1), dim3(1024), 0, h->stream, h->acc(), h->Dc.as<double>(),
-                           h->Minv.as<double>(), (int)h->C, h->xk.as<double>(), h->rk.as<double>(),
-                           h->pk.as<double>(), h->sk.as<double>(), h->uk.as<double>(), ctrl);
+        const int L = h->pcg_L;
+        CHK(launch_schur_sweep<0>(h, h->vecs.as<double>(), nullptr, ctrl2, L));
+        CHK(exchange(h, h->acc() + (size_t)(L & 1) * 6 * h->C, 6 * h->C, 0));   // set == L & 1 until done
+        hipLaunchKernelGGL(k_pcg_update, dim3(kPcgUpdateBlocks), dim3(1024), 0, h->stream, h->acc(),
+                           h->Dc.as<double>(), h->Minv.as<double>(), (int)h->C, h->vecs.as<double>(), ctrl2, L);
         HIPCHK(h, hipGetLastError());
+        h->pcg_L = L + 1;
     }
     return 0;
 }
 
 int pcg_read(sfmba_handle* h, PcgCtrl* hc) {
     static_assert(sizeof(PcgCtrl) <= 24 * sizeof(double), "PcgCtrl fits the pinned tail");
-    HIPCHK(h, hipMemcpyAsync(h->h_scal + 40, h->ctrl.p, sizeof *hc, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_scal + 40, h->ctrl.as<PcgCtrl>() + (h->pcg_L & 1), sizeof *hc,
+                             hipMemcpyDeviceToHost, h->stream));
     CHK(wait_stream(h));
     memcpy(hc, h->h_scal + 40, sizeof *hc);
-#ifdef SFMBA_STAMPS
-    fprintf(stderr, "[stamps] k_pcg_update phases (us):");
-    for (int k = 1; k < 8; ++k) fprintf(stderr, " %.2f", (double)(hc->stamp[k] - hc->stamp[k - 1]) * 0.01);
-    fprintf(stderr, "  total %.2f\n", (double)(hc->stamp[7] - hc->stamp[0]) * 0.01);
-#endif
     return 0;
 }
 
@@ -568,7 +570,7 @@ int sfmba_set_stream(sfmba_handle* h, void* hip_stream) {
     return 0;
 }
 
-int64_t sfmba_exchange_doubles(int64_t n_cameras) { return 33 * n_cameras + kScalSlots; }   // kScalSlots = 32
+int64_t sfmba_exchange_doubles(int64_t n_cameras) { return 39 * n_cameras + kScalSlots; }   // kScalSlots = 32
 
 int sfmba_set_exchange(sfmba_handle* h, void* arena, int64_t arena_doubles, sfmba_allreduce_fn fn,
                        void* ctx, int64_t n_obs_total) {
@@ -718,15 +720,12 @@ int sfmba_set_problem(sfmba_handle* h, int64_t C, int64_t P, int64_t N, const in
     HIPCHK(h, h->p.ensure(sizeof(double) * h->n));
     HIPCHK(h, h->Dc.ensure(sizeof(double) * 6 * C));
     HIPCHK(h, h->Minv.ensure(sizeof(double) * 21 * C));
-    HIPCHK(h, h->xk.ensure(sizeof(double) * 6 * C));
-    HIPCHK(h, h->rk.ensure(sizeof(double) * 6 * C));
-    HIPCHK(h, h->pk.ensure(sizeof(double) * 6 * C));
-    HIPCHK(h, h->sk.ensure(sizeof(double) * 6 * C));
-    HIPCHK(h, h->uk.ensure(sizeof(double) * 6 * C));
+    HIPCHK(h, h->vecs.ensure(sizeof(double) * 2 * kPcgVecs * 6 * C));
+    HIPCHK(h, h->vtmp.ensure(sizeof(double) * 6 * C));
     h->red_bc = grid_1d(6 * C, 256, 32);
     h->red_grid = h->red_bc + grid_1d(3 * P, 256, 992);
     HIPCHK(h, h->part.ensure(sizeof(double) * (size_t)(2048 * kNQ)));
-    HIPCHK(h, h->ctrl.ensure(sizeof(PcgCtrl)));
+    HIPCHK(h, h->ctrl.ensure(2 * sizeof(PcgCtrl)));
     if (h->nb_passes > 0) {
         const int per = (27 + h->nb_passes - 1) / h->nb_passes;
         const size_t nblk = (ranges.size() + kWavesPerSweepBlock - 1) / kWavesPerSweepBlock;
@@ -840,13 +839,13 @@ int sfmba_schur_matvec(sfmba_handle* h, const double* x, const double* dc, const
     for (int64_t c = 0; c < C; ++c)
         for (int k = 0; k < 6; ++k) vp[k * C + c] = v[6 * c + k];
     HIPCHK(h, hipMemcpyAsync(h->e.p, dp, sizeof(double) * 3 * h->P, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->pk.p, vp.data(), sizeof(double) * 6 * C, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->vtmp.p, vp.data(), sizeof(double) * 6 * C, hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(k_point_prep, dim3((h->P + 255) / 256), dim3(256), 0, h->stream, h->V.as<double>(),
                        h->gp.as<double>(), (const double*)nullptr, h->e.as<double>(), (int)h->P, 0.0,
                        (const double*)nullptr, h->Vinv.as<double>(), (double*)nullptr);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemsetAsync(h->acc(), 0, sizeof(double) * 6 * C, h->stream));
-    CHK(launch_schur_sweep<0>(h, h->pk.as<double>(), nullptr, nullptr));
+    CHK(launch_schur_sweep<0>(h, h->vtmp.as<double>(), nullptr, nullptr, 0));
     CHK(exchange(h, h->acc(), 6 * C, 0));
     std::vector<double> a(6 * C);
     HIPCHK(h, hipMemcpyAsync(a.data(), h->acc(), sizeof(double) * 6 * C, hipMemcpyDeviceToHost, h->stream));
@@ -872,7 +871,7 @@ int sfmba_time_kernel(sfmba_handle* h, const double* x, int32_t which, int32_t r
                            h->gp.as<double>(), h->si.as<double>() + 6 * h->C, (const double*)nullptr, (int)h->P,
                            1e-6, (const double*)nullptr, h->Vinv.as<double>(), h->e.as<double>());
         HIPCHK(h, hipMemsetAsync(h->acc(), 0, sizeof(double) * 6 * h->C, h->stream));
-        HIPCHK(h, hipMemcpyAsync(h->pk.p, h->g.p, sizeof(double) * 6 * h->C, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->vtmp.p, h->g.p, sizeof(double) * 6 * h->C, hipMemcpyDeviceToDevice, h->stream));
     }
     hipEvent_t e0, e1;
     HIPCHK(h, hipEventCreate(&e0));
@@ -884,7 +883,7 @@ int sfmba_time_kernel(sfmba_handle* h, const double* x, int32_t which, int32_t r
             case 0: CHK((launch_resjac<true, true>(h, h->x, h->tab, h->jcur, &np))); break;
             case 1: CHK((launch_resjac<false, false>(h, h->x, h->tab, h->jcur, &np))); break;
             case 2: CHK(launch_normal_blocks(h)); break;
-            case 3: CHK(launch_schur_sweep<0>(h, h->pk.as<double>(), nullptr, nullptr)); break;
+            case 3: CHK(launch_schur_sweep<0>(h, h->vtmp.as<double>(), nullptr, nullptr, 0)); break;
             case 10:   // streaming-store ceiling: fill the 12 Jc planes, 16 B per lane, one stream
                 hipLaunchKernelGGL(k_fill16, dim3(h->n_cu * 2), dim3(1024), 0, h->stream, h->Jc[h->jcur].as<double>(),
                                    (int64_t)(6 * h->ld), 1.0);
@@ -997,7 +996,7 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
                            h->Minv.as<double>());
         HIPCHK(h, hipGetLastError());
         HIPCHK(h, hipMemsetAsync(h->acc(), 0, sizeof(double) * 6 * C, h->stream));
-        CHK(launch_schur_sweep<1>(h, nullptr, h->e.as<double>(), nullptr));      // reduced rhs
+        CHK(launch_schur_sweep<1>(h, nullptr, h->e.as<double>(), nullptr, 0));   // reduced rhs -> acc0
         CHK(exchange(h, h->acc(), 6 * C, 0));
         CHK(pcg_start(h, opt));                                 // replaces lsmr, trf.py:477-480
         PcgCtrl hc{};
@@ -1015,7 +1014,8 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
         };
         CHK(tail());
         if (pcg_guess > 0) {
-            HIPCHK(h, hipMemcpyAsync(h->h_scal + 40, h->ctrl.p, sizeof hc, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipMemcpyAsync(h->h_scal + 40, h->ctrl.as<PcgCtrl>() + (h->pcg_L & 1), sizeof hc,
+                                     hipMemcpyDeviceToHost, h->stream));
             CHK(fetch_scalars(h));                              // hand-off 1
             memcpy(&hc, h->h_scal + 40, sizeof hc);
             if (hc.done == 0) {                                 // guess too small: finish and redo the tail
