@@ -441,7 +441,11 @@ __global__ __launch_bounds__(kSweepThreads) void k_normal_blocks_lds(
         for (int a = 0; a < 6; ++a)
 #pragma unroll
             for (int b = a; b < 6; ++b) {
+#ifndef SFMBA_ABLATE_NB_ATOMICS
                 if (n >= col0 && n < col1) unsafeAtomicAdd(u + n, jc[a] * jc[b] + jc[6 + a] * jc[6 + b]);
+#else
+                if (n >= col0 && n < col1 && jc[a] * jc[b] == 123.456) u[n] = jc[6 + a];
+#endif
                 ++n;
             }
 #pragma unroll
@@ -507,7 +511,9 @@ __global__ __launch_bounds__(kSweepThreads) void k_normal_blocks_lds(
 #pragma unroll
             for (int q = 0; q < 9; ++q) v[q] = 0.0;
         }
+#ifndef SFMBA_ABLATE_NB_SEGRED
         seg_reduce<9>(v, act ? sb : -1 - lane, lane);
+#endif
         if (act && i == sb) {
 #pragma unroll
             for (int q = 0; q < 6; ++q) V[(size_t)p * 6 + q] = v[q];
@@ -849,9 +855,21 @@ __global__ void k_cam_prep(const double* __restrict__ Ugc, const double* __restr
 // (MODE 0), or the reduced right-hand side term acc_c -= sum Jc_i^T Jp_i e_p (MODE 1, z = e given).
 // S v = acc + Dc v is completed by k_pcg_update.  LDS_ACC: v and acc live in LDS (2 * 6C doubles).
 // ---------------------------------------------------------------------------------------------
+// The walk over a wave's observation range is precomputed on the host (it depends only on the problem
+// structure): steps[s] = (first observation, count); count <= 64 is a batch that ends on a point
+// boundary, count > 64 a single point with that many observations.  wsteps[wave] = (first step, number
+// of steps).  With the step list known, the index loads of step s+1 are issued while step s computes,
+// so a step costs one memory round trip (its Jacobian blocks) instead of three dependent ones.
+struct StepTable {
+    const int2* __restrict__ wsteps;
+    const int2* __restrict__ steps;
+    const unsigned char* __restrict__ run_off;    // offset of each observation inside its point's run (clipped to 255)
+    int n_waves;
+};
+
 template <bool LDS_ACC, int MODE>
 __global__ __launch_bounds__(kSweepThreads) void k_schur_sweep(
-    const int2* __restrict__ ranges, int n_ranges, ObsArrays o, const double* __restrict__ vin,
+    StepTable st, ObsArrays o, const double* __restrict__ vin,
     const double* __restrict__ Vinv, const double* __restrict__ zin, double* __restrict__ acc, int C,
     const PcgCtrl* __restrict__ ctrl2, int L) {
     extern __shared__ __align__(16) double smem[];
@@ -865,13 +883,23 @@ __global__ __launch_bounds__(kSweepThreads) void k_schur_sweep(
         vin += (size_t)(set * kPcgVecs + kPcgU) * n6;
         acc += (size_t)set * n6;
     }
+    const int wg = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    int s = 0, s_end = 0;
+    if (wg < st.n_waves) { const int2 w = st.wsteps[wg]; s = w.x; s_end = w.x + w.y; }
+    // indices of the first step are requested before the LDS tables are staged
+    int2 cur = make_int2(0, 0);
+    if (s < s_end) cur = st.steps[s];
+    int i = cur.x + lane, c = 0, p = 0, off = 0;
+    if (cur.y <= 64 && lane < cur.y) { c = o.cam_idx[i]; p = o.pt_idx[i]; off = st.run_off[i]; }
+
     double* s_v = smem;
     double* s_acc = smem + n6;
     if (LDS_ACC) {
-        for (int i = threadIdx.x; i < n6; i += blockDim.x) {       // i = k*C + c (global, coalesced)
-            const int k = i / C, c = i - k * C;
-            s_v[6 * c + k] = (MODE == 0) ? vin[i] : 0.0;
-            s_acc[6 * c + k] = 0.0;
+        for (int e = threadIdx.x; e < n6; e += blockDim.x) {       // e = k*C + c (global, coalesced)
+            const int k = e / C, cc = e - k * C;
+            s_v[6 * cc + k] = (MODE == 0) ? vin[e] : 0.0;
+            s_acc[6 * cc + k] = 0.0;
         }
         __syncthreads();
     }
@@ -881,50 +909,46 @@ __global__ __launch_bounds__(kSweepThreads) void k_schur_sweep(
     // global vectors plane-major
     const int cs = LDS_ACC ? 6 : 1, ks = LDS_ACC ? 1 : C;
 
-    const int wg = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    int pos = 0, end = 0;
-    if (wg < n_ranges) { const int2 rg = ranges[wg]; pos = rg.x; end = rg.y; }
-
     // per-observation pieces
-    auto jcv = [&](const double* jc, int c, double& t0, double& t1) {
+    auto jcv = [&](const double* jc, int cc, double& t0, double& t1) {
         t0 = 0.0; t1 = 0.0;
         if (MODE == 0) {
-            const double* a = vv + cs * c;
+            const double* a = vv + cs * cc;
 #pragma unroll
             for (int k = 0; k < 6; ++k) { const double ak = a[ks * k]; t0 += jc[k] * ak; t1 += jc[6 + k] * ak; }
         }
     };
-    auto scatter = [&](const double* jc, const double* jp, int c, double t0, double t1, double z0,
+    auto scatter = [&](const double* jc, const double* jp, int cc, double t0, double t1, double z0,
                        double z1, double z2) {
         const double u0 = t0 - (jp[0] * z0 + jp[1] * z1 + jp[2] * z2);
         const double u1 = t1 - (jp[3] * z0 + jp[4] * z1 + jp[5] * z2);
 #ifndef SFMBA_ABLATE_SCATTER
 #pragma unroll
-        for (int k = 0; k < 6; ++k) unsafeAtomicAdd(av + cs * c + ks * k, jc[k] * u0 + jc[6 + k] * u1);
+        for (int k = 0; k < 6; ++k) unsafeAtomicAdd(av + cs * cc + ks * k, jc[k] * u0 + jc[6 + k] * u1);
 #else
         double sacc = 0.0;
 #pragma unroll
         for (int k = 0; k < 6; ++k) sacc += jc[k] * u0 + jc[6 + k] * u1;
-        if (sacc == 123.456) av[cs * c] = sacc;                             // keep the values live
+        if (sacc == 123.456) av[cs * cc] = sacc;                            // keep the values live
 #endif
     };
 
-    while (pos < end) {
-        const int i = pos + lane;
-        const bool in = i < end;
-        const int p = in ? o.pt_idx[i] : o.pt_idx[pos];
-        const int sb = o.pt_ptr[p], se = o.pt_ptr[p + 1];
-        const bool complete = in && (se <= pos + 64);
-        const int n_take = __popcll(__ballot(complete));
+    while (s < s_end) {
+        // ---- request the next step's indices ---------------------------------------------------
+        int2 nxt = make_int2(0, 0);
+        if (s + 1 < s_end) nxt = st.steps[s + 1];
+        const int in_ = nxt.x + lane;
+        int cn = 0, pn = 0, offn = 0;
+        if (nxt.y <= 64 && lane < nxt.y) { cn = o.cam_idx[in_]; pn = o.pt_idx[in_]; offn = st.run_off[in_]; }
+
         double jc[12], jp[6];
-        if (n_take == 0) {                         // long run
-            const int run_end = __shfl(se, 0);
-            const int pp = __shfl(p, 0);
+        if (cur.y > 64) {                          // one point with more than 64 observations
+            const int run_end = cur.x + cur.y;
+            const int pp = o.pt_idx[cur.x];
             double z0, z1, z2;
             if (MODE == 0) {
                 double y[3] = {0.0, 0.0, 0.0};
-                for (int j = pos + lane; j < run_end; j += 64) {
+                for (int j = cur.x + lane; j < run_end; j += 64) {
                     load_blocks(o, j, jc, jp);
                     double t0, t1;
                     jcv(jc, o.cam_idx[j], t0, t1);
@@ -939,52 +963,52 @@ __global__ __launch_bounds__(kSweepThreads) void k_schur_sweep(
             } else {
                 z0 = zin[3 * (size_t)pp]; z1 = zin[3 * (size_t)pp + 1]; z2 = zin[3 * (size_t)pp + 2];
             }
-            for (int j = pos + lane; j < run_end; j += 64) {
+            for (int j = cur.x + lane; j < run_end; j += 64) {
                 load_blocks(o, j, jc, jp);
-                const int c = o.cam_idx[j];
+                const int cc = o.cam_idx[j];
                 double t0, t1;
-                jcv(jc, c, t0, t1);
-                scatter(jc, jp, c, t0, t1, z0, z1, z2);
+                jcv(jc, cc, t0, t1);
+                scatter(jc, jp, cc, t0, t1, z0, z1, z2);
             }
-            pos = run_end;
-            continue;
-        }
-        const bool act = lane < n_take;
-        int c = 0;
-        double t0 = 0.0, t1 = 0.0, z0 = 0.0, z1 = 0.0, z2 = 0.0;
-        if (act) {
-            load_blocks(o, i, jc, jp);
-            c = o.cam_idx[i];
-            jcv(jc, c, t0, t1);
-        }
-        if (MODE == 0) {
-            double y[3] = {0.0, 0.0, 0.0};
+        } else {
+            const bool act = lane < cur.y;
+            double t0 = 0.0, t1 = 0.0, z0 = 0.0, z1 = 0.0, z2 = 0.0;
+            double vi[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
             if (act) {
-                y[0] = jp[0] * t0 + jp[3] * t1; y[1] = jp[1] * t0 + jp[4] * t1;
-                y[2] = jp[2] * t0 + jp[5] * t1;
+                load_blocks(o, i, jc, jp);
+                if (MODE == 0) {                   // every lane of a run reads its point's block: no
+#pragma unroll                                     // dependent gather after the reduction
+                    for (int k = 0; k < 6; ++k) vi[k] = Vinv[6 * (size_t)p + k];
+                } else {
+                    z0 = zin[3 * (size_t)p]; z1 = zin[3 * (size_t)p + 1]; z2 = zin[3 * (size_t)p + 2];
+                }
+                jcv(jc, c, t0, t1);
             }
-            seg_reduce<3>(y, act ? sb : -1 - lane, lane);
-            if (act && i == sb) {
-                const double* vi = Vinv + 6 * (size_t)p;
-                z0 = vi[0] * y[0] + vi[1] * y[1] + vi[2] * y[2];
+            if (MODE == 0) {
+                double y[3] = {0.0, 0.0, 0.0};
+                if (act) {
+                    y[0] = jp[0] * t0 + jp[3] * t1; y[1] = jp[1] * t0 + jp[4] * t1;
+                    y[2] = jp[2] * t0 + jp[5] * t1;
+                }
+                seg_reduce<3>(y, act ? p : -1 - lane, lane);          // run key = point index
+                z0 = vi[0] * y[0] + vi[1] * y[1] + vi[2] * y[2];      // meaningful on run heads
                 z1 = vi[1] * y[0] + vi[3] * y[1] + vi[4] * y[2];
                 z2 = vi[2] * y[0] + vi[4] * y[1] + vi[5] * y[2];
+                const int head = act ? lane - off : lane;
+                z0 = __shfl(z0, head); z1 = __shfl(z1, head); z2 = __shfl(z2, head);
             }
-            const int head = act ? lane - (i - sb) : lane;
-            z0 = __shfl(z0, head); z1 = __shfl(z1, head); z2 = __shfl(z2, head);
-        } else if (act) {
-            z0 = zin[3 * (size_t)p]; z1 = zin[3 * (size_t)p + 1]; z2 = zin[3 * (size_t)p + 2];
+            if (act) scatter(jc, jp, c, t0, t1, z0, z1, z2);
         }
-        if (act) scatter(jc, jp, c, t0, t1, z0, z1, z2);
-        pos += n_take;
+        cur = nxt; i = in_; c = cn; p = pn; off = offn;
+        ++s;
     }
     if (LDS_ACC) {
         __syncthreads();
-#ifndef SFMBA_ABLATE_FLUSH          // timing-only ablation builds (tools/ablate.sh), never shipped
-        for (int i = threadIdx.x; i < n6; i += blockDim.x) {
-            const int k = i / C, c = i - k * C;
-            const double a = s_acc[6 * c + k];
-            if (a != 0.0) unsafeAtomicAdd(acc + i, a);
+#ifndef SFMBA_ABLATE_FLUSH          // timing-only ablation builds, never shipped
+        for (int e = threadIdx.x; e < n6; e += blockDim.x) {
+            const int k = e / C, cc = e - k * C;
+            const double a = s_acc[6 * cc + k];
+            if (a != 0.0) unsafeAtomicAdd(acc + e, a);
         }
 #else
         if (threadIdx.x == 0 && s_acc[0] == 123.456) acc[0] = s_acc[1];     // keep the table live

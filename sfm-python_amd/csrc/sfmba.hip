@@ -110,7 +110,8 @@ struct sfmba_handle {
     bool lds_tab = true, lds_acc = true, lds_vec = true;
     int nb_passes = 1;                       // column passes of the LDS normal-block tables; 0 = global atomics
 
-    DevBuf cam_idx, pt_idx, pt_ptr, uv, ranges;
+    DevBuf cam_idx, pt_idx, pt_ptr, uv, ranges, wsteps, steps, run_off;
+    int n_steps = 0;
     DevBuf xa, xb, tabA, tabB, r[2], Jc[2], Jp[2], t1;   // J and r double-buffered: a trial step is
                                                        // evaluated into the spare set and swapped in on accept
     int jcur = 0;
@@ -207,6 +208,10 @@ int set_lds(sfmba_handle* h, Kern k, size_t bytes) {
 ObsArrays obs_arrays(const sfmba_handle* h) {
     return ObsArrays{h->cam_idx.as<int>(), h->pt_idx.as<int>(), h->pt_ptr.as<int>(),
                      h->Jc[h->jcur].as<double>(), h->Jp[h->jcur].as<double>(), h->ld};
+}
+
+StepTable step_table(const sfmba_handle* h) {
+    return StepTable{h->wsteps.as<int2>(), h->steps.as<int2>(), h->run_off.as<unsigned char>(), h->n_ranges};
 }
 
 int grid_1d(int64_t n, int block, int cap) {
@@ -331,14 +336,12 @@ int launch_schur_sweep(sfmba_handle* h, const double* vin, const double* zin, co
         const size_t lds = sizeof(double) * 12 * h->C;
         auto kern = k_schur_sweep<true, MODE>;
         CHK(set_lds(h, kern, lds));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), lds, h->stream, h->ranges.as<int2>(),
-                           h->n_ranges, obs_arrays(h), vin, h->Vinv.as<double>(), zin, h->acc(),
-                           (int)h->C, ctrl2, L);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), lds, h->stream, step_table(h),
+                           obs_arrays(h), vin, h->Vinv.as<double>(), zin, h->acc(), (int)h->C, ctrl2, L);
     } else {
         auto kern = k_schur_sweep<false, MODE>;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), 0, h->stream, h->ranges.as<int2>(),
-                           h->n_ranges, obs_arrays(h), vin, h->Vinv.as<double>(), zin, h->acc(),
-                           (int)h->C, ctrl2, L);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), 0, h->stream, step_table(h),
+                           obs_arrays(h), vin, h->Vinv.as<double>(), zin, h->acc(), (int)h->C, ctrl2, L);
     }
     HIPCHK(h, hipGetLastError());
     return 0;
@@ -684,6 +687,33 @@ int sfmba_set_problem(sfmba_handle* h, int64_t C, int64_t P, int64_t N, const in
         }
     }
     h->n_ranges = (int)ranges.size();
+    // step table of the sweeps: per wave range, batches of <= 64 observations that end on a point
+    // boundary; a point with more than 64 observations is one step of its own
+    std::vector<int2> wsteps(ranges.size()), steps;
+    std::vector<unsigned char> run_off(h->ld, 0);
+    for (int64_t p = 0; p < P; ++p)
+        for (int64_t k = ptr[p]; k < ptr[p + 1]; ++k) run_off[k] = (unsigned char)std::min<int64_t>(255, k - ptr[p]);
+    for (size_t w = 0; w < ranges.size(); ++w) {
+        const int first = (int)steps.size();
+        int64_t pos = ranges[w].x;
+        const int64_t end = ranges[w].y;
+        while (pos < end) {
+            const int64_t pfirst = pi[pos];
+            if (ptr[pfirst + 1] - pos > 64) {                    // long run (pos is always a run start)
+                steps.push_back(make_int2((int)pos, (int)(ptr[pfirst + 1] - pos)));
+                pos = ptr[pfirst + 1];
+                continue;
+            }
+            // largest run boundary <= pos + 64
+            int64_t lim = std::min<int64_t>(pos + 64, end), cut;
+            if (lim == end) cut = end;
+            else { const int64_t pl = pi[lim]; cut = (ptr[pl] == lim) ? lim : ptr[pl]; }   // lim inside a run -> its start
+            steps.push_back(make_int2((int)pos, (int)(cut - pos)));
+            pos = cut;
+        }
+        wsteps[w] = make_int2(first, (int)steps.size() - first);
+    }
+    h->n_steps = (int)steps.size();
     h->lds_tab = (size_t)C * kCamTab * sizeof(double) <= kLdsDynMax;
     h->lds_acc = (size_t)C * 12 * sizeof(double) <= kLdsDynMax;
     h->lds_vec = (size_t)C * 6 * sizeof(double) <= kLdsDynMax;
@@ -699,6 +729,9 @@ int sfmba_set_problem(sfmba_handle* h, int64_t C, int64_t P, int64_t N, const in
     HIPCHK(h, h->pt_ptr.ensure(sizeof(int) * (P + 1)));
     HIPCHK(h, h->uv.ensure(sizeof(double) * 2 * ld));
     HIPCHK(h, h->ranges.ensure(sizeof(int2) * std::max<size_t>(1, ranges.size())));
+    HIPCHK(h, h->wsteps.ensure(sizeof(int2) * std::max<size_t>(1, wsteps.size())));
+    HIPCHK(h, h->steps.ensure(sizeof(int2) * std::max<size_t>(1, steps.size())));
+    HIPCHK(h, h->run_off.ensure(ld));
     HIPCHK(h, h->xa.ensure(sizeof(double) * h->n));
     HIPCHK(h, h->xb.ensure(sizeof(double) * h->n));
     HIPCHK(h, h->tabA.ensure(sizeof(double) * kCamTab * C));
@@ -741,8 +774,12 @@ int sfmba_set_problem(sfmba_handle* h, int64_t C, int64_t P, int64_t N, const in
     HIPCHK(h, hipMemcpyAsync(h->pt_idx.p, pi.data(), sizeof(int) * ld, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->pt_ptr.p, ptr.data(), sizeof(int) * (P + 1), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->uv.p, uvs.data(), sizeof(double) * 2 * ld, hipMemcpyHostToDevice, h->stream));
-    if (!ranges.empty())
+    if (!ranges.empty()) {
         HIPCHK(h, hipMemcpyAsync(h->ranges.p, ranges.data(), sizeof(int2) * ranges.size(), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->wsteps.p, wsteps.data(), sizeof(int2) * wsteps.size(), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->steps.p, steps.data(), sizeof(int2) * steps.size(), hipMemcpyHostToDevice, h->stream));
+    }
+    HIPCHK(h, hipMemcpyAsync(h->run_off.p, run_off.data(), ld, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemsetAsync(h->arena, 0, sizeof(double) * (size_t)sfmba_exchange_doubles(C), h->stream));
     HIPCHK(h, hipMemsetAsync(h->r[0].p, 0, sizeof(double) * 2 * ld, h->stream));
     HIPCHK(h, hipMemsetAsync(h->r[1].p, 0, sizeof(double) * 2 * ld, h->stream));
