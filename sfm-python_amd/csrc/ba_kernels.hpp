@@ -113,10 +113,8 @@ __device__ __forceinline__ void seg_reduce(double (&v)[NV], int key, int lane) {
 // bundle_adjustment.py:25, which the reference rebuilds per OBSERVATION), and the coefficients of the
 // right Jacobian Jr = I - b [w]x + c [w]x^2 used by d r / d w.
 // ---------------------------------------------------------------------------------------------
-__global__ void k_cam_table(const double* __restrict__ xc, int C, double* __restrict__ tab) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const double wx = xc[6 * c + 0], wy = xc[6 * c + 1], wz = xc[6 * c + 2];
+__device__ __forceinline__ void cam_table_row(const double* __restrict__ prm, double* __restrict__ t) {
+    const double wx = prm[0], wy = prm[1], wz = prm[2];
     const double th2 = wx * wx + wy * wy + wz * wz;
     const double th = sqrt(th2);
     double a, b, cc;
@@ -135,13 +133,48 @@ __global__ void k_cam_table(const double* __restrict__ xc, int C, double* __rest
     } else {
         cc = (th - sin(th)) / (th2 * th);
     }
-    double* t = tab + (size_t)c * kCamTab;
     t[0] = 1.0 + b * (wx * wx - th2); t[1] = -a * wz + b * wx * wy;     t[2] = a * wy + b * wx * wz;
     t[3] = a * wz + b * wx * wy;      t[4] = 1.0 + b * (wy * wy - th2); t[5] = -a * wx + b * wy * wz;
     t[6] = -a * wy + b * wx * wz;     t[7] = a * wx + b * wy * wz;      t[8] = 1.0 + b * (wz * wz - th2);
-    t[9] = xc[6 * c + 3]; t[10] = xc[6 * c + 4]; t[11] = xc[6 * c + 5];
+    t[9] = prm[3]; t[10] = prm[4]; t[11] = prm[5];
     t[12] = wx; t[13] = wy; t[14] = wz;
     t[15] = b; t[16] = cc;
+}
+
+__global__ void k_cam_table(const double* __restrict__ xc, int C, double* __restrict__ tab) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double prm[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) prm[k] = xc[6 * (size_t)c + k];
+    cam_table_row(prm, tab + (size_t)c * kCamTab);
+}
+
+// Trial point and its camera table in one launch: x_new = x + c1 (g / si^2) + c2 p (step = D step_h,
+// SCIPY trf.py:495-497).  Blocks [0, bc) take one camera per thread (six parameters, then the table
+// row of the NEW parameters); the remaining blocks stream the point coordinates.
+__global__ __launch_bounds__(256) void k_step_table(const double* __restrict__ x,
+                                                    const double* __restrict__ sg,
+                                                    const double* __restrict__ p, double c1, double c2,
+                                                    int C, int64_t n, int bc, double* __restrict__ x_new,
+                                                    double* __restrict__ tab) {
+    if ((int)blockIdx.x < bc) {
+        const int c = blockIdx.x * blockDim.x + threadIdx.x;
+        if (c >= C) return;
+        double prm[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const size_t e = 6 * (size_t)c + k;
+            prm[k] = x[e] + c1 * sg[e] + c2 * p[e];
+            x_new[e] = prm[k];
+        }
+        cam_table_row(prm, tab + (size_t)c * kCamTab);
+        return;
+    }
+    const int64_t n6 = 6 * (int64_t)C;
+    const int nb = gridDim.x - bc;
+    for (int64_t e = n6 + (blockIdx.x - bc) * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)nb * blockDim.x)
+        x_new[e] = x[e] + c1 * sg[e] + c2 * p[e];
 }
 
 // One observation: residual and (JAC) the 2x6 / 2x3 blocks.
@@ -674,28 +707,6 @@ __global__ void k_finish(const double* __restrict__ part, FinishJob job, int nq,
     }
 }
 
-// Regularisation of the damped Gauss-Newton step from the 1-D Cauchy problem along -g_h
-// (SCIPY trf.py:471-475, common.py:251-322), computed on the device so that the host does not have
-// to read G11 back before the Schur solve can be enqueued.  sc: exchange scalars.
-__global__ void k_reg(double* __restrict__ sc, double Delta, double reg_min) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const double a11 = sc[4] + sc[16 + 1];          // |g_h|^2: point slice (summed over ranks) + cameras
-    const double a = 0.5 * sc[1], b = -a11;         // sc[1] = G11 = |J_h g_h|^2
-    double reg = reg_min;
-    if (a11 > 0.0) {
-        const double to_tr = Delta / sqrt(a11);
-        double best = 0.0;
-        const double y_ub = to_tr * (a * to_tr + b);
-        if (y_ub < best) best = y_ub;
-        if (a != 0.0) {
-            const double ext = -0.5 * b / a;
-            if (ext > 0.0 && ext < to_tr) { const double y = ext * (a * ext + b); if (y < best) best = y; }
-        }
-        reg = fmax(-best / (Delta * Delta), reg_min);
-    }
-    sc[13] = reg;
-}
-
 // t1_i = J (D^2 g) per observation and sum |t1|^2 (the quadratic of the 1-D Cauchy problem,
 // SCIPY trf.py:471-475 / common.py:251-299).  Camera slice of D^2 g staged in LDS.
 template <bool LDS_VEC>
@@ -753,14 +764,30 @@ __device__ __forceinline__ void chol3_inverse(const double* a /*upper 6*/, doubl
     inv[5] = m22 * m22;
 }
 
-// Per point: Vinv = (V + reg diag(si_p^2))^-1 and e_p = Vinv g_p.
-__global__ void k_point_prep(const double* __restrict__ V, const double* __restrict__ gp,
-                             const double* __restrict__ sip, const double* __restrict__ dp_extra,
-                             int P, double reg, const double* __restrict__ reg_dev,
-                             double* __restrict__ Vinv, double* __restrict__ e) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= P) return;
-    if (reg_dev) reg = *reg_dev;
+// Regularisation of the damped Gauss-Newton step from the 1-D Cauchy problem along -g_h
+// (SCIPY trf.py:471-475, common.py:251-322), evaluated from the exchange scalars by whoever needs it.
+__device__ __forceinline__ double reg_from_scalars(const double* __restrict__ sc, double Delta, double reg_min) {
+    const double a11 = sc[4] + sc[16 + 1];          // |g_h|^2: point slice (summed over ranks) + cameras
+    const double a = 0.5 * sc[1], b = -a11;         // sc[1] = G11 = |J_h g_h|^2
+    double reg = reg_min;
+    if (a11 > 0.0) {
+        const double to_tr = Delta / sqrt(a11);
+        double best = 0.0;
+        const double y_ub = to_tr * (a * to_tr + b);
+        if (y_ub < best) best = y_ub;
+        if (a != 0.0) {
+            const double ext = -0.5 * b / a;
+            if (ext > 0.0 && ext < to_tr) { const double y = ext * (a * ext + b); if (y < best) best = y; }
+        }
+        reg = fmax(-best / (Delta * Delta), reg_min);
+    }
+    return reg;
+}
+
+__device__ __forceinline__ void point_prep_one(const double* __restrict__ V, const double* __restrict__ gp,
+                                               const double* __restrict__ sip, const double* __restrict__ dp_extra,
+                                               int p, double reg, double* __restrict__ Vinv,
+                                               double* __restrict__ e) {
     double a[6], inv[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) a[k] = V[(size_t)p * 6 + k];
@@ -781,17 +808,22 @@ __global__ void k_point_prep(const double* __restrict__ V, const double* __restr
     }
 }
 
+// Per point: Vinv = (V + reg diag(si_p^2))^-1 and e_p = Vinv g_p.
+__global__ void k_point_prep(const double* __restrict__ V, const double* __restrict__ gp,
+                             const double* __restrict__ sip, const double* __restrict__ dp_extra,
+                             int P, double reg, double* __restrict__ Vinv, double* __restrict__ e) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    point_prep_one(V, gp, sip, dp_extra, p, reg, Vinv, e);
+}
+
 // Per camera: Minv = (U + diag(Dc))^-1 (6x6, Cholesky), the block-Jacobi preconditioner of the
 // reduced camera system; Dc = reg si_c^2 is also written out.  Camera-sized PCG vectors (Dc, Minv,
 // acc, x, r, p, s, u) are stored plane-major, element k of camera c at [k*C + c], so that the
 // one-thread-per-camera PCG kernels read and write them fully coalesced.
-__global__ void k_cam_prep(const double* __restrict__ Ugc, const double* __restrict__ sic,
-                           const double* __restrict__ dc_extra, int C, double reg,
-                           const double* __restrict__ reg_dev, double* __restrict__ Dc,
-                           double* __restrict__ Minv) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    if (reg_dev) reg = *reg_dev;
+__device__ __forceinline__ void cam_prep_one(const double* __restrict__ Ugc, const double* __restrict__ sic,
+                                             const double* __restrict__ dc_extra, int C, int c, double reg,
+                                             double* __restrict__ Dc, double* __restrict__ Minv) {
     double A[6][6];
     {
         int n = 0;
@@ -807,33 +839,33 @@ __global__ void k_cam_prep(const double* __restrict__ Ugc, const double* __restr
         Dc[(size_t)a * C + c] = d;                      // plane-major over cameras (coalesced in the PCG)
         A[a][a] += d;
     }
-    double L[6][6];
+    double Lm[6][6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-        double s = A[j][j];
+        double sj = A[j][j];
 #pragma unroll
-        for (int k = 0; k < j; ++k) s -= L[j][k] * L[j][k];
-        const double ljj = sqrt(s);
-        L[j][j] = ljj;
+        for (int k = 0; k < j; ++k) sj -= Lm[j][k] * Lm[j][k];
+        const double ljj = sqrt(sj);
+        Lm[j][j] = ljj;
         const double inv = 1.0 / ljj;
 #pragma unroll
         for (int i = j + 1; i < 6; ++i) {
             double t = A[i][j];
 #pragma unroll
-            for (int k = 0; k < j; ++k) t -= L[i][k] * L[j][k];
-            L[i][j] = t * inv;
+            for (int k = 0; k < j; ++k) t -= Lm[i][k] * Lm[j][k];
+            Lm[i][j] = t * inv;
         }
     }
     double M[6][6];                         // M = L^-1 (lower triangular)
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-        M[j][j] = 1.0 / L[j][j];
+        M[j][j] = 1.0 / Lm[j][j];
 #pragma unroll
         for (int i = j + 1; i < 6; ++i) {
             double t = 0.0;
 #pragma unroll
-            for (int k = j; k < i; ++k) t -= L[i][k] * M[k][j];
-            M[i][j] = t / L[i][i];
+            for (int k = j; k < i; ++k) t -= Lm[i][k] * M[k][j];
+            M[i][j] = t / Lm[i][i];
         }
     }
     int n = 0;
@@ -847,6 +879,39 @@ __global__ void k_cam_prep(const double* __restrict__ Ugc, const double* __restr
             Minv[(size_t)n * C + c] = t;
             ++n;
         }
+}
+
+__global__ void k_cam_prep(const double* __restrict__ Ugc, const double* __restrict__ sic,
+                           const double* __restrict__ dc_extra, int C, double reg,
+                           double* __restrict__ Dc, double* __restrict__ Minv) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    cam_prep_one(Ugc, sic, dc_extra, C, c, reg, Dc, Minv);
+}
+
+// Everything between the Cauchy product and the reduced right-hand side in one launch: the
+// regularisation term from the exchange scalars (every thread evaluates the same few flops, block 0
+// publishes it in scalar slot 13), blocks [0, bc): one camera per thread (Dc, Minv, acc0 = 0),
+// blocks [bc, grid): one point per thread (Vinv, e).
+__global__ __launch_bounds__(64) void k_prep(double* __restrict__ sc, double Delta, double reg_min,
+                                             const double* __restrict__ Ugc, const double* __restrict__ V,
+                                             const double* __restrict__ gp, const double* __restrict__ si,
+                                             int C, int P, int bc, double* __restrict__ Dc,
+                                             double* __restrict__ Minv, double* __restrict__ acc0,
+                                             double* __restrict__ Vinv, double* __restrict__ e) {
+    const double reg = reg_from_scalars(sc, Delta, reg_min);
+    if (blockIdx.x == 0 && threadIdx.x == 0) sc[13] = reg;
+    if ((int)blockIdx.x < bc) {
+        const int c = blockIdx.x * blockDim.x + threadIdx.x;
+        if (c >= C) return;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc0[(size_t)k * C + c] = 0.0;
+        cam_prep_one(Ugc, si, nullptr, C, c, reg, Dc, Minv);
+        return;
+    }
+    const int p = (blockIdx.x - bc) * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    point_prep_one(V, gp, si + 6 * (size_t)C, nullptr, p, reg, Vinv, e);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1300,15 +1365,6 @@ __global__ void k_transpose6(const double* __restrict__ planes, int C, double* _
     if (ctrl2 != nullptr) planes += (size_t)((ctrl2[L & 1].iters & 1) * kPcgVecs + kPcgX) * 6 * C;
     const int k = i / C, c = i - k * C;
     out[6 * c + k] = planes[i];
-}
-
-// x_new = x + c1 (g / si^2) + c2 p     (step = D step_h, SCIPY trf.py:495-497)
-__global__ void k_step(const double* __restrict__ x, const double* __restrict__ sg,
-                       const double* __restrict__ p, double c1, double c2, int64_t n,
-                       double* __restrict__ x_new) {
-    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n;
-         e += (int64_t)gridDim.x * blockDim.x)
-        x_new[e] = x[e] + c1 * sg[e] + c2 * p[e];
 }
 
 // streaming-store ceiling probe: 16 B per lane, grid-stride

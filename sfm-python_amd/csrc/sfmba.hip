@@ -36,7 +36,7 @@ constexpr size_t kLdsDynMax = kLdsBytes - 512; // dynamic part; every kernel her
 // Scalars at the end of the exchange arena (32 doubles):
 //   summed over ranks [0..11]: 0 sum r^2 | 1 G11 | 2 G12 | 3 G22 | 4..11 q1..q8 of the point slice
 //   max over ranks    [12]   : q0 = max|g| of the point slice
-//   device-local      [13]   : regularisation term of this iteration (k_reg)
+//   device-local      [13]   : regularisation term of this iteration (k_prep)
 //   never exchanged   [16..24]: q0..q8 of the camera slice (replicated on every rank)
 constexpr int kScalSlots = 32;
 constexpr int kSumSlots = 12, kMaxSlot = 12, kRegSlot = 13, kCamSlot = 16;
@@ -127,6 +127,9 @@ struct sfmba_handle {
     ncclComm_t comm = nullptr;               // native RCCL communicator (sfmba_comm_init)
     int64_t n_collectives = 0;
     double* h_scal = nullptr;                // pinned
+    double* h_x = nullptr;                   // pinned staging of the parameter vector
+    size_t h_x_doubles = 0;
+    hipEvent_t ev_handoff = nullptr;
     bool solved = false;
     std::vector<const void*> lds_ready;      // kernels already opted in to 160 KiB dynamic LDS
     int last_pcg_iters = 0;
@@ -233,6 +236,19 @@ int wait_stream(sfmba_handle* h) {
         if (now_s() - t0 > 0.05) break;          // long wait: stop burning the core
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// Same, for a point in the middle of the stream (work enqueued behind it keeps running).
+int wait_event(sfmba_handle* h, hipEvent_t ev) {
+    const double t0 = now_s();
+    for (;;) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e == hipSuccess) return 0;
+        if (e != hipErrorNotReady) return fail(h, -3, "hipEventQuery failed: %s", hipGetErrorString(e));
+        if (now_s() - t0 > 0.05) break;
+    }
+    HIPCHK(h, hipEventSynchronize(ev));
     return 0;
 }
 
@@ -427,8 +443,21 @@ int fetch_scalars(sfmba_handle* h) {
 // q_k summed over the camera slice and the (rank-reduced) point slice
 double qsum(const sfmba_handle* h, int q) { return h->h_scal[3 + q] + h->h_scal[kCamSlot + q]; }
 
+// x crosses PCIe through a pinned staging buffer (an async copy from pageable memory is staged by the
+// runtime anyway, synchronously and in small pieces)
+int ensure_h_x(sfmba_handle* h) {
+    if (h->h_x && h->h_x_doubles >= (size_t)h->n) return 0;
+    if (h->h_x) { (void)hipHostFree(h->h_x); h->h_x = nullptr; h->h_x_doubles = 0; }
+    HIPCHK(h, hipHostMalloc((void**)&h->h_x, sizeof(double) * h->n, hipHostMallocDefault));
+    h->h_x_doubles = (size_t)h->n;
+    return 0;
+}
+
 int upload_x(sfmba_handle* h, const double* x_host) {
-    HIPCHK(h, hipMemcpyAsync(h->x, x_host, sizeof(double) * h->n, hipMemcpyHostToDevice, h->stream));
+    CHK(ensure_h_x(h));
+    HIPCHK(h, hipStreamSynchronize(h->stream));      // the staging buffer may still be in flight
+    memcpy(h->h_x, x_host, sizeof(double) * h->n);
+    HIPCHK(h, hipMemcpyAsync(h->x, h->h_x, sizeof(double) * h->n, hipMemcpyHostToDevice, h->stream));
     return 0;
 }
 
@@ -545,7 +574,8 @@ int sfmba_create(sfmba_handle** out, int device_id) {
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) h->n_cu = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return -3; }
     h->own_stream = true;
-    if (hipHostMalloc((void**)&h->h_scal, sizeof(double) * 64, hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc((void**)&h->h_scal, sizeof(double) * 64, hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_handoff, hipEventDisableTiming) != hipSuccess) {
         (void)hipStreamDestroy(h->stream); delete h; return -4;
     }
     *out = h;
@@ -559,6 +589,8 @@ void sfmba_destroy(sfmba_handle* h) {
     if (h->comm) { if (RcclApi* api = rccl_api()) (void)api->CommDestroy(h->comm); h->comm = nullptr; }
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     if (h->h_scal) (void)hipHostFree(h->h_scal);
+    if (h->h_x) (void)hipHostFree(h->h_x);
+    if (h->ev_handoff) (void)hipEventDestroy(h->ev_handoff);
     delete h;
 }
 
@@ -879,7 +911,7 @@ int sfmba_schur_matvec(sfmba_handle* h, const double* x, const double* dc, const
     HIPCHK(h, hipMemcpyAsync(h->vtmp.p, vp.data(), sizeof(double) * 6 * C, hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(k_point_prep, dim3((h->P + 255) / 256), dim3(256), 0, h->stream, h->V.as<double>(),
                        h->gp.as<double>(), (const double*)nullptr, h->e.as<double>(), (int)h->P, 0.0,
-                       (const double*)nullptr, h->Vinv.as<double>(), (double*)nullptr);
+                       h->Vinv.as<double>(), (double*)nullptr);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemsetAsync(h->acc(), 0, sizeof(double) * 6 * C, h->stream));
     CHK(launch_schur_sweep<0>(h, h->vtmp.as<double>(), nullptr, nullptr, 0));
@@ -906,7 +938,7 @@ int sfmba_time_kernel(sfmba_handle* h, const double* x, int32_t which, int32_t r
         CHK(launch_update_scale(h, 1));
         hipLaunchKernelGGL(k_point_prep, dim3((h->P + 255) / 256), dim3(256), 0, h->stream, h->V.as<double>(),
                            h->gp.as<double>(), h->si.as<double>() + 6 * h->C, (const double*)nullptr, (int)h->P,
-                           1e-6, (const double*)nullptr, h->Vinv.as<double>(), h->e.as<double>());
+                           1e-6, h->Vinv.as<double>(), h->e.as<double>());
         HIPCHK(h, hipMemsetAsync(h->acc(), 0, sizeof(double) * 6 * h->C, h->stream));
         HIPCHK(h, hipMemcpyAsync(h->vtmp.p, h->g.p, sizeof(double) * 6 * h->C, hipMemcpyDeviceToDevice, h->stream));
     }
@@ -975,11 +1007,11 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
 
     // Host/device hand-offs per outer iteration: ONE read-back after the whole linear phase
     // (Cauchy product, Schur PCG, back-substitution, Gram/dot reductions are enqueued without the
-    // host seeing intermediate values: the regularisation term is computed by k_reg on the device
+    // host seeing intermediate values: the regularisation term is computed by k_prep on the device
     // and the PCG stops itself through its device-side control block) and ONE per trial step.
     std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
-    auto eval_jac = [&](const double* x, double* tab, int js) -> int {   // K0 + K1, sum r^2 -> scalar 0
-        CHK(launch_cam_table(h, x, tab));
+    auto eval_jac = [&](const double* x, double* tab, int js, bool table_ready) -> int {   // K0 + K1, sum r^2 -> scalar 0
+        if (!table_ready) CHK(launch_cam_table(h, x, tab));
         int np = 0;
         if (opt.profile) {
             hipEvent_t a, b;
@@ -1001,7 +1033,7 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
     };
 
     // f0, J0 (least_squares.py:838, 903-912)
-    CHK(eval_jac(h->x, h->tab, h->jcur));
+    CHK(eval_jac(h->x, h->tab, h->jcur, false));
     CHK(exchange(h, sc, 1, 0));                      // sum r^2
     CHK(linearise(1));
     CHK(fetch_scalars(h));
@@ -1016,23 +1048,28 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
     double step_norm = 0.0, actual_reduction = 0.0, g_norm = 0.0, reg_term = 0.0;
     bool have_red = false;
     int pcg_guess = 0;                                          // iterations the previous solve needed
+    bool nb_valid = true;                                       // V, g_p, [U|g_c] belong to h->x
     if (opt.verbose >= 2) print_header();
 
     for (;;) {                                                  // trf.py:450
+        if (!nb_valid) {                                        // a rejected trial overwrote the blocks and no
+            CHK(launch_normal_blocks(h));                       // step was accepted afterwards (nfev limit)
+            CHK(exchange(h, h->Ugc(), 27 * C, 0));
+            nb_valid = true;
+        }
         // ---- enqueue the whole linear phase ---------------------------------------------------
         int np = 0;
         CHK(launch_jdot(h, &np));                               // t1 = J D^2 g, G11 = |t1|^2
         CHK(launch_finish(h, h->part.as<double>(), np, 1, 1));
         CHK(exchange(h, sc + 1, 1, 0));
-        hipLaunchKernelGGL(k_reg, dim3(1), dim3(64), 0, h->stream, sc, Delta, opt.reg_min);   // trf.py:471-475
-        hipLaunchKernelGGL(k_point_prep, dim3((P + 255) / 256), dim3(256), 0, h->stream, h->V.as<double>(),
-                           h->gp.as<double>(), h->si.as<double>() + 6 * C, (const double*)nullptr, (int)P,
-                           0.0, sc + kRegSlot, h->Vinv.as<double>(), h->e.as<double>());
-        hipLaunchKernelGGL(k_cam_prep, dim3((C + 63) / 64), dim3(64), 0, h->stream, h->Ugc(), h->si.as<double>(),
-                           (const double*)nullptr, (int)C, 0.0, sc + kRegSlot, h->Dc.as<double>(),
-                           h->Minv.as<double>());
-        HIPCHK(h, hipGetLastError());
-        HIPCHK(h, hipMemsetAsync(h->acc(), 0, sizeof(double) * 6 * C, h->stream));
+        {   // regularisation (trf.py:471-475), Vinv/e per point, Dc/Minv per camera, acc0 = 0: one launch
+            const int bc = (int)((C + 63) / 64), bp = (int)((P + 63) / 64);
+            hipLaunchKernelGGL(k_prep, dim3(bc + bp), dim3(64), 0, h->stream, sc, Delta, opt.reg_min, h->Ugc(),
+                               h->V.as<double>(), h->gp.as<double>(), h->si.as<double>(), (int)C, (int)P, bc,
+                               h->Dc.as<double>(), h->Minv.as<double>(), h->acc(), h->Vinv.as<double>(),
+                               h->e.as<double>());
+            HIPCHK(h, hipGetLastError());
+        }
         CHK(launch_schur_sweep<1>(h, nullptr, h->e.as<double>(), nullptr, 0));   // reduced rhs -> acc0
         CHK(exchange(h, h->acc(), 6 * C, 0));
         CHK(pcg_start(h, opt));                                 // replaces lsmr, trf.py:477-480
@@ -1107,15 +1144,29 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
             const double c2 = two_d ? pS[1] / r22 : 0.0;
             const double c1 = (pS[0] - (two_d ? pS[1] * r12 / r22 : 0.0)) / s11;
             const double step_h_norm = std::sqrt(pS[0] * pS[0] + pS[1] * pS[1]);
-            hipLaunchKernelGGL(k_step, dim3(grid_1d(n, 256, 2048)), dim3(256), 0, h->stream, h->x,
-                               h->sg.as<double>(), h->p.as<double>(), c1, c2, n, h->x_new);
-            HIPCHK(h, hipGetLastError());
+            {
+                const int bc = (int)((C + 255) / 256);
+                hipLaunchKernelGGL(k_step_table, dim3(bc + grid_1d(3 * P, 256, 2048)), dim3(256), 0, h->stream, h->x,
+                                   h->sg.as<double>(), h->p.as<double>(), c1, c2, (int)C, n, bc, h->x_new, h->tab_new);
+                HIPCHK(h, hipGetLastError());
+            }
             // the trial point is evaluated WITH its Jacobian into the spare buffer set: when the step is
             // accepted (the common case) nothing has to be recomputed
-            CHK(eval_jac(h->x_new, h->tab_new, jalt));
+            CHK(eval_jac(h->x_new, h->tab_new, jalt, true));
             CHK(exchange(h, sc, 1, 0));
             HIPCHK(h, hipMemcpyAsync(h->h_scal, sc, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-            CHK(wait_stream(h));                                // hand-off 2
+            HIPCHK(h, hipEventRecord(h->ev_handoff, h->stream));
+            // While the host waits for the trial cost, the GPU already builds the normal-equation
+            // blocks of the trial point (speculating on acceptance, the common case).  They overwrite
+            // V / g_p / [U|g_c], which a rejected step does not need: a retry only re-solves the 2-D
+            // model (host scalars) and re-applies k_step_table to x, D^2 g and p, all untouched.
+            h->jcur = jalt;
+            const int rc_nb = launch_normal_blocks(h);
+            const int rc_ex = rc_nb == 0 ? exchange(h, h->Ugc(), 27 * C, 0) : rc_nb;
+            h->jcur = jalt ^ 1;
+            CHK(rc_ex);
+            nb_valid = false;
+            CHK(wait_event(h, h->ev_handoff));                  // hand-off 2
             ++nfev;
             cost_new = 0.5 * h->h_scal[0];
             if (!std::isfinite(cost_new)) {                     // trf.py:504-506
@@ -1135,10 +1186,12 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
         if (actual_reduction > 0.0) {                           // trf.py:528
             std::swap(h->x, h->x_new);
             std::swap(h->tab, h->tab_new);
-            h->jcur = jalt;                                     // J, f of the accepted point are already there
+            h->jcur = jalt;                                     // J, f and the normal blocks of the accepted
+            nb_valid = true;                                    // point are already there / in flight
             cost = cost_new;
             ++njev;
-            CHK(linearise(0));                                  // enqueued only; read with the next hand-off
+            CHK(launch_update_scale(h, 0));                     // enqueued only; read with the next hand-off
+            CHK(exchange_scalars(h, 4));
         } else {
             step_norm = 0.0;
             actual_reduction = 0.0;
@@ -1153,8 +1206,10 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
     }
     if (status == -1) status = 0;
 
-    HIPCHK(h, hipMemcpyAsync(x_inout, h->x, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    CHK(ensure_h_x(h));
+    HIPCHK(h, hipMemcpyAsync(h->h_x, h->x, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+    CHK(wait_stream(h));
+    memcpy(x_inout, h->h_x, sizeof(double) * n);
     const double t_end = now_s();
     if (!evs.empty()) {
         double tot = 0.0;
