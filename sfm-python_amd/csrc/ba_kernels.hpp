@@ -7,9 +7,10 @@
 //
 // HBM layout (fp64):
 //   cam_idx, pt_idx   int32  [ld]          uv, r   double2 [ld]   (ld = N rounded up to 256)
-//   Jc                double2 [6][ld]      pair-plane m holds entries (2m, 2m+1) of the row-major 2x6 block
-//                                          (entry 6*row + col; row: x/y residual; col: w0 w1 w2 T0 T1 T2)
-//   Jp                double2 [3][ld]      pair-plane m holds entries (2m, 2m+1) of the row-major 2x3 block
+//   J                 double2 [ld/64][9][64]  9 KiB tiles of 64 observations; pair-plane m < 6 holds entries
+//                                          (2m, 2m+1) of the row-major 2x6 camera block (entry 6*row + col;
+//                                          row: x/y residual; col: w0 w1 w2 T0 T1 T2), planes 6..8 the
+//                                          row-major 2x3 point block
 //                     -> every stream moves 16 B per lane (global_load/store_dwordx4, 1 KiB per wave
 //                        instruction) with ONE observation per lane
 //   camtab            double [C][17]       R(9) T(3) w(3) b c   -- staged in LDS by the sweeps
@@ -29,6 +30,19 @@ constexpr int kSweepThreads = 1024;  // one workgroup per CU, 16 waves sharing o
 constexpr int kWavesPerSweepBlock = kSweepThreads / 64;
 
 struct KMat { double k[9]; };
+
+// Address (in doubles) of pair-plane m (0..5: the 2x6 camera block, 6..8: the 2x3 point block) of
+// observation i.  Tiled layout: the nine 16-byte pairs of 64 consecutive observations form one
+// contiguous 9 KiB tile [i/64][m][i%64], so a wave reads or writes ONE region per batch instead of
+// nine streams that lie megabytes apart (fewer open DRAM rows; same bytes).
+__device__ __forceinline__ size_t jaddr(int64_t ld, int i, int m) {
+#if defined(SFMBA_J_PLANAR)
+    return 2 * ((size_t)m * ld + i);
+#else
+    (void)ld;
+    return 2 * (((size_t)(i >> 6) * 9 + m) * 64 + (i & 63));
+#endif
+}
 
 // device-resident control block of the PCG (lets the host enqueue iterations without reading back)
 // The PCG keeps two sets of its five camera-sized vectors and two accumulators and alternates between
@@ -243,12 +257,19 @@ template <bool LDS_TAB, bool JAC, bool STORE_R>
 __global__ __launch_bounds__(kSweepThreads) void k_resjac(
     const double* __restrict__ camtab, const double* __restrict__ pts, const int* __restrict__ cam_idx,
     const int* __restrict__ pt_idx, const double* __restrict__ uv, double* __restrict__ r,
-    double* __restrict__ Jc, double* __restrict__ Jp, int N, int64_t ld, int C, KMat K,
+    double* __restrict__ J, int N, int64_t ld, int C, KMat K,
     double* __restrict__ cost_part) {
     extern __shared__ __align__(16) double smem[];
     __shared__ double red[kWavesPerSweepBlock];
+#if defined(SFMBA_K1_CHUNKED)            // experiment: one contiguous chunk of observations per workgroup
+    const int stride = blockDim.x;
+    const int chunk = (((N + (int)gridDim.x - 1) / (int)gridDim.x) + 63) & ~63;
+    int i = blockIdx.x * chunk + threadIdx.x;
+    N = min(N, (int)(blockIdx.x + 1) * chunk);
+#else
     const int stride = gridDim.x * blockDim.x;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+#endif
     // pipeline registers: batch i (uv, X ready), batch i+stride (indices ready)
     int c0 = 0, p0 = 0, c1 = 0, p1 = 0;
     double2 uv0 = make_double2(0.0, 0.0);
@@ -293,15 +314,15 @@ __global__ __launch_bounds__(kSweepThreads) void k_resjac(
             double sacc = 0.0;
             for (int k = 0; k < 12; ++k) sacc += jc[k];
             for (int k = 0; k < 6; ++k) sacc += jp[k];
-            if (sacc == 123.456) Jc[i] = sacc;
+            if (sacc == 123.456) J[i] = sacc;
         }
 #else
         if (STORE_R) st16(r + 2 * (size_t)i, rx, ry);
         if (JAC) {
 #pragma unroll
-            for (int m = 0; m < 6; ++m) st16(Jc + 2 * ((size_t)m * ld + i), jc[2 * m], jc[2 * m + 1]);
+            for (int m = 0; m < 6; ++m) st16(J + jaddr(ld, i, m), jc[2 * m], jc[2 * m + 1]);
 #pragma unroll
-            for (int m = 0; m < 3; ++m) st16(Jp + 2 * ((size_t)m * ld + i), jp[2 * m], jp[2 * m + 1]);
+            for (int m = 0; m < 3; ++m) st16(J + jaddr(ld, i, 6 + m), jp[2 * m], jp[2 * m + 1]);
         }
 #endif
         i = in;
@@ -319,16 +340,16 @@ __global__ __launch_bounds__(kSweepThreads) void k_resjac(
 }
 
 // Unpack the Jacobian pair-planes into the row-major (N,2,6)/(N,2,3) blocks of the C-ABI (test entry).
-__global__ void k_unpack_jac(const double* __restrict__ Jc, const double* __restrict__ Jp, int N,
+__global__ void k_unpack_jac(const double* __restrict__ J, int N,
                              int64_t ld, double* __restrict__ jc_out, double* __restrict__ jp_out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     for (int m = 0; m < 6; ++m) {
-        const double2 v = *reinterpret_cast<const double2*>(Jc + 2 * ((size_t)m * ld + i));
+        const double2 v = *reinterpret_cast<const double2*>(J + jaddr(ld, i, m));
         jc_out[(size_t)i * 12 + 2 * m] = v.x; jc_out[(size_t)i * 12 + 2 * m + 1] = v.y;
     }
     for (int m = 0; m < 3; ++m) {
-        const double2 v = *reinterpret_cast<const double2*>(Jp + 2 * ((size_t)m * ld + i));
+        const double2 v = *reinterpret_cast<const double2*>(J + jaddr(ld, i, 6 + m));
         jp_out[(size_t)i * 6 + 2 * m] = v.x; jp_out[(size_t)i * 6 + 2 * m + 1] = v.y;
     }
 }
@@ -344,15 +365,14 @@ struct ObsArrays {
     const int* __restrict__ cam_idx;
     const int* __restrict__ pt_idx;
     const int* __restrict__ pt_ptr;   // [P+1] run offsets
-    const double* __restrict__ Jc;
-    const double* __restrict__ Jp;
+    const double* __restrict__ J;     // nine pair-planes per observation (jaddr)
     int64_t ld;
 };
 
 __device__ __forceinline__ void load_jc(const ObsArrays& o, int i, double* jc) {
 #pragma unroll
     for (int m = 0; m < 6; ++m) {
-        const double2 v = *reinterpret_cast<const double2*>(o.Jc + 2 * ((size_t)m * o.ld + i));
+        const double2 v = *reinterpret_cast<const double2*>(o.J + jaddr(o.ld, i, m));
         jc[2 * m] = v.x; jc[2 * m + 1] = v.y;
     }
 }
@@ -360,7 +380,7 @@ __device__ __forceinline__ void load_blocks(const ObsArrays& o, int i, double* j
     load_jc(o, i, jc);
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
-        const double2 v = *reinterpret_cast<const double2*>(o.Jp + 2 * ((size_t)m * o.ld + i));
+        const double2 v = *reinterpret_cast<const double2*>(o.J + jaddr(o.ld, i, 6 + m));
         jp[2 * m] = v.x; jp[2 * m + 1] = v.y;
     }
 }

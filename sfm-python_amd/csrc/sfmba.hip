@@ -112,7 +112,7 @@ struct sfmba_handle {
 
     DevBuf cam_idx, pt_idx, pt_ptr, uv, ranges, wsteps, steps, run_off;
     int n_steps = 0;
-    DevBuf xa, xb, tabA, tabB, r[2], Jc[2], Jp[2], t1;   // J and r double-buffered: a trial step is
+    DevBuf xa, xb, tabA, tabB, r[2], J[2], t1;   // J and r double-buffered: a trial step is
                                                        // evaluated into the spare set and swapped in on accept
     int jcur = 0;
     DevBuf V, Vinv, gp, e;
@@ -210,7 +210,7 @@ int set_lds(sfmba_handle* h, Kern k, size_t bytes) {
 
 ObsArrays obs_arrays(const sfmba_handle* h) {
     return ObsArrays{h->cam_idx.as<int>(), h->pt_idx.as<int>(), h->pt_ptr.as<int>(),
-                     h->Jc[h->jcur].as<double>(), h->Jp[h->jcur].as<double>(), h->ld};
+                     h->J[h->jcur].as<double>(), h->ld};
 }
 
 StepTable step_table(const sfmba_handle* h) {
@@ -273,12 +273,12 @@ int launch_resjac_v(sfmba_handle* h, const double* x, const double* tab, int js,
     if (ev0) {
         hipExtLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), (uint32_t)lds, h->stream, ev0, ev1, 0u, tab, pts,
                               (const int*)h->cam_idx.as<int>(), (const int*)h->pt_idx.as<int>(),
-                              (const double*)h->uv.as<double>(), h->r[js].as<double>(), h->Jc[js].as<double>(),
-                              h->Jp[js].as<double>(), (int)h->N, h->ld, (int)h->C, h->K, h->part.as<double>());
+                              (const double*)h->uv.as<double>(), h->r[js].as<double>(), h->J[js].as<double>(),
+                              (int)h->N, h->ld, (int)h->C, h->K, h->part.as<double>());
     } else {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), lds, h->stream, tab, pts,
                            h->cam_idx.as<int>(), h->pt_idx.as<int>(), h->uv.as<double>(),
-                           h->r[js].as<double>(), h->Jc[js].as<double>(), h->Jp[js].as<double>(), (int)h->N,
+                           h->r[js].as<double>(), h->J[js].as<double>(), (int)h->N,
                            h->ld, (int)h->C, h->K, h->part.as<double>());
     }
     HIPCHK(h, hipGetLastError());
@@ -770,8 +770,7 @@ int sfmba_set_problem(sfmba_handle* h, int64_t C, int64_t P, int64_t N, const in
     HIPCHK(h, h->tabB.ensure(sizeof(double) * kCamTab * C));
     for (int js = 0; js < 2; ++js) {
         HIPCHK(h, h->r[js].ensure(sizeof(double) * 2 * ld));
-        HIPCHK(h, h->Jc[js].ensure(sizeof(double) * 12 * ld));
-        HIPCHK(h, h->Jp[js].ensure(sizeof(double) * 6 * ld));
+        HIPCHK(h, h->J[js].ensure(sizeof(double) * 18 * ld));
     }
     h->jcur = 0;
     HIPCHK(h, h->t1.ensure(sizeof(double) * 2 * ld));
@@ -854,8 +853,8 @@ int sfmba_residual_jacobian(sfmba_handle* h, const double* x, double* r_out, dou
     DevBuf jc_rm, jp_rm;
     HIPCHK(h, jc_rm.ensure(sizeof(double) * 12 * h->N));
     HIPCHK(h, jp_rm.ensure(sizeof(double) * 6 * h->N));
-    hipLaunchKernelGGL(k_unpack_jac, dim3((h->N + 255) / 256), dim3(256), 0, h->stream, h->Jc[h->jcur].as<double>(),
-                       h->Jp[h->jcur].as<double>(), (int)h->N, h->ld, jc_rm.as<double>(), jp_rm.as<double>());
+    hipLaunchKernelGGL(k_unpack_jac, dim3((h->N + 255) / 256), dim3(256), 0, h->stream, h->J[h->jcur].as<double>(),
+                       (int)h->N, h->ld, jc_rm.as<double>(), jp_rm.as<double>());
     HIPCHK(h, hipGetLastError());
     std::vector<double> tr(2 * h->N), tc(12 * h->N), tp(6 * h->N);
     HIPCHK(h, hipMemcpyAsync(tr.data(), h->r[h->jcur].p, sizeof(double) * 2 * h->N, hipMemcpyDeviceToHost, h->stream));
@@ -954,18 +953,16 @@ int sfmba_time_kernel(sfmba_handle* h, const double* x, int32_t which, int32_t r
             case 2: CHK(launch_normal_blocks(h)); break;
             case 3: CHK(launch_schur_sweep<0>(h, h->vtmp.as<double>(), nullptr, nullptr, 0)); break;
             case 10:   // streaming-store ceiling: fill the 12 Jc planes, 16 B per lane, one stream
-                hipLaunchKernelGGL(k_fill16, dim3(h->n_cu * 2), dim3(1024), 0, h->stream, h->Jc[h->jcur].as<double>(),
+                hipLaunchKernelGGL(k_fill16, dim3(h->n_cu * 2), dim3(1024), 0, h->stream, h->J[h->jcur].as<double>(),
                                    (int64_t)(6 * h->ld), 1.0);
                 break;
             case 11:   // same bytes, 2048 workgroups
-                hipLaunchKernelGGL(k_fill16, dim3(2048), dim3(1024), 0, h->stream, h->Jc[h->jcur].as<double>(),
+                hipLaunchKernelGGL(k_fill16, dim3(2048), dim3(1024), 0, h->stream, h->J[h->jcur].as<double>(),
                                    (int64_t)(6 * h->ld), 1.0);
                 break;
             case 13:   // cold streaming-store ceiling: 144 MB per rep, alternating buffer sets (288 MB cycle > 256 MiB Infinity Cache)
-                hipLaunchKernelGGL(k_fill16, dim3(2048), dim3(1024), 0, h->stream, h->Jc[k & 1].as<double>(),
-                                   (int64_t)(6 * h->ld), 1.0);
-                hipLaunchKernelGGL(k_fill16, dim3(2048), dim3(1024), 0, h->stream, h->Jp[k & 1].as<double>(),
-                                   (int64_t)(3 * h->ld), 1.0);
+                hipLaunchKernelGGL(k_fill16, dim3(2048), dim3(1024), 0, h->stream, h->J[k & 1].as<double>(),
+                                   (int64_t)(9 * h->ld), 1.0);
                 break;
             case 12:   // alternate between the two Jacobian buffer sets (defeats Infinity-Cache write hits)
                 CHK((launch_resjac<true, true>(h, h->x, h->tab, k & 1, &np)));
