@@ -706,8 +706,8 @@ __global__ __launch_bounds__(256) void k_vec_reduce(const double* __restrict__ g
 
 // Final sums of partial rows.  One wave per quantity; quantity k < first_sum is a max, else a sum;
 // block y handles the partial rows [row0[y], row0[y] + nrows[y]) and writes quantity k to
-// out[(k < first_sum ? max_off[y] : sum_off[y]) + k].  Fixed lane->row mapping: deterministic.
-struct FinishJob { int row0[2], nrows[2], max_off[2], sum_off[2]; };
+// out[slot[y][k]] (slot < 0: not written).  Fixed lane->row mapping: deterministic.
+struct FinishJob { int row0[2], nrows[2], slot[2][kNQ]; };
 __global__ void k_finish(const double* __restrict__ part, FinishJob job, int nq, int first_sum,
                          double* __restrict__ out) {
     const int y = blockIdx.x;
@@ -719,12 +719,12 @@ __global__ void k_finish(const double* __restrict__ part, FinishJob job, int nq,
     if (k < first_sum) {
         for (int b = lane; b < nparts; b += 64) s = fmax(s, rows[(size_t)b * nq + k]);
         s = wave_max(s);
-        if (lane == 0) out[job.max_off[y] + k] = s;
     } else {
         for (int b = lane; b < nparts; b += 64) s += rows[(size_t)b * nq + k];
         s = wave_sum(s);
-        if (lane == 0) out[job.sum_off[y] + k] = s;
     }
+    const int dst = job.slot[y][k];
+    if (lane == 0 && dst >= 0) out[dst] = s;
 }
 
 // t1_i = J (D^2 g) per observation and sum |t1|^2 (the quadratic of the 1-D Cauchy problem,
@@ -787,7 +787,7 @@ __device__ __forceinline__ void chol3_inverse(const double* a /*upper 6*/, doubl
 // Regularisation of the damped Gauss-Newton step from the 1-D Cauchy problem along -g_h
 // (SCIPY trf.py:471-475, common.py:251-322), evaluated from the exchange scalars by whoever needs it.
 __device__ __forceinline__ double reg_from_scalars(const double* __restrict__ sc, double Delta, double reg_min) {
-    const double a11 = sc[4] + sc[16 + 1];          // |g_h|^2: point slice (summed over ranks) + cameras
+    const double a11 = sc[8] + sc[16 + 1];          // |g_h|^2: point slice (summed over ranks) + cameras
     const double a = 0.5 * sc[1], b = -a11;         // sc[1] = G11 = |J_h g_h|^2
     double reg = reg_min;
     if (a11 > 0.0) {

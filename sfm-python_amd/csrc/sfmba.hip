@@ -34,12 +34,14 @@ namespace {
 constexpr size_t kLdsBytes = 160 * 1024;       // gfx950: 160 KiB LDS per workgroup
 constexpr size_t kLdsDynMax = kLdsBytes - 512; // dynamic part; every kernel here has <= 512 B static LDS
 // Scalars at the end of the exchange arena (32 doubles):
-//   summed over ranks [0..11]: 0 sum r^2 | 1 G11 | 2 G12 | 3 G22 | 4..11 q1..q8 of the point slice
+//   summed over ranks [0..11]: 0 sum r^2 | 1 G11 | 2 G12 | 3 G22 | 4..7 q5..q8 | 8..11 q1..q4 of the point
+//                              slice (grouped so that each phase all-reduces one contiguous run of fresh values)
 //   max over ranks    [12]   : q0 = max|g| of the point slice
 //   device-local      [13]   : regularisation term of this iteration (k_prep)
 //   never exchanged   [16..24]: q0..q8 of the camera slice (replicated on every rank)
 constexpr int kScalSlots = 32;
-constexpr int kSumSlots = 12, kMaxSlot = 12, kRegSlot = 13, kCamSlot = 16;
+constexpr int kMaxSlot = 12, kRegSlot = 13, kCamSlot = 16;
+constexpr int kPointSlot[9] = {12, 8, 9, 10, 11, 4, 5, 6, 7};     // slot of q0..q8 of the point slice
 
 struct DevBuf {
     void* p = nullptr;
@@ -298,17 +300,23 @@ int launch_resjac(sfmba_handle* h, const double* x, const double* tab, int js, i
 // sum of `nparts` partial rows of width nq into the exchange scalars starting at slot `slot`
 int launch_finish(sfmba_handle* h, const double* part, int nparts, int nq, int slot) {
     FinishJob job{};
-    job.row0[0] = 0; job.nrows[0] = nparts; job.max_off[0] = slot; job.sum_off[0] = slot;
+    job.row0[0] = 0; job.nrows[0] = nparts;
+    for (int k = 0; k < kNQ; ++k) job.slot[0][k] = slot + k;
     hipLaunchKernelGGL(k_finish, dim3(1), dim3(64 * nq), 0, h->stream, part, job, nq, 0, h->scal());
     HIPCHK(h, hipGetLastError());
     return 0;
 }
 
-// the two-slice (cameras | points) reductions of k_update_scale / k_vec_reduce
-int launch_finish_slices(sfmba_handle* h) {
+// the two-slice (cameras | points) reductions of k_update_scale / k_vec_reduce; the point slice
+// publishes only quantities [q_lo, q_hi] (the others keep their already rank-reduced values)
+int launch_finish_slices(sfmba_handle* h, int q_lo, int q_hi) {
     FinishJob job{};
-    job.row0[0] = 0;         job.nrows[0] = h->red_bc;               job.max_off[0] = kCamSlot; job.sum_off[0] = kCamSlot;
-    job.row0[1] = h->red_bc; job.nrows[1] = h->red_grid - h->red_bc; job.max_off[1] = kMaxSlot; job.sum_off[1] = 3;
+    job.row0[0] = 0;         job.nrows[0] = h->red_bc;
+    job.row0[1] = h->red_bc; job.nrows[1] = h->red_grid - h->red_bc;
+    for (int k = 0; k < kNQ; ++k) {
+        job.slot[0][k] = kCamSlot + k;
+        job.slot[1][k] = (k >= q_lo && k <= q_hi) ? kPointSlot[k] : -1;
+    }
     hipLaunchKernelGGL(k_finish, dim3(2), dim3(64 * kNQ), 0, h->stream, h->part.as<double>(), job, kNQ, 1, h->scal());
     HIPCHK(h, hipGetLastError());
     return 0;
@@ -414,7 +422,7 @@ int launch_update_scale(sfmba_handle* h, int first) {
                        h->gp.as<double>(), h->x, (int)h->C, (int)h->P, first, h->red_bc, h->si.as<double>(),
                        h->g.as<double>(), h->sg.as<double>(), h->part.as<double>());
     HIPCHK(h, hipGetLastError());
-    return launch_finish_slices(h);
+    return launch_finish_slices(h, 0, 4);
 }
 
 // q0..q8 with the step vector p
@@ -423,15 +431,18 @@ int launch_vec_reduce(sfmba_handle* h) {
                        h->si.as<double>(), h->x, h->sg.as<double>(), h->p.as<double>(), (int)h->C, (int)h->P,
                        h->red_bc, h->part.as<double>());
     HIPCHK(h, hipGetLastError());
-    return launch_finish_slices(h);
+    return launch_finish_slices(h, 5, 8);
 }
 
-// all-reduce freshly written exchange scalars [first_sum_slot, 12) and the max slot over ranks (no-op
-// on one GPU); stays on the stream.  Only slots written since their last reduction may be included.
-int exchange_scalars(sfmba_handle* h, int first_sum_slot) {
-    CHK(exchange(h, h->scal() + first_sum_slot, kSumSlots - first_sum_slot, 0));
+// all-reduce freshly written exchange scalars over ranks (no-op on one GPU); stays on the stream.
+// Only slots written since their last reduction may be included.
+int exchange_linearise(sfmba_handle* h) {       // q1..q4 and max|g| of the point slice
+    CHK(exchange(h, h->scal() + 8, 4, 0));
     CHK(exchange(h, h->scal() + kMaxSlot, 1, 1));
     return 0;
+}
+int exchange_tail(sfmba_handle* h) {            // G12, G22, q5..q8
+    return exchange(h, h->scal() + 2, 6, 0);
 }
 
 // bring all 32 scalars to the host (h_scal) and wait
@@ -441,7 +452,7 @@ int fetch_scalars(sfmba_handle* h) {
 }
 
 // q_k summed over the camera slice and the (rank-reduced) point slice
-double qsum(const sfmba_handle* h, int q) { return h->h_scal[3 + q] + h->h_scal[kCamSlot + q]; }
+double qsum(const sfmba_handle* h, int q) { return h->h_scal[kPointSlot[q]] + h->h_scal[kCamSlot + q]; }
 
 // x crosses PCIe through a pinned staging buffer (an async copy from pageable memory is staged by the
 // runtime anyway, synchronously and in small pieces)
@@ -1025,7 +1036,7 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
         CHK(launch_normal_blocks(h));
         CHK(exchange(h, h->Ugc(), 27 * C, 0));
         CHK(launch_update_scale(h, first));
-        CHK(exchange_scalars(h, 4));                 // q1..q8 and max|g| of the point slice
+        CHK(exchange_linearise(h));
         return 0;
     };
 
@@ -1080,7 +1091,7 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
             CHK(launch_backsub(h, &np));
             CHK(launch_finish(h, h->part.as<double>(), np, 2, 2));
             CHK(launch_vec_reduce(h));
-            CHK(exchange_scalars(h, 2));             // G12, G22, q1..q8, max|g|
+            CHK(exchange_tail(h));
             return 0;
         };
         CHK(tail());
@@ -1188,7 +1199,7 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
             cost = cost_new;
             ++njev;
             CHK(launch_update_scale(h, 0));                     // enqueued only; read with the next hand-off
-            CHK(exchange_scalars(h, 4));
+            CHK(exchange_linearise(h));
         } else {
             step_norm = 0.0;
             actual_reduction = 0.0;
