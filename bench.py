@@ -199,7 +199,7 @@ def main():
                          "algorithmic_bytes_per_launch": k1_bytes(C, P, N),
                          "launches_timed": sum(r[4] for r in results)},
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:     # the CPU baseline is timed on rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline((C, P, N))
             line["speedup_vs_cpu_baseline"] = (steps / elapsed) / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)

@@ -157,7 +157,7 @@ def test_long_tracks_and_ragged_runs(be, orc):
 
 def test_many_cameras_global_table_variants(be, orc):
     """More cameras than fit the LDS tables: 1300 (camera table in L2, 2 normal-block column passes),
-    1800 (Schur accumulators global, 3 passes), 2600 (normal blocks by global atomics)."""
+    1800 (Schur accumulators global, 3 passes), 2600 (4 passes)."""
     from sfmba import make_problem
     for C in (1300, 1800, 2600):
         pb = make_problem(C, 500, 6000, seed=C)
@@ -268,6 +268,30 @@ def test_properties_at_full_size(be):
     assert 0.3 < res.rmse < 0.7            # sqrt(0.5^2 + truncation variance) ~ 0.58 px minus fitted dof
     r_fin = be.residuals(res.x)
     assert abs(0.5 * np.sum(r_fin ** 2) - res.cost) <= 1e-9 * res.cost
+
+
+def test_reproj_error_rt_convention_and_problem_files(tmp_path):
+    """cv2_lite.reproj_error / calc_reproj_error mirror (the pipeline's [R|t] convention) and the .npz
+    problem file round trip."""
+    import sfmba
+    rng = np.random.default_rng(3)
+    g = np.load(os.path.join(GOLDEN, "pack_cases.npz"))
+    R, t = g["R"][5], np.array([0.3, -0.2, 9.0])
+    X = rng.normal(size=(50, 3))
+    uv = rng.normal(size=(50, 2)) * 100
+    K = sfmba.K_SCEAUX
+    ref = (K @ (R @ X.T + t.reshape(3, 1))).T
+    ref = ref[:, :2] / ref[:, 2:3] - uv                       # solve_pnp.py:10-14
+    err = sfmba.reproj_error(X, uv, K, R, t)
+    assert np.abs(err - ref).max() < 1e-9
+    assert abs(sfmba.calc_reproj_error(X, uv, K, R, t) - np.linalg.norm(ref, axis=1).mean()) < 1e-9
+    pb = sfmba.make_problem(4, 30, 120, seed=11)
+    f = tmp_path / "pb.npz"
+    sfmba.save_problem(f, pb.x0, *pb.args)
+    x0, args = sfmba.load_problem(f)
+    a = sfmba.least_squares(sfmba.compute_residuals, x0, x_scale="jac", ftol=1e-10, method="trf", args=args)
+    b = sfmba.least_squares(sfmba.compute_residuals, pb.x0, x_scale="jac", ftol=1e-10, method="trf", args=pb.args)
+    assert abs(a.cost - b.cost) <= 1e-10 * b.cost
 
 
 # ---- the N>1 code path on one GPU: world_size-1 RCCL through the same Exchange / callback plumbing -------
