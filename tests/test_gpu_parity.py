@@ -157,9 +157,9 @@ def test_long_tracks_and_ragged_runs(be, orc):
 
 def test_many_cameras_global_table_variants(be, orc):
     """More cameras than fit the LDS tables: 1300 (camera table in L2, 2 normal-block column passes),
-    1800 (Schur accumulators global, 3 passes), 2600 (4 passes)."""
+    1800 (Schur accumulators global, 3 passes), 2600 (4 passes), 21000 (normal blocks by global atomics)."""
     from sfmba import make_problem
-    for C in (1300, 1800, 2600):
+    for C in (1300, 1800, 2600, 21000):
         pb = make_problem(C, 500, 6000, seed=C)
         be.set_problem(*pb.args)
         r, Jc, Jp = be.residual_jacobian(pb.x0)
@@ -214,6 +214,47 @@ def test_solve_cfg2_matches_recorded_scipy_run(orc):
     assert abs(res.rmse - rec["rmse"]) < 1e-6
     assert res.cost <= rec["cost"] * (1 + 1e-9)
     assert res.nfev <= rec["nfev"]
+
+
+def test_rejected_steps_and_nfev_limit_follow_the_oracle(orc):
+    """Far starts (x0 noise 0.2) make the trust region reject steps: the retry path (2-D model re-solved
+    with a smaller radius, speculative normal blocks discarded) and the max_nfev exit must follow the
+    oracle's restatement of trf_no_bounds."""
+    import sfmba
+    saw_rejection = False
+    for seed in (1, 2, 5):
+        pb = sfmba.make_problem(6, 80, 500, seed=seed, x0_noise=0.2)
+        o = orc.trf_schur(pb.x0, *pb.args, ftol=1e-10, linear="pcg", pcg_tol=1e-3)
+        res = sfmba.least_squares(sfmba.compute_residuals, pb.x0, x_scale="jac", ftol=1e-10, method="trf",
+                                  args=pb.args)
+        assert res.status == o.status
+        assert abs(res.cost - o.cost) <= 1e-8 * o.cost
+        assert (res.nfev, res.njev) == (o.nfev, o.njev)
+        saw_rejection |= res.nfev > res.njev
+    assert saw_rejection
+    pb = sfmba.make_problem(6, 80, 500, seed=5, x0_noise=0.2)
+    for max_nfev in range(2, 14):
+        o = orc.trf_schur(pb.x0, *pb.args, ftol=1e-10, linear="pcg", pcg_tol=1e-3, max_nfev=max_nfev)
+        res = sfmba.least_squares(sfmba.compute_residuals, pb.x0, x_scale="jac", ftol=1e-10, method="trf",
+                                  args=pb.args, max_nfev=max_nfev)
+        assert res.status == o.status == 0 and res.nfev == o.nfev == max_nfev
+        assert abs(res.cost - o.cost) <= 1e-8 * o.cost
+        assert np.abs(res.x - o.x).max() <= 1e-6 * np.abs(o.x).max()
+        r = orc.compute_residuals(res.x, *pb.args)
+        assert np.abs(r - res.fun).max() < 1e-8            # result.fun belongs to result.x
+
+
+def test_cfg3_full_loop_vs_oracle(orc):
+    """BASELINE config 3 (200 cameras / 20k points / 200k observations): the full Schur-LM loop on the
+    GPU against the oracle's."""
+    import sfmba
+    pb = sfmba.make_config("cfg3")
+    o = orc.trf_schur(pb.x0, *pb.args, ftol=1e-10, linear="pcg", pcg_tol=1e-3)
+    res = sfmba.least_squares(sfmba.compute_residuals, pb.x0, x_scale="jac", ftol=1e-10, method="trf",
+                              args=pb.args)
+    assert res.status == o.status and (res.nfev, res.njev) == (o.nfev, o.njev)
+    assert abs(res.cost - o.cost) <= 1e-9 * o.cost
+    assert abs(res.rmse - float(np.sqrt(np.mean(o.fun ** 2)))) < 1e-9
 
 
 def test_error_behaviour(be):
