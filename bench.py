@@ -36,9 +36,14 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI35
 
 
 def k1_bytes(C, P, N):
-    """Algorithmic bytes of one residual+Jacobian launch: per observation
-    read cam_idx 4 + pt_idx 4 + uv 16, write r 16 + Jc 96 + Jp 48 = 184 B; once per point 24 B, per
-    camera 48 B."""
+    """Algorithmic bytes of one residual+Jacobian launch: per observation read
+    cam_idx 4 + pt_idx 4 + uv 16, write r 16 + d r/d w 48 + d r/d X 48 = 136 B; once per point 24 B, per
+    camera 48 B.  SURVEY.md section 8d counts 184 B because it also writes d r/d T, which is -d r/d X and is
+    not stored (see k1_bytes_survey for that accounting)."""
+    return 136 * N + 24 * P + 48 * C
+
+
+def k1_bytes_survey(C, P, N):
     return 184 * N + 24 * P + 48 * C
 
 
@@ -197,6 +202,10 @@ def main():
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                          "traffic": traffic, "avg_launch_us": k1_us,
                          "algorithmic_bytes_per_launch": k1_bytes(C, P, N),
+                         "note": "bytes = 136 N + 24 P + 48 C: the 2x3 block d r/d T = -d r/d X is not stored; "
+                                 "SURVEY 8d's 184 N figure writes it a second time",
+                         "achieved_if_counted_as_survey_184B": (k1_bytes_survey(C, P, N) / (k1_us * 1e-6) / 1e9)
+                                                                if k1_us > 0 else None,
                          "launches_timed": sum(r[4] for r in results)},
         }
         if not a.no_cpu_baseline and world == 1:     # the CPU baseline is timed on rank 0 at N = 1 only

@@ -7,10 +7,9 @@
 //
 // HBM layout (fp64):
 //   cam_idx, pt_idx   int32  [ld]          uv, r   double2 [ld]   (ld = N rounded up to 256)
-//   J                 double2 [ld/64][9][64]  9 KiB tiles of 64 observations; pair-plane m < 6 holds entries
-//                                          (2m, 2m+1) of the row-major 2x6 camera block (entry 6*row + col;
-//                                          row: x/y residual; col: w0 w1 w2 T0 T1 T2), planes 6..8 the
-//                                          row-major 2x3 point block
+//   J                 double2 [ld/64][6][64]  6 KiB tiles of 64 observations: planes 0..2 = d r/d w (2x3
+//                                          row-major, two entries per plane), planes 3..5 = d r/d X;
+//                                          d r/d T = -d r/d X is rebuilt in registers (see jaddr)
 //                     -> every stream moves 16 B per lane (global_load/store_dwordx4, 1 KiB per wave
 //                        instruction) with ONE observation per lane
 //   camtab            double [C][17]       R(9) T(3) w(3) b c   -- staged in LDS by the sweeps
@@ -31,16 +30,21 @@ constexpr int kWavesPerSweepBlock = kSweepThreads / 64;
 
 struct KMat { double k[9]; };
 
-// Address (in doubles) of pair-plane m (0..5: the 2x6 camera block, 6..8: the 2x3 point block) of
-// observation i.  Tiled layout: the nine 16-byte pairs of 64 consecutive observations form one
-// contiguous 9 KiB tile [i/64][m][i%64], so a wave reads or writes ONE region per batch instead of
-// nine streams that lie megabytes apart (fewer open DRAM rows; same bytes).
+// The Jacobian of one observation is stored COMPACT: d r/d T = -d r/d X (the model depends on X - T
+// only), so the 2x6 camera block [d r/d w | d r/d T] is never written; the six doubles of d r/d w and
+// the six of d r/d X are enough (96 B instead of 144 B per observation) and every consumer rebuilds
+// the translation part in registers with three negations per row.
+// Address (in doubles) of pair-plane m of observation i; planes 0..2 = d r/d w row-major
+// (w0 w1 | w2 w0' | w1' w2'), planes 3..5 = d r/d X likewise.  Tiled layout: the six 16-byte pairs of
+// 64 consecutive observations form one contiguous 6 KiB tile [i/64][m][i%64], so a wave reads or
+// writes ONE region per batch instead of six streams that lie megabytes apart.
+constexpr int kJPlanes = 6;
 __device__ __forceinline__ size_t jaddr(int64_t ld, int i, int m) {
 #if defined(SFMBA_J_PLANAR)
     return 2 * ((size_t)m * ld + i);
 #else
     (void)ld;
-    return 2 * (((size_t)(i >> 6) * 9 + m) * 64 + (i & 63));
+    return 2 * (((size_t)(i >> 6) * kJPlanes + m) * 64 + (i & 63));
 #endif
 }
 
@@ -238,9 +242,9 @@ __device__ __forceinline__ void observe(const double* __restrict__ t, double X, 
 // past 160 KiB it stays in L2) and grid-stride over the observations.  All streams are coalesced
 // 16 B/lane except the two int32 index streams; points are gathered (point-major order: neighbouring
 // lanes share a point).  The loop is software pipelined by hand: indices are fetched two batches
-// ahead and uv/point one batch ahead, so the loads of the next batch are in flight while the 9+1
-// dwordx4 stores of the current one issue (the kernel is store-issue/HBM-write bound: 160 of its
-// 184 B per observation are writes).  cost_part[block] = sum r^2 of the block.
+// ahead and uv/point one batch ahead, so the loads of the next batch are in flight while the 6+1
+// dwordx4 stores of the current one issue (the kernel is HBM-write bound: 112 of its 136 B per
+// observation are writes).  cost_part[block] = sum r^2 of the block.
 // ---------------------------------------------------------------------------------------------
 // 16-byte streaming store of two doubles (one global_store_dwordx4)
 __device__ __forceinline__ void st16(double* __restrict__ p, double a, double b) {
@@ -319,10 +323,12 @@ __global__ __launch_bounds__(kSweepThreads) void k_resjac(
 #else
         if (STORE_R) st16(r + 2 * (size_t)i, rx, ry);
         if (JAC) {
+            // compact form: d r/d w (jc[0..2], jc[6..8]) and d r/d X (jp); d r/d T = -jp is not stored
+            st16(J + jaddr(ld, i, 0), jc[0], jc[1]);
+            st16(J + jaddr(ld, i, 1), jc[2], jc[6]);
+            st16(J + jaddr(ld, i, 2), jc[7], jc[8]);
 #pragma unroll
-            for (int m = 0; m < 6; ++m) st16(J + jaddr(ld, i, m), jc[2 * m], jc[2 * m + 1]);
-#pragma unroll
-            for (int m = 0; m < 3; ++m) st16(J + jaddr(ld, i, 6 + m), jp[2 * m], jp[2 * m + 1]);
+            for (int m = 0; m < 3; ++m) st16(J + jaddr(ld, i, 3 + m), jp[2 * m], jp[2 * m + 1]);
         }
 #endif
         i = in;
@@ -344,14 +350,18 @@ __global__ void k_unpack_jac(const double* __restrict__ J, int N,
                              int64_t ld, double* __restrict__ jc_out, double* __restrict__ jp_out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
-    for (int m = 0; m < 6; ++m) {
-        const double2 v = *reinterpret_cast<const double2*>(J + jaddr(ld, i, m));
-        jc_out[(size_t)i * 12 + 2 * m] = v.x; jc_out[(size_t)i * 12 + 2 * m + 1] = v.y;
-    }
+    double w[6], x[6];
     for (int m = 0; m < 3; ++m) {
-        const double2 v = *reinterpret_cast<const double2*>(J + jaddr(ld, i, 6 + m));
-        jp_out[(size_t)i * 6 + 2 * m] = v.x; jp_out[(size_t)i * 6 + 2 * m + 1] = v.y;
+        const double2 a = *reinterpret_cast<const double2*>(J + jaddr(ld, i, m));
+        const double2 b = *reinterpret_cast<const double2*>(J + jaddr(ld, i, 3 + m));
+        w[2 * m] = a.x; w[2 * m + 1] = a.y; x[2 * m] = b.x; x[2 * m + 1] = b.y;
     }
+    for (int row = 0; row < 2; ++row)
+        for (int k = 0; k < 3; ++k) {
+            jc_out[(size_t)i * 12 + 6 * row + k] = w[3 * row + k];
+            jc_out[(size_t)i * 12 + 6 * row + 3 + k] = -x[3 * row + k];
+            jp_out[(size_t)i * 6 + 3 * row + k] = x[3 * row + k];
+        }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -365,24 +375,31 @@ struct ObsArrays {
     const int* __restrict__ cam_idx;
     const int* __restrict__ pt_idx;
     const int* __restrict__ pt_ptr;   // [P+1] run offsets
-    const double* __restrict__ J;     // nine pair-planes per observation (jaddr)
+    const double* __restrict__ J;     // six pair-planes per observation (jaddr)
     int64_t ld;
 };
 
-__device__ __forceinline__ void load_jc(const ObsArrays& o, int i, double* jc) {
-#pragma unroll
-    for (int m = 0; m < 6; ++m) {
-        const double2 v = *reinterpret_cast<const double2*>(o.J + jaddr(o.ld, i, m));
-        jc[2 * m] = v.x; jc[2 * m + 1] = v.y;
-    }
-}
+// jc (2x6 row-major) and jp (2x3 row-major) of observation i from the compact pair-planes
 __device__ __forceinline__ void load_blocks(const ObsArrays& o, int i, double* jc, double* jp) {
-    load_jc(o, i, jc);
+    double w[6];
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
-        const double2 v = *reinterpret_cast<const double2*>(o.J + jaddr(o.ld, i, 6 + m));
-        jp[2 * m] = v.x; jp[2 * m + 1] = v.y;
+        const double2 a = *reinterpret_cast<const double2*>(o.J + jaddr(o.ld, i, m));
+        const double2 b = *reinterpret_cast<const double2*>(o.J + jaddr(o.ld, i, 3 + m));
+        w[2 * m] = a.x; w[2 * m + 1] = a.y;
+        jp[2 * m] = b.x; jp[2 * m + 1] = b.y;
     }
+#pragma unroll
+    for (int row = 0; row < 2; ++row)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            jc[6 * row + k] = w[3 * row + k];
+            jc[6 * row + 3 + k] = -jp[3 * row + k];
+        }
+}
+__device__ __forceinline__ void load_jc(const ObsArrays& o, int i, double* jc) {
+    double jp[6];
+    load_blocks(o, i, jc, jp);
 }
 
 // K2+K3: V_p = sum Jp^T Jp (6), g_p = sum Jp^T r (3) by segmented reduction;

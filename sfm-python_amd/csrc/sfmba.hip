@@ -782,7 +782,7 @@ int sfmba_set_problem(sfmba_handle* h, int64_t C, int64_t P, int64_t N, const in
     HIPCHK(h, h->tabB.ensure(sizeof(double) * kCamTab * C));
     for (int js = 0; js < 2; ++js) {
         HIPCHK(h, h->r[js].ensure(sizeof(double) * 2 * ld));
-        HIPCHK(h, h->J[js].ensure(sizeof(double) * 18 * ld));
+        HIPCHK(h, h->J[js].ensure(sizeof(double) * 12 * ld));
     }
     h->jcur = 0;
     HIPCHK(h, h->t1.ensure(sizeof(double) * 2 * ld));
@@ -974,7 +974,7 @@ int sfmba_time_kernel(sfmba_handle* h, const double* x, int32_t which, int32_t r
                 break;
             case 13:   // cold streaming-store ceiling: 144 MB per rep, alternating buffer sets (288 MB cycle > 256 MiB Infinity Cache)
                 hipLaunchKernelGGL(k_fill16, dim3(2048), dim3(1024), 0, h->stream, h->J[k & 1].as<double>(),
-                                   (int64_t)(9 * h->ld), 1.0);
+                                   (int64_t)(6 * h->ld), 1.0);
                 break;
             case 12:   // alternate between the two Jacobian buffer sets (defeats Infinity-Cache write hits)
                 CHK((launch_resjac<true, true>(h, h->x, h->tab, k & 1, &np)));
