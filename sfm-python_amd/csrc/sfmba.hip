@@ -824,6 +824,10 @@ int sfmba_set_problem(sfmba_handle* h, int64_t C, int64_t P, int64_t N, const in
     }
     HIPCHK(h, hipMemcpyAsync(h->run_off.p, run_off.data(), ld, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemsetAsync(h->arena, 0, sizeof(double) * (size_t)sfmba_exchange_doubles(C), h->stream));
+    // points without observations are never written by the normal-block kernel: their blocks must be 0
+    HIPCHK(h, hipMemsetAsync(h->V.p, 0, sizeof(double) * 6 * P, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->gp.p, 0, sizeof(double) * 3 * P, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->p.p, 0, sizeof(double) * h->n, h->stream));      // ... and their step is 0
     HIPCHK(h, hipMemsetAsync(h->r[0].p, 0, sizeof(double) * 2 * ld, h->stream));
     HIPCHK(h, hipMemsetAsync(h->r[1].p, 0, sizeof(double) * 2 * ld, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));     // host staging vectors go out of scope

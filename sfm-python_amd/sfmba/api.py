@@ -104,7 +104,7 @@ def project_points(points, camera_params, K, device=0):
 def least_squares(fun, x0, jac="2-point", bounds=(-np.inf, np.inf), method="trf", ftol=1e-8, xtol=1e-8,
                   gtol=1e-8, x_scale=1.0, loss="linear", f_scale=1.0, diff_step=None, tr_solver=None,
                   tr_options=None, jac_sparsity=None, max_nfev=None, verbose=0, args=(), kwargs=None,
-                  device=0, max_iter=None, pcg_tol=None, profile=False):
+                  device=0, max_iter=None, pcg_tol=None, profile=False, return_jac=False):
     """Drop-in for the reference's ``least_squares(compute_residuals, x0, jac_sparsity=..., verbose=...,
     x_scale='jac', ftol=tol, method='trf', args=(...))`` (sfm.py:266-268).
 
@@ -113,7 +113,9 @@ def least_squares(fun, x0, jac="2-point", bounds=(-np.inf, np.inf), method="trf"
     ``jac_sparsity`` is accepted and shape-checked; ``jac``, ``diff_step``, ``tr_solver``,
     ``tr_options`` are accepted and ignored (the Jacobian is analytic, the trust-region step comes
     from the Schur-complement PCG).  Unsupported: bounds, robust losses, methods other than 'trf',
-    x_scale other than 'jac'.
+    x_scale other than 'jac'.  ``return_jac=True`` fills ``result.jac`` with the analytic Jacobian at
+    ``result.x`` in scipy's CSR layout (2N x (6C+3P), 9 entries per row); by default it is ``None``
+    because the reference only reads ``result.x`` (sfm.py:271,281).
     """
     if method != "trf":
         raise ValueError("sfmba.least_squares implements method='trf' only (the reference's choice).")
@@ -154,7 +156,24 @@ def least_squares(fun, x0, jac="2-point", bounds=(-np.inf, np.inf), method="trf"
         opt.pcg_tol = float(pcg_tol)
     opt.profile = 1 if profile else 0
     x, res, fun_v, grad = be.solve(x0, opt)
-    return _make_result(x, res, fun_v, grad, verbose)
+    out = _make_result(x, res, fun_v, grad, verbose)
+    if return_jac:
+        out.jac = _jacobian_csr(be, x, int(n_cameras), int(n_points), camera_indices, point_indices)
+    return out
+
+
+def _jacobian_csr(be, x, n_cameras, n_points, camera_indices, point_indices):
+    from scipy.sparse import csr_matrix
+    _, Jc, Jp = be.residual_jacobian(x)
+    ci = np.asarray(camera_indices, dtype=np.int64)
+    pi = np.asarray(point_indices, dtype=np.int64)
+    n_obs = len(ci)
+    cols = np.concatenate([ci[:, None] * 6 + np.arange(6)[None, :],
+                           n_cameras * 6 + pi[:, None] * 3 + np.arange(3)[None, :]], axis=1)
+    cols = np.repeat(cols[:, None, :], 2, axis=1).reshape(-1)
+    vals = np.concatenate([Jc, Jp], axis=2).reshape(-1)
+    indptr = np.arange(0, 18 * n_obs + 1, 9)
+    return csr_matrix((vals, cols, indptr), shape=(2 * n_obs, 6 * n_cameras + 3 * n_points))
 
 
 def _make_result(x, res, fun_v, grad, verbose):

@@ -120,3 +120,12 @@ def make_problem(n_cameras: int, n_points: int, n_obs: int, seed: int = 0,
 def make_config(name: str, seed: int = 0) -> BAProblem:
     C, P, N = CONFIGS[name]
     return make_problem(C, P, N, seed=seed)
+
+
+def drop_observations(pb: BAProblem, cameras=(), points=()) -> BAProblem:
+    """Same cameras and points, minus every observation of the given cameras / points (they stay in
+    ``x`` as unobserved parameters: zero Jacobian columns, which scipy's ``x_scale='jac'`` maps to scale 1)."""
+    keep = ~np.isin(pb.camera_indices, np.asarray(list(cameras), dtype=np.int64)) & \
+           ~np.isin(pb.point_indices, np.asarray(list(points), dtype=np.int64))
+    return BAProblem(pb.n_cameras, pb.n_points, pb.camera_indices[keep], pb.point_indices[keep],
+                     pb.points_2d[keep], pb.K, pb.x0, pb.x_true)

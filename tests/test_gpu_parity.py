@@ -257,6 +257,23 @@ def test_cfg3_full_loop_vs_oracle(orc):
     assert abs(res.rmse - float(np.sqrt(np.mean(o.fun ** 2)))) < 1e-9
 
 
+def test_unobserved_camera_and_point(orc):
+    import sfmba
+    g = np.load(os.path.join(GOLDEN, "lsq_tiny_cases.npz"))
+    pb = sfmba.drop_observations(sfmba.make_problem(5, 40, 200, seed=9), cameras=(3,), points=(7,))
+    status, nfev, njev, cost, rmse, opt = g["gaps_summary"]
+    res = sfmba.least_squares(sfmba.compute_residuals, pb.x0, x_scale="jac", ftol=1e-10, method="trf",
+                              args=pb.args, return_jac=True)
+    assert res.success and abs(res.rmse - rmse) < 1e-6 and res.cost <= cost * (1 + 1e-9)
+    for sl in (slice(18, 24), slice(30 + 21, 30 + 24)):          # unobserved parameters do not move
+        assert np.array_equal(res.x[sl], pb.x0[sl])
+    # result.jac: scipy's CSR layout, analytic values; J^T f reproduces result.grad
+    r, Jc, Jp = orc.jacobian_blocks(res.x, *pb.args)
+    J = orc.jacobian_csr(Jc, Jp, 5, 40, pb.camera_indices, pb.point_indices)
+    assert res.jac.shape == J.shape and abs(res.jac - J).max() <= 1e-11 * abs(J).max()
+    assert np.abs(res.jac.T @ res.fun - res.grad).max() <= 1e-9 * max(1.0, np.abs(res.grad).max())
+
+
 def test_error_behaviour(be):
     import sfmba
     pb = sfmba.make_problem(3, 8, 20, seed=0)

@@ -106,6 +106,20 @@ def test_trf_schur_reaches_scipy_minimum_on_tiny_problems():
             assert np.abs(res.fun - g[pre + "fun"]).max() < 5e-2
 
 
+def test_unobserved_camera_and_point_match_scipy():
+    """Zero Jacobian columns (a camera and a point without observations): scipy's x_scale='jac' maps
+    them to scale 1 and never moves them; so does the restatement."""
+    from sfmba.synthetic import drop_observations
+    g = np.load(os.path.join(GOLDEN, "lsq_tiny_cases.npz"))
+    pb = drop_observations(make_problem(5, 40, 200, seed=9), cameras=(3,), points=(7,))
+    assert np.array_equal(pb.x0, g["gaps_x0"])
+    status, nfev, njev, cost, rmse, opt = g["gaps_summary"]
+    res = orc.trf_schur(pb.x0, *pb.args, ftol=1e-10, linear="pcg", pcg_tol=1e-3)
+    assert abs(float(np.sqrt(np.mean(res.fun ** 2))) - rmse) < 1e-6 and res.cost <= cost * (1 + 1e-9)
+    for sl in (slice(18, 24), slice(30 + 21, 30 + 24)):
+        assert np.array_equal(res.x[sl], pb.x0[sl]) and np.array_equal(g["gaps_x"][sl], pb.x0[sl])
+
+
 def test_trf_schur_cfg2_matches_recorded_scipy_run():
     path = os.path.join(GOLDEN, "scipy_cfg2_run.json")
     if not os.path.exists(path):

@@ -29,7 +29,7 @@ from scipy.spatial.transform import Rotation as Rot
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "sfm-python_amd"))
-from sfmba.synthetic import make_problem  # noqa: E402
+from sfmba.synthetic import drop_observations, make_problem  # noqa: E402
 
 REF_BA = "/root/reference/sfm_lite/bundle_adjustment.py"
 OUT = os.path.join(ROOT, "tests", "golden")
@@ -155,6 +155,15 @@ def lsq_tiny(ba):
         out[pre + "summary"] = np.array([res.status, res.nfev, res.njev, res.cost,
                                          np.sqrt(np.mean(res.fun ** 2)), res.optimality])
         print(f"  lsq tiny {C}/{P}/{N}: status {res.status} nfev {res.nfev} cost {res.cost:.6f}")
+    # unobserved camera and point (zero Jacobian columns), single-observation points
+    pb = drop_observations(make_problem(5, 40, 200, seed=9), cameras=(3,), points=(7,))
+    S = ba.create_sparsity_matrix(5, 40, pb.n_obs, pb.camera_indices, pb.point_indices)
+    res = least_squares(ba.compute_residuals, pb.x0, jac_sparsity=S, verbose=0, x_scale="jac",
+                        ftol=1e-10, method="trf", args=pb.args)
+    out["gaps_x0"], out["gaps_x"], out["gaps_fun"] = pb.x0, res.x, res.fun
+    out["gaps_summary"] = np.array([res.status, res.nfev, res.njev, res.cost,
+                                    np.sqrt(np.mean(res.fun ** 2)), res.optimality])
+    print(f"  lsq gaps 5/40/{pb.n_obs}: status {res.status} nfev {res.nfev} cost {res.cost:.6f}")
     out["n_cases"] = np.array(3)
     return out
 
