@@ -1092,12 +1092,16 @@ __global__ __launch_bounds__(kSweepThreads) void k_schur_sweep(
                     y[0] = jp[0] * t0 + jp[3] * t1; y[1] = jp[1] * t0 + jp[4] * t1;
                     y[2] = jp[2] * t0 + jp[5] * t1;
                 }
+#ifndef SFMBA_ABLATE_SWEEP_SEGRED
                 seg_reduce<3>(y, act ? p : -1 - lane, lane);          // run key = point index
+#endif
                 z0 = vi[0] * y[0] + vi[1] * y[1] + vi[2] * y[2];      // meaningful on run heads
                 z1 = vi[1] * y[0] + vi[3] * y[1] + vi[4] * y[2];
                 z2 = vi[2] * y[0] + vi[4] * y[1] + vi[5] * y[2];
+#ifndef SFMBA_ABLATE_SWEEP_SEGRED
                 const int head = act ? lane - off : lane;
                 z0 = __shfl(z0, head); z1 = __shfl(z1, head); z2 = __shfl(z2, head);
+#endif
             }
             if (act) scatter(jc, jp, c, t0, t1, z0, z1, z2);
         }
