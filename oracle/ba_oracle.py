@@ -256,14 +256,27 @@ def normal_blocks(r, Jc, Jp, n_cameras, n_points, camera_indices, point_indices)
     return NormalBlocks(U, V, W, gc, gp)
 
 
+class NoComm:
+    """Single-process stand-in for the collectives of an observation-sharded solve."""
+    def sum(self, a):
+        return a
+
+    def max(self, a):
+        return a
+
+
 def schur_solve(nb: NormalBlocks, Dc, Dp, camera_indices, point_indices, rhs_c, rhs_p,
-                method="dense", pcg_tol=1e-10, pcg_maxiter=None, precond="block_u", info=None):
+                method="dense", pcg_tol=1e-10, pcg_maxiter=None, precond="block_u", info=None,
+                comm=None):
     """Solve [[U+Dc, W],[W^T, V+Dp]] [dc; dp] = [rhs_c; rhs_p] by eliminating the points.
 
     Dc (C,6), Dp (P,3) are the diagonal damping terms.  ``method='dense'`` forms S explicitly and
     uses a dense solve; ``method='pcg'`` runs block-Jacobi preconditioned CG on the implicit S (the
-    algorithm of the HIP path).
+    algorithm of the HIP path).  With ``comm`` the observations are one shard of a larger problem: ``nb.U``
+    and ``rhs_c`` are already summed over shards, every sum over observations that lands on cameras
+    goes through ``comm.sum`` (exactly the all-reduces of the HIP path), points stay local.
     """
+    comm = comm or NoComm()
     C, P = nb.U.shape[0], nb.V.shape[0]
     ci, pi = np.asarray(camera_indices), np.asarray(point_indices)
     Ud = nb.U.copy()
@@ -273,17 +286,18 @@ def schur_solve(nb: NormalBlocks, Dc, Dp, camera_indices, point_indices, rhs_c, 
     Vinv = np.linalg.inv(Vd)
     # reduced rhs: rhs_c - sum_i W_i Vinv_p rhs_p
     t = np.einsum("pij,pj->pi", Vinv, rhs_p)
-    red = rhs_c.copy()
-    np.add.at(red, ci, -np.einsum("nij,nj->ni", nb.W, t[pi]))
+    acc = np.zeros_like(rhs_c)
+    np.add.at(acc, ci, -np.einsum("nij,nj->ni", nb.W, t[pi]))
+    red = rhs_c + comm.sum(acc)
 
     def S_mv(vc):
         vc = vc.reshape(C, 6)
         y = np.zeros((P, 3))
         np.add.at(y, pi, np.einsum("nij,ni->nj", nb.W, vc[ci]))
         z = np.einsum("pij,pj->pi", Vinv, y)
-        out = np.einsum("cij,cj->ci", Ud, vc)
-        np.add.at(out, ci, -np.einsum("nij,nj->ni", nb.W, z[pi]))
-        return out.reshape(-1)
+        acc = np.zeros((C, 6))
+        np.add.at(acc, ci, -np.einsum("nij,nj->ni", nb.W, z[pi]))
+        return (np.einsum("cij,cj->ci", Ud, vc) + comm.sum(acc)).reshape(-1)
 
     if method == "dense":
         S = np.zeros((C, 6, C, 6))
@@ -387,40 +401,55 @@ class TRFResult:
 
 def trf_schur(x0, n_cameras, n_points, camera_indices, point_indices, points_2d, K,
               ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None, linear="dense",
-              pcg_tol=1e-10, precond="block_u", reg_min=1e-10, verbose=0):
+              pcg_tol=1e-10, precond="block_u", reg_min=1e-10, verbose=0, comm=None):
     """Restatement of trf_no_bounds(tr_solver='lsmr', x_scale='jac', loss='linear').
 
     Line references are to SCIPY/optimize/_lsq/trf.py.  Difference from scipy: gn_h of trf.py:480
-    is the exact minimiser of |J_h p + f|^2 + reg |p|^2 (Schur complement), not an LSMR iterate,
-    and J is analytic rather than forward-differenced.
+    is the minimiser of |J_h p + f|^2 + reg |p|^2 through the Schur complement, not an LSMR iterate,
+    and J is analytic rather than forward-differenced.  The 2-D subspace of trf.py:481-485 is
+    orthonormalised by Gram-Schmidt from dot products (as the HIP path does) instead of numpy's QR.
+
+    ``comm`` (test infrastructure for the N>1 path): when given, (camera_indices, ...) describe ONE
+    SHARD -- all cameras, the shard's own points and observations -- and every reduction the HIP path
+    all-reduces goes through ``comm.sum`` / ``comm.max``; x holds [all cameras | local points].
     """
+    comm = comm or NoComm()
     C, P = n_cameras, n_points
+    n6 = 6 * C
     ci, pi = np.asarray(camera_indices), np.asarray(point_indices)
     uv = np.asarray(points_2d, dtype=np.float64)
     args = (C, P, ci, pi, uv, K)
 
     def Jdot(Jc, Jp, vec):           # J @ vec -> (N,2)
-        vc = vec[:6 * C].reshape(C, 6)
-        vp = vec[6 * C:].reshape(P, 3)
+        vc = vec[:n6].reshape(C, 6)
+        vp = vec[n6:].reshape(P, 3)
         return np.einsum("nki,ni->nk", Jc, vc[ci]) + np.einsum("nki,ni->nk", Jp, vp[pi])
 
-    x = np.asarray(x0, dtype=np.float64).copy()
-    r, Jc, Jp = jacobian_blocks(x, *args)
-    if not np.all(np.isfinite(r)):
-        raise ValueError("Residuals are not finite in the initial point.")   # least_squares.py:844
-    nfev = njev = 1
-    cost = 0.5 * float(np.sum(r * r))                                          # :418
-    nb = normal_blocks(r, Jc, Jp, C, P, ci, pi)
-    g = np.concatenate([nb.gc.ravel(), nb.gp.ravel()])                         # :420
+    def dot(a, b):                   # camera slice is replicated, point slice is summed over shards
+        return float(a[:n6] @ b[:n6]) + float(comm.sum(float(a[n6:] @ b[n6:])))
+
+    def linearise(x):
+        r, Jc, Jp = jacobian_blocks(x, *args)
+        nb = normal_blocks(r, Jc, Jp, C, P, ci, pi)
+        nb.U = comm.sum(nb.U)
+        nb.gc = comm.sum(nb.gc)
+        return r, Jc, Jp, nb
 
     def col_norms(nb):
         d = np.concatenate([np.einsum("cii->ci", nb.U).ravel(), np.einsum("pii->pi", nb.V).ravel()])
         return np.sqrt(d)
 
+    x = np.asarray(x0, dtype=np.float64).copy()
+    r, Jc, Jp, nb = linearise(x)
+    cost = 0.5 * float(comm.sum(float(np.sum(r * r))))                         # :418
+    if not np.isfinite(cost):
+        raise ValueError("Residuals are not finite in the initial point.")   # least_squares.py:844
+    nfev = njev = 1
+    g = np.concatenate([nb.gc.ravel(), nb.gp.ravel()])                         # :420
     scale_inv = col_norms(nb)                                                  # :424, common.py:598
     scale_inv[scale_inv == 0] = 1
     scale = 1.0 / scale_inv
-    Delta = np.linalg.norm(x * scale_inv)                                      # :428
+    Delta = math.sqrt(dot(x * scale_inv, x * scale_inv))                       # :428
     if Delta == 0:
         Delta = 1.0
     if max_nfev is None:
@@ -432,7 +461,8 @@ def trf_schur(x0, n_cameras, n_points, camera_indices, point_indices, points_2d,
     history = []
     info = {}
     while True:                                                                # :450
-        g_norm = float(np.max(np.abs(g)))
+        gmax_p = float(np.max(np.abs(g[n6:]))) if P else 0.0
+        g_norm = max(float(np.max(np.abs(g[:n6]))), float(comm.max(gmax_p)))
         if g_norm < gtol:
             status = 1
         history.append(dict(iteration=iteration, nfev=nfev, cost=cost, reduction=actual_reduction,
@@ -447,46 +477,63 @@ def trf_schur(x0, n_cameras, n_points, camera_indices, point_indices, points_2d,
             break
         d = scale
         g_h = d * g                                                            # :461
+        sg = d * g_h                                                           # D^2 g
         # regularisation from the 1-D Cauchy problem, :471-475
-        v = Jdot(Jc, Jp, d * (-g_h))
-        a = 0.5 * float(np.sum(v * v))
-        b = -float(g_h @ g_h)
-        to_tr = Delta / np.linalg.norm(g_h)
-        ts = [0.0, to_tr]
+        t1 = Jdot(Jc, Jp, sg)                                                  # J_h g_h
+        G11 = float(comm.sum(float(np.sum(t1 * t1))))
+        a11 = dot(g_h, g_h)
+        a = 0.5 * G11
+        b = -a11
+        to_tr = Delta / math.sqrt(a11)
+        ys = [0.0, to_tr * (a * to_tr + b)]
         if a != 0:
             ext = -0.5 * b / a
             if 0.0 < ext < to_tr:
-                ts.append(ext)
-        ys = [t * (a * t + b) for t in ts]
-        ag_value = min(ys)
-        reg_term = max(-ag_value / Delta ** 2, reg_min)   # floor: see DESIGN.md (rank-2 V_p blocks)
+                ys.append(ext * (a * ext + b))
+        reg_term = max(-min(ys) / Delta ** 2, reg_min)   # floor: see DESIGN.md (rank-2 V_p blocks)
         # damped Gauss-Newton step, :477-480:  (J^T J + reg diag(scale_inv^2)) p = -g,  gn_h = p/d
         damp = reg_term * scale_inv ** 2
         info["pcg_iters"] = 0
-        dc, dp = schur_solve(nb, damp[:6 * C].reshape(C, 6), damp[6 * C:].reshape(P, 3), ci, pi,
+        dc, dp = schur_solve(nb, damp[:n6].reshape(C, 6), damp[n6:].reshape(P, 3), ci, pi,
                              -nb.gc, -nb.gp, method=linear, pcg_tol=pcg_tol, precond=precond,
-                             info=info)
-        gn_h = np.concatenate([dc.ravel(), dp.ravel()]) * scale_inv
-        # 2-D subspace, :481-485
-        S = np.vstack((g_h, gn_h)).T
-        S, _ = np.linalg.qr(S, mode="reduced")
-        JS = np.stack([Jdot(Jc, Jp, d * S[:, 0]).ravel(), Jdot(Jc, Jp, d * S[:, 1]).ravel()], axis=1)
-        B_S = JS.T @ JS
-        g_S = S.T @ g_h
+                             info=info, comm=comm)
+        p = np.concatenate([dc.ravel(), dp.ravel()])
+        gn_h = p * scale_inv
+        # 2-D subspace span(g_h, gn_h), Gram-Schmidt (:481-485)
+        t2 = Jdot(Jc, Jp, p)                                                   # J_h gn_h
+        G12 = float(comm.sum(float(np.sum(t1 * t2))))
+        G22 = float(comm.sum(float(np.sum(t2 * t2))))
+        a12, a22 = dot(g_h, gn_h), dot(gn_h, gn_h)
+        b11, b12, b22 = dot(sg, sg), dot(sg, p), dot(p, p)
+        x_norm = math.sqrt(dot(x, x))
+        s11 = math.sqrt(a11)
+        r12 = a12 / s11
+        r22sq = a22 - r12 * r12
+        two_d = r22sq > 1e-28 * a22 and r22sq > 0.0
+        r22 = math.sqrt(r22sq) if two_d else 1.0
+        if two_d:
+            B_S = np.array([[G11 / a11, (G12 / s11 - r12 * G11 / a11) / r22],
+                            [0.0, (G22 - 2.0 * r12 * G12 / s11 + r12 * r12 * G11 / a11) / (r22 * r22)]])
+        else:
+            B_S = np.array([[G11 / a11, 0.0], [0.0, 1.0]])
+        B_S[1, 0] = B_S[0, 1]
+        g_S = np.array([s11, 0.0])
         actual_reduction = -1.0
         while actual_reduction <= 0 and nfev < max_nfev:                       # :488
             p_S, _ = solve_trust_region_2d(B_S, g_S, Delta)
-            step_h = S @ p_S
+            if not two_d:
+                p_S = np.array([p_S[0], 0.0])
             predicted_reduction = -(0.5 * float(p_S @ B_S @ p_S) + float(g_S @ p_S))
-            step = d * step_h
-            x_new = x + step
+            c2 = p_S[1] / r22 if two_d else 0.0
+            c1 = (p_S[0] - (p_S[1] * r12 / r22 if two_d else 0.0)) / s11
+            step_h_norm = float(np.linalg.norm(p_S))
+            x_new = x + c1 * sg + c2 * p                                       # step = D step_h
             r_new = compute_residuals(x_new, *args).reshape(-1, 2)
             nfev += 1
-            step_h_norm = np.linalg.norm(step_h)
-            if not np.all(np.isfinite(r_new)):                                 # :504
+            cost_new = 0.5 * float(comm.sum(float(np.sum(r_new * r_new))))
+            if not np.isfinite(cost_new):                                      # :504
                 Delta = 0.25 * step_h_norm
                 continue
-            cost_new = 0.5 * float(np.sum(r_new * r_new))
             actual_reduction = cost - cost_new
             # update_tr_radius, common.py:222-245
             if predicted_reduction > 0:
@@ -500,20 +547,19 @@ def trf_schur(x0, n_cameras, n_points, camera_indices, point_indices, points_2d,
                 Delta_new = 0.25 * step_h_norm
             elif ratio > 0.75 and step_h_norm > 0.95 * Delta:
                 Delta_new = 2.0 * Delta
-            step_norm = float(np.linalg.norm(step))
+            step_norm = math.sqrt(max(0.0, c1 * c1 * b11 + 2.0 * c1 * c2 * b12 + c2 * c2 * b22))
             # check_termination, common.py:705-717
             ftol_ok = actual_reduction < ftol * cost and ratio > 0.25
-            xtol_ok = step_norm < xtol * (xtol + np.linalg.norm(x))
+            xtol_ok = step_norm < xtol * (xtol + x_norm)
             status = 4 if (ftol_ok and xtol_ok) else 2 if ftol_ok else 3 if xtol_ok else None
             if status is not None:
                 break
             Delta = Delta_new
         if actual_reduction > 0:                                               # :528
             x = x_new
-            r, Jc, Jp = jacobian_blocks(x, *args)
+            r, Jc, Jp, nb = linearise(x)
             njev += 1
             cost = cost_new
-            nb = normal_blocks(r, Jc, Jp, C, P, ci, pi)
             g = np.concatenate([nb.gc.ravel(), nb.gp.ravel()])
             scale_inv = np.maximum(col_norms(nb), scale_inv)                   # common.py:606
             scale = 1.0 / scale_inv
