@@ -35,6 +35,11 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
+def k1_bytes_f32(C, P, N):
+    """fp32-storage mode: idx 8 + uv 8 read, r 8 + Jacobian 48 written per observation."""
+    return 72 * N + 24 * P + 48 * C
+
+
 def k1_bytes(C, P, N):
     """Algorithmic bytes of one residual+Jacobian launch: per observation read
     cam_idx 4 + pt_idx 4 + uv 16, write r 16 + d r/d w 48 + d r/d X 48 = 136 B; once per point 24 B, per
@@ -89,6 +94,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-exchange", action="store_true",
                     help="use the collective path even at world size 1 (plumbing check)")
+    ap.add_argument("--storage-bits", type=int, default=64, choices=[64, 32],
+                    help="64: fp64 streams (configs 2-4); 32: fp32 storage of pixels/residuals/Jacobian with fp64 "
+                         "arithmetic and accumulation (config 5)")
     ap.add_argument("--exchange", default="native", choices=["native", "torch"],
                     help="native: RCCL called from C++ on the solver stream; torch: torch.distributed callback")
     a = ap.parse_args()
@@ -121,6 +129,7 @@ def main():
 
     with torch.cuda.stream(stream):
         be.set_stream(stream.cuda_stream)
+        be.set_precision(a.storage_bits)
         be.set_problem(*pb.args)
         ex = None
         if td is not None:
@@ -170,12 +179,13 @@ def main():
     if rank == 0:
         steps = sum(r[0] for r in results)
         k1_us = sum(r[3] * r[4] for r in results) / max(1, sum(r[4] for r in results))
-        achieved = k1_bytes(C, P, N) / (k1_us * 1e-6) / 1e9 if k1_us > 0 else None
+        kb = k1_bytes_f32 if a.storage_bits == 32 else k1_bytes
+        achieved = kb(C, P, N) / (k1_us * 1e-6) / 1e9 if k1_us > 0 else None
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "k1_traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            if tj.get("workload") == a.workload:
+            if tj.get("workload") == a.workload and a.storage_bits == 64:
                 traffic = tj.get("hbm_bytes_per_launch")
         full = [r for r in results if r[6] != 0] or results
         line = {
@@ -186,7 +196,7 @@ def main():
             "n_gpus": world, "steps": steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * elapsed / steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64" if a.storage_bits == 64 else "f64 arithmetic, f32 storage", "data": "synthetic",
             "config": {"workload": f"{a.workload}: {C} cameras / {P} points / {N} observations per GPU shard, "
                                    f"shared cameras, seed 0 (SURVEY.md 8d generator)",
                        "solver": "TRF (scipy trf_no_bounds restated) + analytic Jacobian + Schur PCG, ftol=1e-10",
@@ -201,7 +211,7 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                          "traffic": traffic, "avg_launch_us": k1_us,
-                         "algorithmic_bytes_per_launch": k1_bytes(C, P, N),
+                         "algorithmic_bytes_per_launch": kb(C, P, N),
                          "note": "bytes = 136 N + 24 P + 48 C: the 2x3 block d r/d T = -d r/d X is not stored; "
                                  "SURVEY 8d's 184 N figure writes it a second time",
                          "achieved_if_counted_as_survey_184B": (k1_bytes_survey(C, P, N) / (k1_us * 1e-6) / 1e9)

@@ -67,7 +67,7 @@ typedef struct sfmba_result {
     int64_t iterations;    /* outer (trust-region) iterations                                    */
     int64_t pcg_iterations;/* total inner PCG iterations                                         */
     int32_t status;        /* 0 max_nfev/max_iter, 1 gtol, 2 ftol, 3 xtol, 4 ftol+xtol           */
-    int32_t reserved;
+    int32_t reserved;      /* number of PCG solves that stopped on a numerical breakdown         */
     double  seconds_total; /* wall time of the call, host clock, H2D/D2H included                */
     double  seconds_device;/* wall time between upload and download                              */
     double  resjac_avg_us; /* HIP-event average of the residual+Jacobian kernel (profile=1)      */
@@ -88,6 +88,11 @@ const char* sfmba_last_error(const sfmba_handle* h);     /* valid until the next
 void sfmba_default_options(sfmba_options* opt);
 /* Run every kernel of `h` on this hipStream_t (default: a stream the handle owns). */
 int  sfmba_set_stream(sfmba_handle* h, void* hip_stream);
+
+/* Storage precision of the per-observation streams (uv, r, Jacobian): 64 (default) or 32.  Arithmetic
+ * and every accumulation are fp64 in both modes; 32 halves the bytes of the sweeps (BASELINE.json
+ * config 5).  Takes effect at the next sfmba_set_problem. */
+int  sfmba_set_precision(sfmba_handle* h, int32_t storage_bits);
 
 /* ---- problem (the args= tuple of sfm.py:268) ---------------------------------------------- */
 /* camera_indices, point_indices: (N) int64; points_2d: (N,2) float64 (caller converts the

@@ -126,6 +126,25 @@ __device__ __forceinline__ void seg_reduce(double (&v)[NV], int key, int lane) {
     }
 }
 
+// fp32-STORAGE mode (BASELINE config 5): uv, r, t1 and the compact Jacobian are kept as floats, all
+// arithmetic and every accumulation stays fp64.  The Jacobian tile of 64 observations is then three
+// float4 planes: (w0 w1 w2 w0') (w1' w2' X0 X1) (X2 X0' X1' X2')  -- 48 B per observation.
+__device__ __forceinline__ size_t jaddr_f32(int i, int m) {       // in float4 units
+    return ((size_t)(i >> 6) * 3 + m) * 64 + (i & 63);
+}
+// element i of an array of pairs stored as double2 (f32 = 0) or float2 (f32 = 1)
+__device__ __forceinline__ double2 load_pair(const double* __restrict__ base, int f32, int i) {
+    if (f32) {
+        const float2 v = reinterpret_cast<const float2*>(base)[i];
+        return make_double2((double)v.x, (double)v.y);
+    }
+    return reinterpret_cast<const double2*>(base)[i];
+}
+__device__ __forceinline__ void store_pair(double* __restrict__ base, int f32, int i, double a, double b) {
+    if (f32) reinterpret_cast<float2*>(base)[i] = make_float2((float)a, (float)b);
+    else reinterpret_cast<double2*>(base)[i] = make_double2(a, b);
+}
+
 // ---------------------------------------------------------------------------------------------
 // K0: per-camera table.  R = I + a [w]x + b [w]x^2 (== scipy Rotation.from_rotvec(w).as_matrix(),
 // bundle_adjustment.py:25, which the reference rebuilds per OBSERVATION), and the coefficients of the
@@ -257,7 +276,7 @@ __device__ __forceinline__ void st16(double* __restrict__ p, double a, double b)
 #endif
 }
 
-template <bool LDS_TAB, bool JAC, bool STORE_R>
+template <bool LDS_TAB, bool JAC, bool STORE_R, bool F32>
 __global__ __launch_bounds__(kSweepThreads) void k_resjac(
     const double* __restrict__ camtab, const double* __restrict__ pts, const int* __restrict__ cam_idx,
     const int* __restrict__ pt_idx, const double* __restrict__ uv, double* __restrict__ r,
@@ -278,7 +297,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_resjac(
     int c0 = 0, p0 = 0, c1 = 0, p1 = 0;
     double2 uv0 = make_double2(0.0, 0.0);
     double X0 = 0.0, Y0 = 0.0, Z0 = 0.0;
-    if (i < N) { c0 = cam_idx[i]; p0 = pt_idx[i]; uv0 = *reinterpret_cast<const double2*>(uv + 2 * (size_t)i); }
+    if (i < N) { c0 = cam_idx[i]; p0 = pt_idx[i]; uv0 = load_pair(uv, F32, i); }
     if (i + stride < N) { c1 = cam_idx[i + stride]; p1 = pt_idx[i + stride]; }
     if (i < N) { const double* __restrict__ Xp = pts + 3 * (size_t)p0; X0 = Xp[0]; Y0 = Xp[1]; Z0 = Xp[2]; }
     if (LDS_TAB) {                               // stage the camera table while those loads fly
@@ -299,7 +318,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_resjac(
         double X1 = 0.0, Y1 = 0.0, Z1 = 0.0;
         if (in2 < N) { c2 = cam_idx[in2]; p2 = pt_idx[in2]; }
         if (in < N) {
-            uv1 = *reinterpret_cast<const double2*>(uv + 2 * (size_t)in);
+            uv1 = load_pair(uv, F32, in);
             const double* __restrict__ Xp = pts + 3 * (size_t)p1;
             X1 = Xp[0]; Y1 = Xp[1]; Z1 = Xp[2];
         }
@@ -313,7 +332,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_resjac(
 #endif
         acc += rx * rx + ry * ry;
 #if defined(SFMBA_ABLATE_K1_STORES)      // timing-only ablation: everything but the Jacobian stores
-        if (STORE_R) st16(r + 2 * (size_t)i, rx, ry);
+        if (STORE_R) store_pair(r, F32, i, rx, ry);
         if (JAC) {
             double sacc = 0.0;
             for (int k = 0; k < 12; ++k) sacc += jc[k];
@@ -321,14 +340,23 @@ __global__ __launch_bounds__(kSweepThreads) void k_resjac(
             if (sacc == 123.456) J[i] = sacc;
         }
 #else
-        if (STORE_R) st16(r + 2 * (size_t)i, rx, ry);
+        if (STORE_R) {
+            if (F32) store_pair(r, 1, i, rx, ry); else st16(r + 2 * (size_t)i, rx, ry);
+        }
         if (JAC) {
             // compact form: d r/d w (jc[0..2], jc[6..8]) and d r/d X (jp); d r/d T = -jp is not stored
-            st16(J + jaddr(ld, i, 0), jc[0], jc[1]);
-            st16(J + jaddr(ld, i, 1), jc[2], jc[6]);
-            st16(J + jaddr(ld, i, 2), jc[7], jc[8]);
+            if (F32) {
+                float4* __restrict__ Jf = reinterpret_cast<float4*>(J);
+                Jf[jaddr_f32(i, 0)] = make_float4((float)jc[0], (float)jc[1], (float)jc[2], (float)jc[6]);
+                Jf[jaddr_f32(i, 1)] = make_float4((float)jc[7], (float)jc[8], (float)jp[0], (float)jp[1]);
+                Jf[jaddr_f32(i, 2)] = make_float4((float)jp[2], (float)jp[3], (float)jp[4], (float)jp[5]);
+            } else {
+                st16(J + jaddr(ld, i, 0), jc[0], jc[1]);
+                st16(J + jaddr(ld, i, 1), jc[2], jc[6]);
+                st16(J + jaddr(ld, i, 2), jc[7], jc[8]);
 #pragma unroll
-            for (int m = 0; m < 3; ++m) st16(J + jaddr(ld, i, 3 + m), jp[2 * m], jp[2 * m + 1]);
+                for (int m = 0; m < 3; ++m) st16(J + jaddr(ld, i, 3 + m), jp[2 * m], jp[2 * m + 1]);
+            }
         }
 #endif
         i = in;
@@ -346,15 +374,22 @@ __global__ __launch_bounds__(kSweepThreads) void k_resjac(
 }
 
 // Unpack the Jacobian pair-planes into the row-major (N,2,6)/(N,2,3) blocks of the C-ABI (test entry).
-__global__ void k_unpack_jac(const double* __restrict__ J, int N,
-                             int64_t ld, double* __restrict__ jc_out, double* __restrict__ jp_out) {
+__global__ void k_unpack_jac(const double* __restrict__ J, int N, int64_t ld, int f32,
+                             double* __restrict__ jc_out, double* __restrict__ jp_out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     double w[6], x[6];
-    for (int m = 0; m < 3; ++m) {
-        const double2 a = *reinterpret_cast<const double2*>(J + jaddr(ld, i, m));
-        const double2 b = *reinterpret_cast<const double2*>(J + jaddr(ld, i, 3 + m));
-        w[2 * m] = a.x; w[2 * m + 1] = a.y; x[2 * m] = b.x; x[2 * m + 1] = b.y;
+    if (f32) {
+        const float4* __restrict__ Jf = reinterpret_cast<const float4*>(J);
+        const float4 a = Jf[jaddr_f32(i, 0)], b = Jf[jaddr_f32(i, 1)], c = Jf[jaddr_f32(i, 2)];
+        w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y;
+        x[0] = b.z; x[1] = b.w; x[2] = c.x; x[3] = c.y; x[4] = c.z; x[5] = c.w;
+    } else {
+        for (int m = 0; m < 3; ++m) {
+            const double2 a = *reinterpret_cast<const double2*>(J + jaddr(ld, i, m));
+            const double2 b = *reinterpret_cast<const double2*>(J + jaddr(ld, i, 3 + m));
+            w[2 * m] = a.x; w[2 * m + 1] = a.y; x[2 * m] = b.x; x[2 * m + 1] = b.y;
+        }
     }
     for (int row = 0; row < 2; ++row)
         for (int k = 0; k < 3; ++k) {
@@ -375,19 +410,27 @@ struct ObsArrays {
     const int* __restrict__ cam_idx;
     const int* __restrict__ pt_idx;
     const int* __restrict__ pt_ptr;   // [P+1] run offsets
-    const double* __restrict__ J;     // six pair-planes per observation (jaddr)
+    const double* __restrict__ J;     // six pair-planes per observation (jaddr) / three float4 planes (f32)
     int64_t ld;
+    int f32;                          // fp32-storage mode: J, r, t1 hold floats
 };
 
 // jc (2x6 row-major) and jp (2x3 row-major) of observation i from the compact pair-planes
 __device__ __forceinline__ void load_blocks(const ObsArrays& o, int i, double* jc, double* jp) {
     double w[6];
+    if (o.f32) {
+        const float4* __restrict__ Jf = reinterpret_cast<const float4*>(o.J);
+        const float4 a = Jf[jaddr_f32(i, 0)], b = Jf[jaddr_f32(i, 1)], c = Jf[jaddr_f32(i, 2)];
+        w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y;
+        jp[0] = b.z; jp[1] = b.w; jp[2] = c.x; jp[3] = c.y; jp[4] = c.z; jp[5] = c.w;
+    } else {
 #pragma unroll
-    for (int m = 0; m < 3; ++m) {
-        const double2 a = *reinterpret_cast<const double2*>(o.J + jaddr(o.ld, i, m));
-        const double2 b = *reinterpret_cast<const double2*>(o.J + jaddr(o.ld, i, 3 + m));
-        w[2 * m] = a.x; w[2 * m + 1] = a.y;
-        jp[2 * m] = b.x; jp[2 * m + 1] = b.y;
+        for (int m = 0; m < 3; ++m) {
+            const double2 a = *reinterpret_cast<const double2*>(o.J + jaddr(o.ld, i, m));
+            const double2 b = *reinterpret_cast<const double2*>(o.J + jaddr(o.ld, i, 3 + m));
+            w[2 * m] = a.x; w[2 * m + 1] = a.y;
+            jp[2 * m] = b.x; jp[2 * m + 1] = b.y;
+        }
     }
 #pragma unroll
     for (int row = 0; row < 2; ++row)
@@ -446,7 +489,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_normal_blocks(
             for (int q = 0; q < 9; ++q) v[q] = 0.0;
             for (int j = pos + lane; j < run_end; j += 64) {
                 load_blocks(o, j, jc, jp);
-                const double rx = r[2 * (size_t)j], ry = r[2 * (size_t)j + 1];
+                const double2 rr_ = load_pair(r, o.f32, j); const double rx = rr_.x, ry = rr_.y;
                 cam_accumulate(j, jc, rx, ry);
                 double w[9];
                 point_terms(jp, rx, ry, w);
@@ -467,7 +510,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_normal_blocks(
         const bool act = lane < n_take;
         if (act) {
             load_blocks(o, i, jc, jp);
-            const double rx = r[2 * (size_t)i], ry = r[2 * (size_t)i + 1];
+            const double2 rr_ = load_pair(r, o.f32, i); const double rx = rr_.x, ry = rr_.y;
             cam_accumulate(i, jc, rx, ry);
             point_terms(jp, rx, ry, v);
         } else {
@@ -534,7 +577,8 @@ __global__ __launch_bounds__(kSweepThreads) void k_normal_blocks_lds(
         for (int i = pos + lane; i < end; i += 64) {
             double jc[12];
             load_jc(o, i, jc);
-            cam_accumulate(i, jc, r[2 * (size_t)i], r[2 * (size_t)i + 1]);
+            const double2 rr_ = load_pair(r, o.f32, i);
+            cam_accumulate(i, jc, rr_.x, rr_.y);
         }
         pos = end;
     }
@@ -553,7 +597,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_normal_blocks_lds(
             for (int q = 0; q < 9; ++q) v[q] = 0.0;
             for (int j = pos + lane; j < run_end; j += 64) {
                 load_blocks(o, j, jc, jp);
-                const double rx = r[2 * (size_t)j], ry = r[2 * (size_t)j + 1];
+                const double2 rr_ = load_pair(r, o.f32, j); const double rx = rr_.x, ry = rr_.y;
                 cam_accumulate(j, jc, rx, ry);
                 double w[9];
                 point_terms(jp, rx, ry, w);
@@ -574,7 +618,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_normal_blocks_lds(
         const bool act = lane < n_take;
         if (act) {
             load_blocks(o, i, jc, jp);
-            const double rx = r[2 * (size_t)i], ry = r[2 * (size_t)i + 1];
+            const double2 rr_ = load_pair(r, o.f32, i); const double rx = rr_.x, ry = rr_.y;
             cam_accumulate(i, jc, rx, ry);
             point_terms(jp, rx, ry, v);
         } else {
@@ -769,7 +813,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_jdot(ObsArrays o, const doubl
         for (int k = 0; k < 6; ++k) { t0 += jc[k] * a[k]; t1v += jc[6 + k] * a[k]; }
 #pragma unroll
         for (int k = 0; k < 3; ++k) { t0 += jp[k] * b[k]; t1v += jp[3 + k] * b[k]; }
-        *reinterpret_cast<double2*>(t1 + 2 * (size_t)i) = make_double2(t0, t1v);
+        store_pair(t1, o.f32, i, t0, t1v);
         acc += t0 * t0 + t1v * t1v;
     }
     acc = wave_sum(acc);
@@ -1334,7 +1378,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_backsub(
     auto gram = [&](int i, const double* jp, double t0, double t1v, double z0, double z1, double z2) {
         const double a0 = t0 + jp[0] * z0 + jp[1] * z1 + jp[2] * z2;
         const double a1 = t1v + jp[3] * z0 + jp[4] * z1 + jp[5] * z2;
-        const double2 tt = *reinterpret_cast<const double2*>(t1 + 2 * (size_t)i);
+        const double2 tt = load_pair(t1, o.f32, i);
         g12 += tt.x * a0 + tt.y * a1;
         g22 += a0 * a0 + a1 * a1;
     };

@@ -109,6 +109,8 @@ struct sfmba_handle {
     bool permuted = false;
     std::vector<int64_t> order;              // sorted position -> caller's observation index
     int n_ranges = 0;
+    bool f32 = false;                        // fp32 storage of uv, r, t1 and the Jacobian (arithmetic stays fp64)
+    bool f32_next = false;                   // takes effect at the next sfmba_set_problem
     bool lds_tab = true, lds_acc = true, lds_vec = true;
     int nb_passes = 1;                       // column passes of the LDS normal-block tables; 0 = global atomics
 
@@ -212,7 +214,7 @@ int set_lds(sfmba_handle* h, Kern k, size_t bytes) {
 
 ObsArrays obs_arrays(const sfmba_handle* h) {
     return ObsArrays{h->cam_idx.as<int>(), h->pt_idx.as<int>(), h->pt_ptr.as<int>(),
-                     h->J[h->jcur].as<double>(), h->ld};
+                     h->J[h->jcur].as<double>(), h->ld, h->f32 ? 1 : 0};
 }
 
 StepTable step_table(const sfmba_handle* h) {
@@ -266,11 +268,11 @@ int launch_cam_table(sfmba_handle* h, const double* x, double* tab) {
 // sum r^2 partials in `part` and returns the number of partials.  With ev0/ev1 the dispatch itself
 // is bracketed (hipExtLaunchKernelGGL: start/stop taken from the kernel's own dispatch, as rocprofv3
 // does), so the measured duration is the kernel's and not host launch latency.
-template <bool LDS, bool JAC, bool STORE_R>
+template <bool LDS, bool JAC, bool STORE_R, bool F32>
 int launch_resjac_v(sfmba_handle* h, const double* x, const double* tab, int js, int grid, size_t lds,
                     hipEvent_t ev0, hipEvent_t ev1) {
     const double* pts = x + 6 * h->C;
-    auto kern = k_resjac<LDS, JAC, STORE_R>;
+    auto kern = k_resjac<LDS, JAC, STORE_R, F32>;
     CHK(set_lds(h, kern, lds));
     if (ev0) {
         hipExtLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), (uint32_t)lds, h->stream, ev0, ev1, 0u, tab, pts,
@@ -292,9 +294,12 @@ int launch_resjac(sfmba_handle* h, const double* x, const double* tab, int js, i
                   hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
     const int grid = grid_1d(h->N, kSweepThreads, h->n_cu);
     *nparts = grid;
+    const size_t lds = (size_t)h->C * kCamTab * sizeof(double);
     if (h->lds_tab)
-        return launch_resjac_v<true, JAC, STORE_R>(h, x, tab, js, grid, (size_t)h->C * kCamTab * sizeof(double), ev0, ev1);
-    return launch_resjac_v<false, JAC, STORE_R>(h, x, tab, js, grid, 0, ev0, ev1);
+        return h->f32 ? launch_resjac_v<true, JAC, STORE_R, true>(h, x, tab, js, grid, lds, ev0, ev1)
+                      : launch_resjac_v<true, JAC, STORE_R, false>(h, x, tab, js, grid, lds, ev0, ev1);
+    return h->f32 ? launch_resjac_v<false, JAC, STORE_R, true>(h, x, tab, js, grid, 0, ev0, ev1)
+                  : launch_resjac_v<false, JAC, STORE_R, false>(h, x, tab, js, grid, 0, ev0, ev1);
 }
 
 // sum of `nparts` partial rows of width nq into the exchange scalars starting at slot `slot`
@@ -472,6 +477,21 @@ int upload_x(sfmba_handle* h, const double* x_host) {
     return 0;
 }
 
+// residual vector of the current buffer set, 2N doubles in the library's (point-major) order
+int download_residuals(sfmba_handle* h, std::vector<double>& out) {
+    out.resize(2 * h->N);
+    if (h->f32) {
+        std::vector<float> tmp(2 * h->N);
+        HIPCHK(h, hipMemcpyAsync(tmp.data(), h->r[h->jcur].p, sizeof(float) * 2 * h->N, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        for (int64_t k = 0; k < 2 * h->N; ++k) out[k] = tmp[k];
+    } else {
+        HIPCHK(h, hipMemcpyAsync(out.data(), h->r[h->jcur].p, sizeof(double) * 2 * h->N, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    return 0;
+}
+
 int check_ready(sfmba_handle* h, const void* x) {
     if (!h->have_problem) return fail(h, -1, "sfmba_set_problem has not been called");
     if (!x) return fail(h, -1, "x is NULL");
@@ -616,6 +636,13 @@ int sfmba_set_stream(sfmba_handle* h, void* hip_stream) {
     return 0;
 }
 
+int sfmba_set_precision(sfmba_handle* h, int32_t storage_bits) {
+    CHK(enter(h));
+    if (storage_bits != 64 && storage_bits != 32) return fail(h, -1, "storage_bits must be 64 or 32");
+    h->f32_next = storage_bits == 32;
+    return 0;
+}
+
 int64_t sfmba_exchange_doubles(int64_t n_cameras) { return 39 * n_cameras + kScalSlots; }   // kScalSlots = 32
 
 int sfmba_set_exchange(sfmba_handle* h, void* arena, int64_t arena_doubles, sfmba_allreduce_fn fn,
@@ -696,6 +723,7 @@ int sfmba_set_problem(sfmba_handle* h, int64_t C, int64_t P, int64_t N, const in
         if (!std::isfinite(K[k])) return fail(h, -1, "K is not finite");
         h->K.k[k] = K[k];
     }
+    h->f32 = h->f32_next;
     h->C = C; h->P = P; h->N = N; h->n = 6 * C + 3 * P;
     h->N_total = N;
     h->ld = (N + 255) / 256 * 256;
@@ -771,7 +799,8 @@ int sfmba_set_problem(sfmba_handle* h, int64_t C, int64_t P, int64_t N, const in
     HIPCHK(h, h->cam_idx.ensure(sizeof(int) * ld));
     HIPCHK(h, h->pt_idx.ensure(sizeof(int) * ld));
     HIPCHK(h, h->pt_ptr.ensure(sizeof(int) * (P + 1)));
-    HIPCHK(h, h->uv.ensure(sizeof(double) * 2 * ld));
+    const size_t esz = h->f32 ? sizeof(float) : sizeof(double);     // element size of the per-observation streams
+    HIPCHK(h, h->uv.ensure(esz * 2 * ld));
     HIPCHK(h, h->ranges.ensure(sizeof(int2) * std::max<size_t>(1, ranges.size())));
     HIPCHK(h, h->wsteps.ensure(sizeof(int2) * std::max<size_t>(1, wsteps.size())));
     HIPCHK(h, h->steps.ensure(sizeof(int2) * std::max<size_t>(1, steps.size())));
@@ -781,11 +810,11 @@ int sfmba_set_problem(sfmba_handle* h, int64_t C, int64_t P, int64_t N, const in
     HIPCHK(h, h->tabA.ensure(sizeof(double) * kCamTab * C));
     HIPCHK(h, h->tabB.ensure(sizeof(double) * kCamTab * C));
     for (int js = 0; js < 2; ++js) {
-        HIPCHK(h, h->r[js].ensure(sizeof(double) * 2 * ld));
-        HIPCHK(h, h->J[js].ensure(sizeof(double) * 12 * ld));
+        HIPCHK(h, h->r[js].ensure(esz * 2 * ld));
+        HIPCHK(h, h->J[js].ensure(esz * 12 * ld));
     }
     h->jcur = 0;
-    HIPCHK(h, h->t1.ensure(sizeof(double) * 2 * ld));
+    HIPCHK(h, h->t1.ensure(esz * 2 * ld));
     HIPCHK(h, h->V.ensure(sizeof(double) * 6 * P));
     HIPCHK(h, h->Vinv.ensure(sizeof(double) * 6 * P));
     HIPCHK(h, h->gp.ensure(sizeof(double) * 3 * P));
@@ -816,7 +845,13 @@ int sfmba_set_problem(sfmba_handle* h, int64_t C, int64_t P, int64_t N, const in
     HIPCHK(h, hipMemcpyAsync(h->cam_idx.p, ci.data(), sizeof(int) * ld, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->pt_idx.p, pi.data(), sizeof(int) * ld, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->pt_ptr.p, ptr.data(), sizeof(int) * (P + 1), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->uv.p, uvs.data(), sizeof(double) * 2 * ld, hipMemcpyHostToDevice, h->stream));
+    std::vector<float> uvf;
+    if (h->f32) {                            // integer pixels up to 2^24 are exact in fp32
+        uvf.assign(uvs.begin(), uvs.end());
+        HIPCHK(h, hipMemcpyAsync(h->uv.p, uvf.data(), sizeof(float) * 2 * ld, hipMemcpyHostToDevice, h->stream));
+    } else {
+        HIPCHK(h, hipMemcpyAsync(h->uv.p, uvs.data(), sizeof(double) * 2 * ld, hipMemcpyHostToDevice, h->stream));
+    }
     if (!ranges.empty()) {
         HIPCHK(h, hipMemcpyAsync(h->ranges.p, ranges.data(), sizeof(int2) * ranges.size(), hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipMemcpyAsync(h->wsteps.p, wsteps.data(), sizeof(int2) * wsteps.size(), hipMemcpyHostToDevice, h->stream));
@@ -828,8 +863,8 @@ int sfmba_set_problem(sfmba_handle* h, int64_t C, int64_t P, int64_t N, const in
     HIPCHK(h, hipMemsetAsync(h->V.p, 0, sizeof(double) * 6 * P, h->stream));
     HIPCHK(h, hipMemsetAsync(h->gp.p, 0, sizeof(double) * 3 * P, h->stream));
     HIPCHK(h, hipMemsetAsync(h->p.p, 0, sizeof(double) * h->n, h->stream));      // ... and their step is 0
-    HIPCHK(h, hipMemsetAsync(h->r[0].p, 0, sizeof(double) * 2 * ld, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->r[1].p, 0, sizeof(double) * 2 * ld, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->r[0].p, 0, esz * 2 * ld, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->r[1].p, 0, esz * 2 * ld, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));     // host staging vectors go out of scope
     h->have_problem = true;
     return 0;
@@ -843,17 +878,12 @@ int sfmba_residuals(sfmba_handle* h, const double* x, double* r_out) {
     CHK(launch_cam_table(h, h->x, h->tab));
     int np = 0;
     CHK((launch_resjac<false, true>(h, h->x, h->tab, h->jcur, &np)));
-    if (!h->permuted) {
-        HIPCHK(h, hipMemcpyAsync(r_out, h->r[h->jcur].p, sizeof(double) * 2 * h->N, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-    } else {
-        std::vector<double> tmp(2 * h->N);
-        HIPCHK(h, hipMemcpyAsync(tmp.data(), h->r[h->jcur].p, sizeof(double) * 2 * h->N, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        for (int64_t k = 0; k < h->N; ++k) {
-            r_out[2 * h->order[k]] = tmp[2 * k];
-            r_out[2 * h->order[k] + 1] = tmp[2 * k + 1];
-        }
+    std::vector<double> tmp;
+    CHK(download_residuals(h, tmp));
+    for (int64_t k = 0; k < h->N; ++k) {
+        const int64_t d = h->permuted ? h->order[k] : k;
+        r_out[2 * d] = tmp[2 * k];
+        r_out[2 * d + 1] = tmp[2 * k + 1];
     }
     return 0;
 }
@@ -870,10 +900,10 @@ int sfmba_residual_jacobian(sfmba_handle* h, const double* x, double* r_out, dou
     HIPCHK(h, jc_rm.ensure(sizeof(double) * 12 * h->N));
     HIPCHK(h, jp_rm.ensure(sizeof(double) * 6 * h->N));
     hipLaunchKernelGGL(k_unpack_jac, dim3((h->N + 255) / 256), dim3(256), 0, h->stream, h->J[h->jcur].as<double>(),
-                       (int)h->N, h->ld, jc_rm.as<double>(), jp_rm.as<double>());
+                       (int)h->N, h->ld, h->f32 ? 1 : 0, jc_rm.as<double>(), jp_rm.as<double>());
     HIPCHK(h, hipGetLastError());
-    std::vector<double> tr(2 * h->N), tc(12 * h->N), tp(6 * h->N);
-    HIPCHK(h, hipMemcpyAsync(tr.data(), h->r[h->jcur].p, sizeof(double) * 2 * h->N, hipMemcpyDeviceToHost, h->stream));
+    std::vector<double> tr, tc(12 * h->N), tp(6 * h->N);
+    CHK(download_residuals(h, tr));
     HIPCHK(h, hipMemcpyAsync(tc.data(), jc_rm.p, sizeof(double) * 12 * h->N, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(tp.data(), jp_rm.p, sizeof(double) * 6 * h->N, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -970,7 +1000,7 @@ int sfmba_time_kernel(sfmba_handle* h, const double* x, int32_t which, int32_t r
             case 3: CHK(launch_schur_sweep<0>(h, h->vtmp.as<double>(), nullptr, nullptr, 0)); break;
             case 10:   // streaming-store ceiling: fill the 12 Jc planes, 16 B per lane, one stream
                 hipLaunchKernelGGL(k_fill16, dim3(h->n_cu * 2), dim3(1024), 0, h->stream, h->J[h->jcur].as<double>(),
-                                   (int64_t)(6 * h->ld), 1.0);
+                                   (int64_t)((h->f32 ? 3 : 6) * h->ld), 1.0);
                 break;
             case 11:   // same bytes, 2048 workgroups
                 hipLaunchKernelGGL(k_fill16, dim3(2048), dim3(1024), 0, h->stream, h->J[h->jcur].as<double>(),
@@ -1061,6 +1091,7 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
     double step_norm = 0.0, actual_reduction = 0.0, g_norm = 0.0, reg_term = 0.0;
     bool have_red = false;
     int pcg_guess = 0;                                          // iterations the previous solve needed
+    int64_t pcg_breakdowns = 0;
     bool nb_valid = true;                                       // V, g_p, [U|g_c] belong to h->x
     if (opt.verbose >= 2) print_header();
 
@@ -1113,7 +1144,11 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
         } else {
             CHK(fetch_scalars(h));
         }
-        if (hc.done == 3) return fail(h, -3, "PCG breakdown: reduced camera system is not positive definite");
+        // hc.done == 3: the CG recurrences lost positive definiteness (rounding, typically on a converged
+        // system whose right-hand side is noise).  The iterate of the last good step is kept -- it is
+        // zero when the very first step failed, in which case the 2-D model below degenerates to the
+        // steepest-descent line, exactly scipy's fallback when gn_h adds nothing to span(g_h).
+        if (hc.done == 3) ++pcg_breakdowns;
 
         // ---- loop head of trf.py:450-459, evaluated now that the scalars are on the host -----------
         g_norm = std::max(h->h_scal[kMaxSlot], h->h_scal[kCamSlot + 0]);
@@ -1244,6 +1279,7 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
     out->seconds_device = t_end - t_dev0;
     out->last_step_norm = step_norm;
     out->last_reg = reg_term;
+    out->reserved = (int32_t)pcg_breakdowns;
     h->solved = true;
     return 0;
 }
@@ -1252,9 +1288,8 @@ int sfmba_get_fun_grad(sfmba_handle* h, double* fun_out, double* grad_out) {
     CHK(enter(h));
     if (!h->have_problem || !h->solved) return fail(h, -1, "no completed sfmba_solve on this handle");
     if (fun_out) {
-        std::vector<double> tmp(2 * h->N);
-        HIPCHK(h, hipMemcpyAsync(tmp.data(), h->r[h->jcur].p, sizeof(double) * 2 * h->N, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
+        std::vector<double> tmp;
+        CHK(download_residuals(h, tmp));
         for (int64_t k = 0; k < h->N; ++k) {
             const int64_t d = h->permuted ? h->order[k] : k;
             fun_out[2 * d] = tmp[2 * k];

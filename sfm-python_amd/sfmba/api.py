@@ -86,6 +86,7 @@ def create_sparsity_matrix(n_cameras, n_points, n_obs, camera_indices, point3d_i
 def compute_residuals(x, n_cameras, n_points, camera_indices, point_indices, points_2d, K, device=0):
     """(2N,) interleaved residuals pi(K R(w)(X - T)) - uv, evaluated by the HIP kernel."""
     be = get_backend(device)
+    be.set_precision(64)
     be.set_problem(n_cameras, n_points, camera_indices, point_indices, points_2d, K)
     return be.residuals(x)
 
@@ -104,7 +105,7 @@ def project_points(points, camera_params, K, device=0):
 def least_squares(fun, x0, jac="2-point", bounds=(-np.inf, np.inf), method="trf", ftol=1e-8, xtol=1e-8,
                   gtol=1e-8, x_scale=1.0, loss="linear", f_scale=1.0, diff_step=None, tr_solver=None,
                   tr_options=None, jac_sparsity=None, max_nfev=None, verbose=0, args=(), kwargs=None,
-                  device=0, max_iter=None, pcg_tol=None, profile=False, return_jac=False):
+                  device=0, max_iter=None, pcg_tol=None, profile=False, return_jac=False, storage_bits=64):
     """Drop-in for the reference's ``least_squares(compute_residuals, x0, jac_sparsity=..., verbose=...,
     x_scale='jac', ftol=tol, method='trf', args=(...))`` (sfm.py:266-268).
 
@@ -115,7 +116,8 @@ def least_squares(fun, x0, jac="2-point", bounds=(-np.inf, np.inf), method="trf"
     from the Schur-complement PCG).  Unsupported: bounds, robust losses, methods other than 'trf',
     x_scale other than 'jac'.  ``return_jac=True`` fills ``result.jac`` with the analytic Jacobian at
     ``result.x`` in scipy's CSR layout (2N x (6C+3P), 9 entries per row); by default it is ``None``
-    because the reference only reads ``result.x`` (sfm.py:271,281).
+    because the reference only reads ``result.x`` (sfm.py:271,281).  ``storage_bits=32`` keeps the
+    per-observation streams (pixels, residuals, Jacobian) in fp32 with fp64 arithmetic and accumulation.
     """
     if method != "trf":
         raise ValueError("sfmba.least_squares implements method='trf' only (the reference's choice).")
@@ -144,6 +146,7 @@ def least_squares(fun, x0, jac="2-point", bounds=(-np.inf, np.inf), method="trf"
         raise ValueError("`jac_sparsity` has wrong shape.")          # least_squares.py:160-161
 
     be = get_backend(device)
+    be.set_precision(storage_bits)
     be.set_problem(n_cameras, n_points, camera_indices, point_indices, points_2d, K)
     opt = be.default_options()
     opt.ftol = 0.0 if ftol is None else float(ftol)

@@ -57,6 +57,11 @@ class Backend:
             raise MemoryError(msg)
         raise BackendError(f"sfmba error {rc}: {msg}")
 
+    def set_precision(self, storage_bits: int):
+        """64 (default) or 32: storage of uv / r / Jacobian; arithmetic stays fp64.  Applies from the
+        next set_problem."""
+        self._check(self._lib.sfmba_set_precision(self._h, int(storage_bits)))
+
     def set_stream(self, hip_stream: int):
         self._check(self._lib.sfmba_set_stream(self._h, C.c_void_p(int(hip_stream))))
 

@@ -352,6 +352,39 @@ def test_reproj_error_rt_convention_and_problem_files(tmp_path):
     assert abs(a.cost - b.cost) <= 1e-10 * b.cost
 
 
+# ---- fp32-storage mode (BASELINE config 5): floats in HBM, fp64 arithmetic and accumulation --------------
+
+def test_fp32_storage_mode(orc):
+    """Stated tolerances: stored residuals / Jacobian entries carry one fp32 rounding (<= 2^-24 relative
+    to the largest magnitude, checked at 1e-6); the solve reaches scipy's RMSE on the SceauxCastle-scale
+    problem to 1e-6 px and the fp64 path's cost to 1e-9 relative."""
+    import sfmba
+    be = sfmba.Backend(0)
+    try:
+        be.set_precision(32)
+        pb = sfmba.make_problem(11, 300, 2000, seed=2)
+        be.set_problem(*pb.args)
+        r, Jc, Jp = be.residual_jacobian(pb.x0)
+        r_o, Jc_o, Jp_o = orc.jacobian_blocks(pb.x0, *pb.args)
+        assert np.abs(r - r_o.ravel()).max() <= 1e-6 * np.abs(r_o).max()
+        assert _rel(Jc, Jc_o) < 1e-6 and _rel(Jp, Jp_o) < 1e-6
+        nb = orc.normal_blocks(r_o, Jc_o, Jp_o, pb.n_cameras, pb.n_points, pb.camera_indices, pb.point_indices)
+        U, V, gc, gp = be.normal_blocks(pb.x0)
+        assert _rel(U, _upper(nb.U)) < 1e-6 and _rel(V, _upper(nb.V)) < 1e-6
+        assert _rel(gc, nb.gc) < 1e-5 and _rel(gp, nb.gp) < 1e-5
+    finally:
+        be.close()
+    rec = json.load(open(os.path.join(GOLDEN, "scipy_cfg2_run.json")))
+    pb = sfmba.make_problem(11, 3000, 10000, seed=0)
+    a = sfmba.least_squares(sfmba.compute_residuals, pb.x0, x_scale="jac", ftol=1e-10, method="trf",
+                            args=pb.args, storage_bits=32)
+    b = sfmba.least_squares(sfmba.compute_residuals, pb.x0, x_scale="jac", ftol=1e-10, method="trf",
+                            args=pb.args, storage_bits=64)
+    assert a.success and abs(a.rmse - rec["rmse"]) < 1e-6
+    assert abs(a.cost - b.cost) <= 1e-9 * b.cost
+    assert np.abs(a.fun - b.fun).max() < 1e-4
+
+
 # ---- the N>1 code path on one GPU: world_size-1 RCCL through the same Exchange / callback plumbing -------
 
 def test_exchange_path_world1_nccl():
