@@ -19,6 +19,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -1092,12 +1093,18 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
     bool have_red = false;
     int pcg_guess = 0;                                          // iterations the previous solve needed
     int64_t pcg_breakdowns = 0;
-    bool nb_valid = true;                                       // V, g_p, [U|g_c] belong to h->x
+    bool nb_valid = true;                                       // V, g_p, [U|g_c] (and, single-buffered, J and r) belong to h->x
+    // Single-buffered Jacobian: the trial point is evaluated into the SAME J / r buffers the sweeps of
+    // this iteration have just read, so K1's stores land on lines that are still resident in the
+    // Infinity Cache instead of cold ones.  A rejected step leaves J / r describing the rejected point;
+    // nothing uses them before the next trial overwrites them, except the two rare exits handled below.
+    static const bool single_buffer = std::getenv("SFMBA_DOUBLE_BUFFER") == nullptr;
     if (opt.verbose >= 2) print_header();
 
     for (;;) {                                                  // trf.py:450
         if (!nb_valid) {                                        // a rejected trial overwrote the blocks and no
-            CHK(launch_normal_blocks(h));                       // step was accepted afterwards (nfev limit)
+            if (single_buffer) CHK(eval_jac(h->x, h->tab, h->jcur, true));   // step was accepted afterwards
+            CHK(launch_normal_blocks(h));                       // (nfev limit)
             CHK(exchange(h, h->Ugc(), 27 * C, 0));
             nb_valid = true;
         }
@@ -1181,7 +1188,7 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
 
         actual_reduction = -1.0;
         double cost_new = cost;
-        const int jalt = h->jcur ^ 1;
+        const int jalt = single_buffer ? h->jcur : (h->jcur ^ 1);
         while (actual_reduction <= 0.0 && nfev < max_nfev) {    // trf.py:488
             double pS[2];
             solve_trust_region_2d(B, gS, Delta, pS);
@@ -1208,10 +1215,11 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
             // blocks of the trial point (speculating on acceptance, the common case).  They overwrite
             // V / g_p / [U|g_c], which a rejected step does not need: a retry only re-solves the 2-D
             // model (host scalars) and re-applies k_step_table to x, D^2 g and p, all untouched.
+            const int jkeep = h->jcur;
             h->jcur = jalt;
             const int rc_nb = launch_normal_blocks(h);
             const int rc_ex = rc_nb == 0 ? exchange(h, h->Ugc(), 27 * C, 0) : rc_nb;
-            h->jcur = jalt ^ 1;
+            h->jcur = jkeep;
             CHK(rc_ex);
             nb_valid = false;
             CHK(wait_event(h, h->ev_handoff));                  // hand-off 2
@@ -1253,6 +1261,10 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
         }
     }
     if (status == -1) status = 0;
+    if (single_buffer && !nb_valid) {                           // last trial was rejected: result.fun is f(x)
+        int np = 0;
+        CHK((launch_resjac<false, true>(h, h->x, h->tab, h->jcur, &np)));
+    }
 
     CHK(ensure_h_x(h));
     HIPCHK(h, hipMemcpyAsync(h->h_x, h->x, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
