@@ -52,8 +52,8 @@ __device__ __forceinline__ size_t jaddr(int64_t ld, int i, int m) {
 // The PCG keeps two sets of its five camera-sized vectors and two accumulators and alternates between
 // them every iteration (set = iters & 1), so that the update kernel can run on several workgroups that
 // all read the old set completely while each writes its slice of the new one.
-constexpr int kPcgVecs = 5;     // x r p s u
-constexpr int kPcgX = 0, kPcgR = 1, kPcgP = 2, kPcgS = 3, kPcgU = 4;
+constexpr int kPcgVecs = 6;     // x r p s u (plane-major [k][C]) and u once more camera-major [C][6]
+constexpr int kPcgX = 0, kPcgR = 1, kPcgP = 2, kPcgS = 3, kPcgU = 4, kPcgUcm = 5;
 constexpr int kPcgUpdateBlocks = 8;
 
 struct PcgCtrl {
@@ -999,7 +999,11 @@ __global__ __launch_bounds__(64) void k_prep(double* __restrict__ sc, double Del
 // K4/K5 sweep: one pass over the observations applies the implicit Schur complement,
 //   acc_c += sum_{i in c} Jc_i^T ( Jc_i v_c - Jp_i z_p ),  z_p = Vinv_p sum_{i in p} Jp_i^T Jc_i v_c
 // (MODE 0), or the reduced right-hand side term acc_c -= sum Jc_i^T Jp_i e_p (MODE 1, z = e given).
-// S v = acc + Dc v is completed by k_pcg_update.  LDS_ACC: v and acc live in LDS (2 * 6C doubles).
+// S v = acc + Dc v is completed by k_pcg_update.  ACC selects where the camera-sized operands live:
+//   1  v and acc in LDS (2 * 6C doubles; up to ~1700 cameras)
+//   2  acc of the camera range [c_lo, c_hi) in LDS, v gathered from the camera-major copy in L2; the
+//      host runs one pass per range (each pass repeats the per-point part: ~3400 cameras per pass)
+//   0  everything global (fp64 atomics to HBM): only a last resort
 // ---------------------------------------------------------------------------------------------
 // The walk over a wave's observation range is precomputed on the host (it depends only on the problem
 // structure): steps[s] = (first observation, count); count <= 64 is a batch that ends on a point
@@ -1013,12 +1017,13 @@ struct StepTable {
     int n_waves;
 };
 
-template <bool LDS_ACC, int MODE>
+template <int ACC, int MODE>
 __global__ __launch_bounds__(kSweepThreads) void k_schur_sweep(
     StepTable st, ObsArrays o, const double* __restrict__ vin,
     const double* __restrict__ Vinv, const double* __restrict__ zin, double* __restrict__ acc, int C,
-    const PcgCtrl* __restrict__ ctrl2, int L) {
+    const PcgCtrl* __restrict__ ctrl2, int L, int c_lo, int c_hi) {
     extern __shared__ __align__(16) double smem[];
+    constexpr bool LDS_ACC = ACC == 1;
     const int n6 = 6 * C;
     if (ctrl2 != nullptr) {
         // inside the PCG: `vin` is the base of the ping-pong vector sets, `acc` the base of the two
@@ -1026,7 +1031,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_schur_sweep(
         const PcgCtrl* __restrict__ ctrl = ctrl2 + (L & 1);
         if (ctrl->done != 0) return;                         // grid-uniform
         const int set = ctrl->iters & 1;
-        vin += (size_t)(set * kPcgVecs + kPcgU) * n6;
+        vin += (size_t)(set * kPcgVecs + (ACC == 2 ? kPcgUcm : kPcgU)) * n6;
         acc += (size_t)set * n6;
     }
     const int wg = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -1040,7 +1045,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_schur_sweep(
     if (cur.y <= 64 && lane < cur.y) { c = o.cam_idx[i]; p = o.pt_idx[i]; off = st.run_off[i]; }
 
     double* s_v = smem;
-    double* s_acc = smem + n6;
+    double* s_acc = (ACC == 2) ? smem : smem + n6;
     if (LDS_ACC) {
         for (int e = threadIdx.x; e < n6; e += blockDim.x) {       // e = k*C + c (global, coalesced)
             const int k = e / C, cc = e - k * C;
@@ -1048,12 +1053,18 @@ __global__ __launch_bounds__(kSweepThreads) void k_schur_sweep(
             s_acc[6 * cc + k] = 0.0;
         }
         __syncthreads();
+    } else if (ACC == 2) {
+        for (int e = threadIdx.x; e < 6 * (c_hi - c_lo); e += blockDim.x) s_acc[e] = 0.0;
+        __syncthreads();
     }
+    // v: LDS table (ACC 1), camera-major copy in global memory (ACC 2; the standalone test entry hands a
+    // plane-major vector and ctrl2 == nullptr, see the host), plane-major global (ACC 0)
     const double* __restrict__ vv = LDS_ACC ? s_v : vin;
-    double* __restrict__ av = LDS_ACC ? s_acc : acc;
-    // element k of camera c: LDS tables are camera-major (one camera's 6 values adjacent), the
-    // global vectors plane-major
-    const int cs = LDS_ACC ? 6 : 1, ks = LDS_ACC ? 1 : C;
+    double* __restrict__ av = (ACC == 0) ? acc : (ACC == 1 ? s_acc : s_acc - 6 * (size_t)c_lo);
+    // element k of camera c: LDS tables and the camera-major copy keep one camera's 6 values adjacent,
+    // the plane-major global vectors do not
+    const int cs = (ACC == 0) ? 1 : 6, ks = (ACC == 0) ? C : 1;
+    const int acs = (ACC == 0) ? 1 : 6, aks = (ACC == 0) ? C : 1;
 
     // per-observation pieces
     auto jcv = [&](const double* jc, int cc, double& t0, double& t1) {
@@ -1068,14 +1079,15 @@ __global__ __launch_bounds__(kSweepThreads) void k_schur_sweep(
                        double z1, double z2) {
         const double u0 = t0 - (jp[0] * z0 + jp[1] * z1 + jp[2] * z2);
         const double u1 = t1 - (jp[3] * z0 + jp[4] * z1 + jp[5] * z2);
+        if (ACC == 2 && (cc < c_lo || cc >= c_hi)) return;                  // another pass owns this camera
 #ifndef SFMBA_ABLATE_SCATTER
 #pragma unroll
-        for (int k = 0; k < 6; ++k) unsafeAtomicAdd(av + cs * cc + ks * k, jc[k] * u0 + jc[6 + k] * u1);
+        for (int k = 0; k < 6; ++k) unsafeAtomicAdd(av + acs * cc + aks * k, jc[k] * u0 + jc[6 + k] * u1);
 #else
         double sacc = 0.0;
 #pragma unroll
         for (int k = 0; k < 6; ++k) sacc += jc[k] * u0 + jc[6 + k] * u1;
-        if (sacc == 123.456) av[cs * cc] = sacc;                            // keep the values live
+        if (sacc == 123.456) av[acs * cc] = sacc;                           // keep the values live
 #endif
     };
 
@@ -1152,6 +1164,15 @@ __global__ __launch_bounds__(kSweepThreads) void k_schur_sweep(
         cur = nxt; i = in_; c = cn; p = pn; off = offn;
         ++s;
     }
+    if (ACC == 2) {
+        __syncthreads();
+        const int nr = c_hi - c_lo;
+        for (int e = threadIdx.x; e < 6 * nr; e += blockDim.x) {    // e = k*nr + (c - c_lo): coalesced per plane
+            const int k = e / nr, cc = e - k * nr;
+            const double a = s_acc[6 * cc + k];
+            if (a != 0.0) unsafeAtomicAdd(acc + (size_t)k * C + c_lo + cc, a);
+        }
+    }
     if (LDS_ACC) {
         __syncthreads();
 #ifndef SFMBA_ABLATE_FLUSH          // timing-only ablation builds, never shipped
@@ -1219,6 +1240,7 @@ __global__ __launch_bounds__(1024) void k_pcg_init(const double* __restrict__ Ug
         for (int k = 0; k < 6; ++k) {
             const double z = minv_row(m, rr, k);
             uk[(size_t)k * C + c] = z;
+            vecs[kPcgUcm * n6 + 6 * (size_t)c + k] = z;
             s[0] += z * rr[k];
         }
     }
@@ -1312,6 +1334,7 @@ __global__ __launch_bounds__(1024) void k_pcg_update(double* __restrict__ acc,
                 vout[kPcgX * n6 + e] = xx[k]; vout[kPcgR * n6 + e] = rr[k];
                 vout[kPcgP * n6 + e] = pp[k]; vout[kPcgS * n6 + e] = ss[k];
                 vout[kPcgU * n6 + e] = uu[k];
+                vout[kPcgUcm * n6 + 6 * (size_t)c + k] = uu[k];
                 acc_out[e] = 0.0;                        // the sweep after next accumulates here
             }
         }

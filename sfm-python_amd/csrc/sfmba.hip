@@ -113,6 +113,7 @@ struct sfmba_handle {
     bool f32 = false;                        // fp32 storage of uv, r, t1 and the Jacobian (arithmetic stays fp64)
     bool f32_next = false;                   // takes effect at the next sfmba_set_problem
     bool lds_tab = true, lds_acc = true, lds_vec = true;
+    int acc_mode = 1, acc_range = 0;         // operand placement of the Schur sweep (launch_schur_sweep)
     int nb_passes = 1;                       // column passes of the LDS normal-block tables; 0 = global atomics
 
     DevBuf cam_idx, pt_idx, pt_ptr, uv, ranges, wsteps, steps, run_off;
@@ -122,7 +123,7 @@ struct sfmba_handle {
     int jcur = 0;
     DevBuf V, Vinv, gp, e;
     DevBuf g, si, sg, p;                     // n-vectors; p = [dc | dp]
-    DevBuf Dc, Minv, vecs, vtmp;               // camera-sized, plane-major [k][C]; vecs = 2 sets x (x r p s u)
+    DevBuf Dc, Minv, vecs, vtmp, vcm;               // camera-sized, plane-major [k][C]; vecs = 2 sets x (x r p s u)
     DevBuf part, ctrl, tables;
     DevBuf arena_own;
     double* arena = nullptr;                 // [acc0 6C | acc1 6C | Ugc 27C | 32 scalars]
@@ -358,22 +359,37 @@ int launch_normal_blocks(sfmba_handle* h) {
 }
 
 // MODE 0 inside the PCG: vin = base of the vector sets, ctrl2/L select set and accumulator on the
-// device; MODE 0 standalone (test entry): vin = the vector itself, ctrl2 = nullptr; MODE 1: zin = e.
+// device; MODE 0 standalone (test entry): vin = the vector itself (plane-major), ctrl2 = nullptr;
+// MODE 1: zin = e.  Operand placement (h->acc_mode): 1 = v and acc in LDS; 2 = acc in LDS per camera
+// range, one pass per range, v from the camera-major copy; 0 = all global.
+template <int ACC, int MODE>
+int launch_schur_sweep_v(sfmba_handle* h, const double* vin, const double* zin, const PcgCtrl* ctrl2, int L,
+                         size_t lds, int c_lo, int c_hi) {
+    const int grid = (h->n_ranges + kWavesPerSweepBlock - 1) / kWavesPerSweepBlock;
+    auto kern = k_schur_sweep<ACC, MODE>;
+    CHK(set_lds(h, kern, lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), lds, h->stream, step_table(h), obs_arrays(h), vin,
+                       h->Vinv.as<double>(), zin, h->acc(), (int)h->C, ctrl2, L, c_lo, c_hi);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
 template <int MODE>
 int launch_schur_sweep(sfmba_handle* h, const double* vin, const double* zin, const PcgCtrl* ctrl2, int L) {
-    const int grid = (h->n_ranges + kWavesPerSweepBlock - 1) / kWavesPerSweepBlock;
-    if (h->lds_acc) {
-        const size_t lds = sizeof(double) * 12 * h->C;
-        auto kern = k_schur_sweep<true, MODE>;
-        CHK(set_lds(h, kern, lds));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), lds, h->stream, step_table(h),
-                           obs_arrays(h), vin, h->Vinv.as<double>(), zin, h->acc(), (int)h->C, ctrl2, L);
-    } else {
-        auto kern = k_schur_sweep<false, MODE>;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), 0, h->stream, step_table(h),
-                           obs_arrays(h), vin, h->Vinv.as<double>(), zin, h->acc(), (int)h->C, ctrl2, L);
+    const int C = (int)h->C;
+    if (h->acc_mode == 1) return launch_schur_sweep_v<1, MODE>(h, vin, zin, ctrl2, L, sizeof(double) * 12 * C, 0, C);
+    if (h->acc_mode == 0) return launch_schur_sweep_v<0, MODE>(h, vin, zin, ctrl2, L, 0, 0, C);
+    const double* v = vin;
+    if (MODE == 0 && ctrl2 == nullptr) {          // standalone: make the camera-major copy the kernel gathers from
+        hipLaunchKernelGGL(k_transpose6, dim3((6 * C + 255) / 256), dim3(256), 0, h->stream, vin, C,
+                           h->vcm.as<double>(), (const PcgCtrl*)nullptr, 0);
+        HIPCHK(h, hipGetLastError());
+        v = h->vcm.as<double>();
     }
-    HIPCHK(h, hipGetLastError());
+    for (int c_lo = 0; c_lo < C; c_lo += h->acc_range) {
+        const int c_hi = std::min(C, c_lo + h->acc_range);
+        CHK((launch_schur_sweep_v<2, MODE>(h, v, zin, ctrl2, L, sizeof(double) * 6 * (size_t)(c_hi - c_lo), c_lo, c_hi)));
+    }
     return 0;
 }
 
@@ -789,6 +805,13 @@ int sfmba_set_problem(sfmba_handle* h, int64_t C, int64_t P, int64_t N, const in
     h->lds_tab = (size_t)C * kCamTab * sizeof(double) <= kLdsDynMax;
     h->lds_acc = (size_t)C * 12 * sizeof(double) <= kLdsDynMax;
     h->lds_vec = (size_t)C * 6 * sizeof(double) <= kLdsDynMax;
+    h->acc_range = (int)(kLdsDynMax / (6 * sizeof(double)));
+    h->acc_mode = h->lds_acc ? 1 : 2;
+    if (const char* e = std::getenv("SFMBA_ACC_MODE")) {        // test hook: force a placement
+        const int m = std::atoi(e);
+        if (m == 0 || m == 2 || (m == 1 && h->lds_acc)) h->acc_mode = m;
+        if (const char* r = std::getenv("SFMBA_ACC_RANGE")) h->acc_range = std::max(1, std::min(h->acc_range, std::atoi(r)));
+    }
     {   // normal-block LDS tables: as many column passes as the 27 columns need (a pass costs ~25 us
         // per million observations, the global-atomics fallback ~1300 us); atomics only past ~20k cameras
         const size_t budget = kLdsDynMax;
@@ -828,6 +851,7 @@ int sfmba_set_problem(sfmba_handle* h, int64_t C, int64_t P, int64_t N, const in
     HIPCHK(h, h->Minv.ensure(sizeof(double) * 21 * C));
     HIPCHK(h, h->vecs.ensure(sizeof(double) * 2 * kPcgVecs * 6 * C));
     HIPCHK(h, h->vtmp.ensure(sizeof(double) * 6 * C));
+    HIPCHK(h, h->vcm.ensure(sizeof(double) * 6 * C));
     h->red_bc = grid_1d(6 * C, 256, 32);
     h->red_grid = h->red_bc + grid_1d(3 * P, 256, 992);
     HIPCHK(h, h->part.ensure(sizeof(double) * (size_t)(2048 * kNQ)));

@@ -170,6 +170,29 @@ def test_many_cameras_global_table_variants(be, orc):
         _matvec_case(be, orc, pb, nb)
 
 
+def test_schur_sweep_operand_placements(be, orc, monkeypatch):
+    """The three placements of the sweep's camera-sized operands (LDS tables; LDS accumulator per camera
+    range with one pass per range; all global) give the same product and the same solve."""
+    import sfmba
+    pb = sfmba.make_problem(40, 400, 5000, seed=3)
+    ref = None
+    for mode, rng in (("1", None), ("2", "16"), ("2", "40"), ("0", None)):
+        monkeypatch.setenv("SFMBA_ACC_MODE", mode)
+        if rng:
+            monkeypatch.setenv("SFMBA_ACC_RANGE", rng)
+        else:
+            monkeypatch.delenv("SFMBA_ACC_RANGE", raising=False)
+        nb = _blocks_case(be, orc, pb)
+        y = _matvec_case(be, orc, pb, nb)
+        res = sfmba.least_squares(sfmba.compute_residuals, pb.x0, x_scale="jac", ftol=1e-10, method="trf",
+                                  args=pb.args)
+        if ref is None:
+            ref = (y, res)
+        assert _rel(y, ref[0]) < 1e-11
+        assert (res.status, res.nfev) == (ref[1].status, ref[1].nfev)
+        assert abs(res.cost - ref[1].cost) <= 1e-10 * ref[1].cost
+
+
 # ---- A5-A9: the solver -------------------------------------------------------------------------------
 
 def test_solve_matches_scipy_on_tiny_problems(orc):
