@@ -155,6 +155,44 @@ def test_long_tracks_and_ragged_runs(be, orc):
     _matvec_case(be, orc, pb2, nb)
 
 
+def test_random_track_length_distributions(be, orc):
+    """Random run structures: geometric and heavy-tailed track lengths, runs of exactly 64 / 65 / 128 /
+    256 / 300 observations (step cuts, the > 64 long-run path, the 255 clip of the run-offset byte),
+    points without observations, a camera seen once."""
+    from sfmba import make_problem
+    rng = np.random.default_rng(42)
+    for trial in range(5):
+        P = 150
+        if trial == 0:
+            lens = rng.geometric(0.15, P)
+        elif trial == 1:
+            lens = np.minimum(1 + (rng.pareto(1.2, P) * 3).astype(int), 400)
+        elif trial == 2:
+            lens = rng.integers(0, 4, P)                       # many empty points
+            lens[:6] = [64, 65, 128, 256, 300, 1]
+        elif trial == 3:
+            lens = np.full(P, 1)
+            lens[::7] = 63
+        else:
+            lens = rng.integers(1, 130, P)
+        lens = np.asarray(lens, dtype=np.int64)
+        lens[-1] = max(lens[-1], 1)
+        N = int(lens.sum())
+        C = 9
+        base = make_problem(C, P, max(N, P), seed=100 + trial)
+        pi = np.repeat(np.arange(P, dtype=np.int64), lens)
+        ci = rng.integers(0, C - 1, N).astype(np.int64)
+        ci[0] = C - 1                                          # camera C-1 is seen exactly once
+        uv = base.points_2d[:N]
+        pb = type(base)(C, P, ci, pi, uv, base.K, base.x0, base.x_true)
+        nb = _blocks_case(be, orc, pb)
+        _matvec_case(be, orc, pb, nb, seed=trial)
+        r, Jc, Jp = be.residual_jacobian(pb.x0)
+        r_o, Jc_o, Jp_o = orc.jacobian_blocks(pb.x0, *pb.args)
+        assert np.abs(r - r_o.ravel()).max() <= 1e-11 * max(3000.0, np.abs(r_o).max())
+        assert _rel(Jc, Jc_o) < 1e-11 and _rel(Jp, Jp_o) < 1e-11
+
+
 def test_many_cameras_global_table_variants(be, orc):
     """More cameras than fit the LDS tables: 1300 (camera table in L2, 2 normal-block column passes),
     1800 (Schur accumulators global, 3 passes), 2600 (4 passes), 21000 (normal blocks by global atomics)."""
