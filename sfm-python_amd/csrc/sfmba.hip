@@ -1150,7 +1150,7 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
         CHK(pcg_start(h, opt));                                 // replaces lsmr, trf.py:477-480
         PcgCtrl hc{};
         if (pcg_guess > 0) {
-            CHK(pcg_enqueue(h, pcg_guess + 2));                 // speculative: no read-back
+            CHK(pcg_enqueue(h, pcg_guess + 1));                 // speculative: no read-back (the count rarely grows)
         } else {
             CHK(pcg_finish_polling(h, opt, &hc));
         }
