@@ -479,10 +479,11 @@ double qsum(const sfmba_handle* h, int q) { return h->h_scal[kPointSlot[q]] + h-
 // x crosses PCIe through a pinned staging buffer (an async copy from pageable memory is staged by the
 // runtime anyway, synchronously and in small pieces)
 int ensure_h_x(sfmba_handle* h) {
-    if (h->h_x && h->h_x_doubles >= (size_t)h->n) return 0;
+    const size_t need = (size_t)std::max<int64_t>(h->n, 2 * h->N);      // also stages the residual vector
+    if (h->h_x && h->h_x_doubles >= need) return 0;
     if (h->h_x) { (void)hipHostFree(h->h_x); h->h_x = nullptr; h->h_x_doubles = 0; }
-    HIPCHK(h, hipHostMalloc((void**)&h->h_x, sizeof(double) * h->n, hipHostMallocDefault));
-    h->h_x_doubles = (size_t)h->n;
+    HIPCHK(h, hipHostMalloc((void**)&h->h_x, sizeof(double) * need, hipHostMallocDefault));
+    h->h_x_doubles = need;
     return 0;
 }
 
@@ -494,17 +495,20 @@ int upload_x(sfmba_handle* h, const double* x_host) {
     return 0;
 }
 
-// residual vector of the current buffer set, 2N doubles in the library's (point-major) order
-int download_residuals(sfmba_handle* h, std::vector<double>& out) {
-    out.resize(2 * h->N);
-    if (h->f32) {
-        std::vector<float> tmp(2 * h->N);
-        HIPCHK(h, hipMemcpyAsync(tmp.data(), h->r[h->jcur].p, sizeof(float) * 2 * h->N, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        for (int64_t k = 0; k < 2 * h->N; ++k) out[k] = tmp[k];
-    } else {
-        HIPCHK(h, hipMemcpyAsync(out.data(), h->r[h->jcur].p, sizeof(double) * 2 * h->N, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
+// residual vector of the current buffer set into the caller's array (2N doubles, caller's observation
+// order), through the pinned staging buffer
+int download_residuals(sfmba_handle* h, double* r_out) {
+    CHK(ensure_h_x(h));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const size_t bytes = (h->f32 ? sizeof(float) : sizeof(double)) * 2 * (size_t)h->N;
+    HIPCHK(h, hipMemcpyAsync(h->h_x, h->r[h->jcur].p, bytes, hipMemcpyDeviceToHost, h->stream));
+    CHK(wait_stream(h));
+    if (!h->f32 && !h->permuted) { memcpy(r_out, h->h_x, bytes); return 0; }
+    const float* sf = reinterpret_cast<const float*>(h->h_x);
+    for (int64_t k = 0; k < h->N; ++k) {
+        const int64_t d = h->permuted ? h->order[k] : k;
+        r_out[2 * d] = h->f32 ? (double)sf[2 * k] : h->h_x[2 * k];
+        r_out[2 * d + 1] = h->f32 ? (double)sf[2 * k + 1] : h->h_x[2 * k + 1];
     }
     return 0;
 }
@@ -903,14 +907,7 @@ int sfmba_residuals(sfmba_handle* h, const double* x, double* r_out) {
     CHK(launch_cam_table(h, h->x, h->tab));
     int np = 0;
     CHK((launch_resjac<false, true>(h, h->x, h->tab, h->jcur, &np)));
-    std::vector<double> tmp;
-    CHK(download_residuals(h, tmp));
-    for (int64_t k = 0; k < h->N; ++k) {
-        const int64_t d = h->permuted ? h->order[k] : k;
-        r_out[2 * d] = tmp[2 * k];
-        r_out[2 * d + 1] = tmp[2 * k + 1];
-    }
-    return 0;
+    return download_residuals(h, r_out);
 }
 
 int sfmba_residual_jacobian(sfmba_handle* h, const double* x, double* r_out, double* Jc_out, double* Jp_out) {
@@ -927,14 +924,13 @@ int sfmba_residual_jacobian(sfmba_handle* h, const double* x, double* r_out, dou
     hipLaunchKernelGGL(k_unpack_jac, dim3((h->N + 255) / 256), dim3(256), 0, h->stream, h->J[h->jcur].as<double>(),
                        (int)h->N, h->ld, h->f32 ? 1 : 0, jc_rm.as<double>(), jp_rm.as<double>());
     HIPCHK(h, hipGetLastError());
-    std::vector<double> tr, tc(12 * h->N), tp(6 * h->N);
-    CHK(download_residuals(h, tr));
+    std::vector<double> tc(12 * h->N), tp(6 * h->N);
+    CHK(download_residuals(h, r_out));
     HIPCHK(h, hipMemcpyAsync(tc.data(), jc_rm.p, sizeof(double) * 12 * h->N, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(tp.data(), jp_rm.p, sizeof(double) * 6 * h->N, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     for (int64_t k = 0; k < h->N; ++k) {
         const int64_t d = h->permuted ? h->order[k] : k;
-        memcpy(r_out + 2 * d, tr.data() + 2 * k, sizeof(double) * 2);
         memcpy(Jc_out + 12 * d, tc.data() + 12 * k, sizeof(double) * 12);
         memcpy(Jp_out + 6 * d, tp.data() + 6 * k, sizeof(double) * 6);
     }
@@ -1323,18 +1319,12 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
 int sfmba_get_fun_grad(sfmba_handle* h, double* fun_out, double* grad_out) {
     CHK(enter(h));
     if (!h->have_problem || !h->solved) return fail(h, -1, "no completed sfmba_solve on this handle");
-    if (fun_out) {
-        std::vector<double> tmp;
-        CHK(download_residuals(h, tmp));
-        for (int64_t k = 0; k < h->N; ++k) {
-            const int64_t d = h->permuted ? h->order[k] : k;
-            fun_out[2 * d] = tmp[2 * k];
-            fun_out[2 * d + 1] = tmp[2 * k + 1];
-        }
-    }
+    if (fun_out) CHK(download_residuals(h, fun_out));
     if (grad_out) {
-        HIPCHK(h, hipMemcpyAsync(grad_out, h->g.p, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
+        CHK(ensure_h_x(h));
+        HIPCHK(h, hipMemcpyAsync(h->h_x, h->g.p, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->stream));
+        CHK(wait_stream(h));
+        memcpy(grad_out, h->h_x, sizeof(double) * h->n);
     }
     return 0;
 }
