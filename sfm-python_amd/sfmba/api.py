@@ -105,12 +105,16 @@ def project_points(points, camera_params, K, device=0):
 def least_squares(fun, x0, jac="2-point", bounds=(-np.inf, np.inf), method="trf", ftol=1e-8, xtol=1e-8,
                   gtol=1e-8, x_scale=1.0, loss="linear", f_scale=1.0, diff_step=None, tr_solver=None,
                   tr_options=None, jac_sparsity=None, max_nfev=None, verbose=0, args=(), kwargs=None,
-                  device=0, max_iter=None, pcg_tol=None, profile=False, return_jac=False, storage_bits=64):
+                  device=0, max_iter=None, pcg_tol=None, profile=False, return_jac=False, storage_bits=64,
+                  check_fun=True):
     """Drop-in for the reference's ``least_squares(compute_residuals, x0, jac_sparsity=..., verbose=...,
     x_scale='jac', ftol=tol, method='trf', args=(...))`` (sfm.py:266-268).
 
     ``fun`` must be the bundle-adjustment residual (the reference's ``compute_residuals`` or this
-    module's): it is not called -- the same model runs as a HIP kernel with an analytic Jacobian.
+    module's): the optimisation does not call it -- the same model runs as a HIP kernel with an analytic
+    Jacobian.  With ``check_fun=True`` (default) a foreign ``fun`` is evaluated once on the first few
+    observations and compared with the model this back end implements; a mismatch raises ``ValueError``
+    instead of silently optimising a different function.
     ``jac_sparsity`` is accepted and shape-checked; ``jac``, ``diff_step``, ``tr_solver``,
     ``tr_options`` are accepted and ignored (the Jacobian is analytic, the trust-region step comes
     from the Schur-complement PCG).  Unsupported: bounds, robust losses, methods other than 'trf',
@@ -145,6 +149,9 @@ def least_squares(fun, x0, jac="2-point", bounds=(-np.inf, np.inf), method="trf"
     if jac_sparsity is not None and tuple(jac_sparsity.shape) != (2 * n_obs, n):
         raise ValueError("`jac_sparsity` has wrong shape.")          # least_squares.py:160-161
 
+    if check_fun and fun is not compute_residuals:
+        _check_fun(fun, x0, int(n_cameras), int(n_points), camera_indices, point_indices, points_2d, K)
+
     be = get_backend(device)
     be.set_precision(storage_bits)
     be.set_problem(n_cameras, n_points, camera_indices, point_indices, points_2d, K)
@@ -163,6 +170,33 @@ def least_squares(fun, x0, jac="2-point", bounds=(-np.inf, np.inf), method="trf"
     if return_jac:
         out.jac = _jacobian_csr(be, x, int(n_cameras), int(n_points), camera_indices, point_indices)
     return out
+
+
+def _check_fun(fun, x0, n_cameras, n_points, camera_indices, point_indices, points_2d, K, k=6):
+    """Argument validation, not a compute path: does ``fun`` implement pi(K R(w)(X - T)) - uv?  Evaluated
+    on the first k observations only (the reference's function costs ~15 us per observation)."""
+    ci = np.asarray(camera_indices)[:k]
+    pi = np.asarray(point_indices)[:k]
+    uv = np.asarray(points_2d)[:k]
+    if len(ci) == 0 or not callable(fun):
+        raise ValueError("`fun` must be callable and the problem must have observations")
+    try:
+        got = np.asarray(fun(x0, n_cameras, n_points, ci, pi, uv, K), dtype=np.float64).ravel()
+    except Exception as exc:                                   # noqa: BLE001
+        raise ValueError(f"`fun` could not be evaluated with the bundle-adjustment arguments: {exc}") from exc
+    Kf = np.asarray(K, dtype=np.float64)
+    cams = x0[:6 * n_cameras].reshape(n_cameras, 6)
+    pts = x0[6 * n_cameras:].reshape(n_points, 3)
+    want = np.empty((len(ci), 2))
+    for j, (c, p) in enumerate(zip(ci, pi)):
+        q = Kf @ (_matrix_from_rotvec(cams[c, :3]) @ (pts[p] - cams[c, 3:]))
+        want[j] = q[:2] / q[2] - uv[j]
+    want = want.ravel()
+    if got.shape != want.shape or not np.allclose(got, want, rtol=1e-6, atol=1e-6 * max(1.0, np.abs(want).max()),
+                                                  equal_nan=True):
+        raise ValueError("`fun` does not compute the bundle-adjustment residual pi(K R(w)(X - T)) - uv that "
+                         "sfmba.least_squares optimises (sfm_lite/bundle_adjustment.py:35-42); pass "
+                         "check_fun=False to skip this check")
 
 
 def _jacobian_csr(be, x, n_cameras, n_points, camera_indices, point_indices):

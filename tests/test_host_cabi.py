@@ -96,6 +96,22 @@ def test_least_squares_argument_validation():
         sfmba.least_squares(f, pb.x0, method="trf", x_scale="jac", args=pb.args, bounds=(0, 1))
 
 
+def test_fun_is_checked_against_the_model():
+    """A foreign `fun` is compared with the model on a few observations before anything is optimised."""
+    import sfmba
+    from sfmba import api
+    from oracle import ba_oracle as orc
+    pb = sfmba.make_problem(3, 8, 20, seed=0)
+    api._check_fun(orc.compute_residuals, pb.x0, *pb.args)                  # the right model passes
+    api._check_fun(orc.compute_residuals_loop, pb.x0, *pb.args)
+    with pytest.raises(ValueError, match="does not compute"):
+        api._check_fun(lambda x, *a: orc.compute_residuals(x, *a) * 2.0, pb.x0, *pb.args)
+    with pytest.raises(ValueError, match="could not be evaluated"):
+        api._check_fun(lambda x: x, pb.x0, *pb.args)
+    with pytest.raises(ValueError, match="does not compute"):            # checked before the GPU is touched
+        sfmba.least_squares(lambda x, *a: np.zeros(12), pb.x0, x_scale="jac", method="trf", args=pb.args)
+
+
 def test_create_sparsity_matrix_matches_reference_capture():
     import sfmba
     g = np.load(os.path.join(GOLDEN, "sparsity_cases.npz"))
