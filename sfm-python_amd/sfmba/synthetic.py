@@ -129,3 +129,49 @@ def drop_observations(pb: BAProblem, cameras=(), points=()) -> BAProblem:
            ~np.isin(pb.point_indices, np.asarray(list(points), dtype=np.int64))
     return BAProblem(pb.n_cameras, pb.n_points, pb.camera_indices[keep], pb.point_indices[keep],
                      pb.points_2d[keep], pb.K, pb.x0, pb.x_true)
+
+
+def _rotvec_from_matrix(R: np.ndarray) -> np.ndarray:
+    """Log map for generic rotations (angle away from 0 and pi handled; used by the ring scene only)."""
+    tr = np.clip((np.trace(R) - 1.0) / 2.0, -1.0, 1.0)
+    th = np.arccos(tr)
+    if th < 1e-12:
+        return np.zeros(3)
+    ax = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    if np.pi - th < 1e-6:                      # near pi: take the axis from the symmetric part
+        A = (R + np.eye(3)) / 2.0
+        k = int(np.argmax(np.diag(A)))
+        v = A[:, k] / np.sqrt(A[k, k])
+        return th * v * (1.0 if ax @ v >= 0 else -1.0)
+    return th * ax / (2.0 * np.sin(th))
+
+
+def make_ring_problem(n_cameras: int, n_points: int, n_obs: int, seed: int = 0, radius: float = 8.0,
+                      pixel_noise: float = 0.5, x0_noise: float = 0.01) -> BAProblem:
+    """Cameras on a circle around the point cloud, all looking at its centre: rotation vectors of every
+    magnitude up to pi (the first camera sits at exactly 180 degrees), depths from radius-3 to radius+3.
+    Same layout conventions as :func:`make_problem`."""
+    rng = np.random.default_rng(seed)
+    K = K_SCEAUX.copy()
+    ang = np.pi + 2.0 * np.pi * np.arange(n_cameras) / n_cameras
+    cam_T = np.stack([radius * np.sin(ang), 0.3 * rng.normal(size=n_cameras), -radius * np.cos(ang)], axis=1)
+    cam_w = np.empty((n_cameras, 3))
+    for c in range(n_cameras):
+        z = -cam_T[c] / np.linalg.norm(cam_T[c])            # optical axis towards the origin
+        x = np.cross([0.0, 1.0, 0.0], z)
+        x /= np.linalg.norm(x)
+        y = np.cross(z, x)
+        cam_w[c] = _rotvec_from_matrix(np.stack([x, y, z]))  # rows: camera axes in world coordinates
+    pts = rng.normal(0.0, 1.0, (n_points, 3))
+    pt_idx = np.concatenate([np.arange(n_points, dtype=np.int64),
+                             rng.integers(0, n_points, n_obs - n_points, dtype=np.int64)])
+    cam_idx = rng.integers(0, n_cameras, n_obs, dtype=np.int64)
+    order = np.argsort(pt_idx, kind="stable")
+    pt_idx, cam_idx = pt_idx[order], cam_idx[order]
+    R = _rodrigues_batch(cam_w)
+    q = np.einsum("nij,nj->ni", R[cam_idx], pts[pt_idx] - cam_T[cam_idx])
+    p = q @ K.T
+    uv = np.trunc(p[:, :2] / p[:, 2:3] + rng.normal(0.0, pixel_noise, (n_obs, 2))).astype(np.int64)
+    x_true = np.concatenate([np.hstack([cam_w, cam_T]).ravel(), pts.ravel()])
+    x0 = x_true + rng.normal(0.0, x0_noise, x_true.shape)
+    return BAProblem(n_cameras, n_points, cam_idx, pt_idx, uv, K, x0, x_true)

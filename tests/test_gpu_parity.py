@@ -335,6 +335,23 @@ def test_unobserved_camera_and_point(orc):
     assert np.abs(res.jac.T @ res.fun - res.grad).max() <= 1e-9 * max(1.0, np.abs(res.grad).max())
 
 
+def test_ring_scene_large_rotations(orc):
+    """Rotation vectors of every magnitude up to pi inside the solver (not only in K1): against scipy's
+    recorded result and the oracle."""
+    import sfmba
+    from sfmba.synthetic import make_ring_problem
+    g = np.load(os.path.join(GOLDEN, "lsq_tiny_cases.npz"))
+    pb = make_ring_problem(12, 150, 900, seed=1)
+    status, nfev, njev, cost, rmse, opt = g["ring_summary"]
+    res = sfmba.least_squares(sfmba.compute_residuals, pb.x0, x_scale="jac", ftol=1e-10, method="trf",
+                              args=pb.args)
+    o = orc.trf_schur(pb.x0, *pb.args, ftol=1e-10, linear="pcg", pcg_tol=1e-3)
+    assert res.success and abs(res.rmse - rmse) < 1e-6 and res.cost <= cost * (1 + 1e-9)
+    assert (res.status, res.nfev, res.njev) == (o.status, o.nfev, o.njev)
+    assert abs(res.cost - o.cost) <= 1e-9 * o.cost
+    assert np.abs(res.fun - g["ring_fun"]).max() < 5e-2
+
+
 def test_error_behaviour(be):
     import sfmba
     pb = sfmba.make_problem(3, 8, 20, seed=0)

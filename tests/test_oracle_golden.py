@@ -120,6 +120,18 @@ def test_unobserved_camera_and_point_match_scipy():
         assert np.array_equal(res.x[sl], pb.x0[sl]) and np.array_equal(g["gaps_x"][sl], pb.x0[sl])
 
 
+def test_ring_scene_large_rotations_match_scipy():
+    """Cameras on a ring (rotation vectors up to pi) inside a full solve, against scipy's result."""
+    from sfmba.synthetic import make_ring_problem
+    g = np.load(os.path.join(GOLDEN, "lsq_tiny_cases.npz"))
+    pb = make_ring_problem(12, 150, 900, seed=1)
+    assert np.array_equal(pb.x0, g["ring_x0"])
+    status, nfev, njev, cost, rmse, opt = g["ring_summary"]
+    res = orc.trf_schur(pb.x0, *pb.args, ftol=1e-10, linear="pcg", pcg_tol=1e-3)
+    assert abs(float(np.sqrt(np.mean(res.fun ** 2))) - rmse) < 1e-6 and res.cost <= cost * (1 + 1e-9)
+    assert np.abs(res.fun - g["ring_fun"]).max() < 5e-2
+
+
 def test_trf_schur_cfg2_matches_recorded_scipy_run():
     path = os.path.join(GOLDEN, "scipy_cfg2_run.json")
     if not os.path.exists(path):

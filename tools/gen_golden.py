@@ -29,7 +29,7 @@ from scipy.spatial.transform import Rotation as Rot
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "sfm-python_amd"))
-from sfmba.synthetic import drop_observations, make_problem  # noqa: E402
+from sfmba.synthetic import drop_observations, make_problem, make_ring_problem  # noqa: E402
 
 REF_BA = "/root/reference/sfm_lite/bundle_adjustment.py"
 OUT = os.path.join(ROOT, "tests", "golden")
@@ -164,6 +164,15 @@ def lsq_tiny(ba):
     out["gaps_summary"] = np.array([res.status, res.nfev, res.njev, res.cost,
                                     np.sqrt(np.mean(res.fun ** 2)), res.optimality])
     print(f"  lsq gaps 5/40/{pb.n_obs}: status {res.status} nfev {res.nfev} cost {res.cost:.6f}")
+    # cameras on a ring looking inward: rotation vectors up to pi inside a full solve
+    pb = make_ring_problem(12, 150, 900, seed=1)
+    S = ba.create_sparsity_matrix(12, 150, 900, pb.camera_indices, pb.point_indices)
+    res = least_squares(ba.compute_residuals, pb.x0, jac_sparsity=S, verbose=0, x_scale="jac",
+                        ftol=1e-10, method="trf", args=pb.args)
+    out["ring_x0"], out["ring_x"], out["ring_fun"] = pb.x0, res.x, res.fun
+    out["ring_summary"] = np.array([res.status, res.nfev, res.njev, res.cost,
+                                    np.sqrt(np.mean(res.fun ** 2)), res.optimality])
+    print(f"  lsq ring 12/150/900: status {res.status} nfev {res.nfev} cost {res.cost:.6f}")
     out["n_cases"] = np.array(3)
     return out
 
