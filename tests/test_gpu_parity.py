@@ -514,3 +514,70 @@ def test_exchange_path_world1_nccl():
         be2.close()
     finally:
         td.destroy_process_group()
+
+
+# ---- a REAL two-rank run of the C++ solver: both ranks share the one GPU, collectives over gloo ------------
+
+def _two_rank_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as td
+    import sfmba
+    from sfmba import dist as sdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pb = sfmba.make_problem(11, 3000, 10000, seed=0)
+        shards = sdist.partition_points(pb.point_indices, pb.n_points, world)
+        loc = sdist.shard_problem(pb, shards[rank])
+        be = sfmba.Backend(0)
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            be.set_stream(stream.cuda_stream)
+            be.set_problem(*loc.args)
+            ex = sdist.Exchange(be, n_obs_local=loc.n_obs, device="cuda")     # gloo all-reduces CUDA tensors
+            opt = be.default_options()
+            opt.ftol = 1e-10
+            x, res, fun, grad = be.solve(loc.x0, opt)
+            torch.cuda.synchronize()
+        xs = [None] * world
+        td.all_gather_object(xs, x)
+        if rank == 0:
+            q.put(dict(x=sdist.merge_solutions(xs, shards, pb.n_cameras, pb.n_points),
+                       cams_equal=all(np.array_equal(xi[:66], xs[0][:66]) for xi in xs),
+                       status=int(res.status), nfev=int(res.nfev), cost=float(res.cost), rmse=float(res.rmse),
+                       calls=ex.n_calls))
+        be.close()
+    finally:
+        td.destroy_process_group()
+
+
+def test_two_rank_solve_on_one_gpu_gloo():
+    """The production solver, observation-sharded over TWO processes that share the single GPU, with the
+    callback transport over gloo: replicated cameras bitwise identical on both ranks, merged solution and
+    cost equal to the single-process solve (and scipy's RMSE to 1e-6)."""
+    import socket
+    import torch.multiprocessing as mp
+    import sfmba
+    rec = json.load(open(os.path.join(GOLDEN, "scipy_cfg2_run.json")))
+    pb = sfmba.make_problem(11, 3000, 10000, seed=0)
+    ref = sfmba.least_squares(sfmba.compute_residuals, pb.x0, x_scale="jac", ftol=1e-10, method="trf",
+                              args=pb.args)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    assert out["cams_equal"] and out["calls"] > 20
+    assert (out["status"], out["nfev"]) == (ref.status, ref.nfev)
+    assert abs(out["cost"] - ref.cost) <= 1e-10 * ref.cost
+    assert abs(out["rmse"] - rec["rmse"]) < 1e-6
+    assert np.abs(out["x"] - ref.x).max() <= 1e-6 * np.abs(ref.x).max()
