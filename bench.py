@@ -97,6 +97,9 @@ def main():
     ap.add_argument("--storage-bits", type=int, default=64, choices=[64, 32],
                     help="64: fp64 streams (configs 2-4); 32: fp32 storage of pixels/residuals/Jacobian with fp64 "
                          "arithmetic and accumulation (config 5)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend (gloo + --exchange torch + --one-device rehearses N>1 on one GPU)")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--exchange", default="native", choices=["native", "torch"],
                     help="native: RCCL called from C++ on the solver stream; torch: torch.distributed callback")
     a = ap.parse_args()
@@ -113,6 +116,8 @@ def main():
     import sfmba
     from sfmba import dist as sdist
 
+    if a.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     C, P, N = sfmba.synthetic.CONFIGS[a.workload]
     stream = torch.cuda.Stream()
@@ -121,7 +126,10 @@ def main():
         import torch.distributed as td
         if world == 1 and "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
-        td.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if a.dist_backend == "nccl":
+            td.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            td.init_process_group(backend="gloo")
         pb = sdist.make_sharded_problem(C, P, N, rank, world, seed=0) if world > 1 else sfmba.make_problem(C, P, N, seed=0)
     else:
         td = None
@@ -133,7 +141,15 @@ def main():
         be.set_problem(*pb.args)
         ex = None
         if td is not None:
-            ex = (sdist.NativeComm if a.exchange == "native" else sdist.Exchange)(be, n_obs_local=N)
+            if a.exchange == "native":
+                try:
+                    ex = sdist.NativeComm(be, n_obs_local=N)
+                except Exception as exc:                      # noqa: BLE001 -- e.g. librccl not loadable
+                    print(f"[bench] native RCCL transport unavailable ({exc}); using the torch.distributed "
+                          f"callback transport", file=sys.stderr, flush=True)
+                    a.exchange = "torch"
+            if a.exchange == "torch":
+                ex = sdist.Exchange(be, n_obs_local=N, device="cuda")
 
         opt = be.default_options()
         opt.ftol, opt.xtol, opt.gtol = 1e-10, 1e-8, 1e-8           # the reference's ftol, scipy defaults
@@ -197,6 +213,7 @@ def main():
             "ms_per_step": 1e3 * elapsed / steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64" if a.storage_bits == 64 else "f64 arithmetic, f32 storage", "data": "synthetic",
+            "transport": None if td is None else a.exchange,
             "config": {"workload": f"{a.workload}: {C} cameras / {P} points / {N} observations per GPU shard, "
                                    f"shared cameras, seed 0 (SURVEY.md 8d generator)",
                        "solver": "TRF (scipy trf_no_bounds restated) + analytic Jacobian + Schur PCG, ftol=1e-10",
