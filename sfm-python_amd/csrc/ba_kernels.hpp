@@ -22,6 +22,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "tr2d.hpp"
+
 namespace sfmba {
 
 constexpr int kCamTab = 17;          // doubles per camera-table row
@@ -187,14 +189,36 @@ __global__ void k_cam_table(const double* __restrict__ xc, int C, double* __rest
     cam_table_row(prm, tab + (size_t)c * kCamTab);
 }
 
+// The first trust-region step of an outer iteration, decided on the device so that the host does not
+// have to read the model's scalars back before the trial point can be evaluated: one thread builds
+// the 2-D model from the (rank-reduced) exchange scalars and solves it for the radius the host passed.
+// sc[25..31] = c1, c2, predicted reduction, |step_h|, |step|, skip flag, Delta used (slots 16..24 hold the
+// camera-slice sums).
+__global__ void k_tr_step(double* __restrict__ sc, double Delta, const PcgCtrl* __restrict__ ctrl) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // The step is only meaningful when the speculatively enqueued PCG iterations sufficed.  If they did
+    // not, raise the skip flag: every kernel of the trial evaluation behind this one returns at once,
+    // so J, r and the normal blocks of x stay intact and the host can finish the PCG and retry.
+    if (ctrl != nullptr && ctrl->done == 0) { sc[30] = 1.0; return; }
+    auto q = [&](int point_slot, int k) { return sc[point_slot] + sc[16 + k]; };   // points (reduced) + cameras
+    const TrModel m = tr_build_model(sc[1], sc[2], sc[3], q(8, 1), q(4, 5), q(5, 6), q(11, 4), q(6, 7), q(7, 8));
+    const TrStep st = tr_solve_step(m, Delta);
+    sc[25] = st.c1; sc[26] = st.c2; sc[27] = st.predicted; sc[28] = st.step_h_norm; sc[29] = st.step_norm;
+    sc[30] = 0.0; sc[31] = Delta;
+}
+
 // Trial point and its camera table in one launch: x_new = x + c1 (g / si^2) + c2 p (step = D step_h,
 // SCIPY trf.py:495-497).  Blocks [0, bc) take one camera per thread (six parameters, then the table
 // row of the NEW parameters); the remaining blocks stream the point coordinates.
 __global__ __launch_bounds__(256) void k_step_table(const double* __restrict__ x,
                                                     const double* __restrict__ sg,
                                                     const double* __restrict__ p, double c1, double c2,
+                                                    const double* __restrict__ coef,
                                                     int C, int64_t n, int bc, double* __restrict__ x_new,
-                                                    double* __restrict__ tab) {
+                                                    double* __restrict__ tab,
+                                                    const double* __restrict__ skip) {
+    if (skip != nullptr && *skip != 0.0) return;   // speculative launch cancelled by k_tr_step
+    if (coef != nullptr) { c1 = coef[0]; c2 = coef[1]; }       // coefficients decided by k_tr_step
     if ((int)blockIdx.x < bc) {
         const int c = blockIdx.x * blockDim.x + threadIdx.x;
         if (c >= C) return;
@@ -281,9 +305,10 @@ __global__ __launch_bounds__(kSweepThreads) void k_resjac(
     const double* __restrict__ camtab, const double* __restrict__ pts, const int* __restrict__ cam_idx,
     const int* __restrict__ pt_idx, const double* __restrict__ uv, double* __restrict__ r,
     double* __restrict__ J, int N, int64_t ld, int C, KMat K,
-    double* __restrict__ cost_part) {
+    double* __restrict__ cost_part, const double* __restrict__ skip) {
     extern __shared__ __align__(16) double smem[];
     __shared__ double red[kWavesPerSweepBlock];
+    if (skip != nullptr && *skip != 0.0) return;   // speculative launch cancelled by k_tr_step
 #if defined(SFMBA_K1_CHUNKED)            // experiment: one contiguous chunk of observations per workgroup
     const int stride = blockDim.x;
     const int chunk = (((N + (int)gridDim.x - 1) / (int)gridDim.x) + 63) & ~63;
@@ -449,7 +474,9 @@ __device__ __forceinline__ void load_jc(const ObsArrays& o, int i, double* jc) {
 //        U_c = sum Jc^T Jc (21), g_c = sum Jc^T r (6) by global fp64 atomics into Ugc[C][27].
 __global__ __launch_bounds__(kSweepThreads) void k_normal_blocks(
     const int2* __restrict__ ranges, int n_ranges, ObsArrays o, const double* __restrict__ r,
-    double* __restrict__ V, double* __restrict__ gp, double* __restrict__ Ugc) {
+    double* __restrict__ V, double* __restrict__ gp, double* __restrict__ Ugc,
+    const double* __restrict__ skip) {
+    if (skip != nullptr && *skip != 0.0) return;   // speculative launch cancelled by k_tr_step
     const int wg = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (wg >= n_ranges) return;
     const int lane = threadIdx.x & 63;
@@ -536,8 +563,9 @@ __global__ __launch_bounds__(kSweepThreads) void k_normal_blocks(
 __global__ __launch_bounds__(kSweepThreads) void k_normal_blocks_lds(
     const int2* __restrict__ ranges, int n_ranges, ObsArrays o, const double* __restrict__ r,
     double* __restrict__ V, double* __restrict__ gp, double* __restrict__ partial, int C, int col0,
-    int ncols, int do_points) {
+    int ncols, int do_points, const double* __restrict__ skip) {
     extern __shared__ __align__(16) double smem[];
+    if (skip != nullptr && *skip != 0.0) return;   // speculative launch cancelled by k_tr_step
     const int ntab = C * ncols;
     for (int i = threadIdx.x; i < ntab; i += blockDim.x) smem[i] = 0.0;
     __syncthreads();
@@ -645,8 +673,10 @@ __global__ __launch_bounds__(kSweepThreads) void k_normal_blocks_lds(
 // workgroup axis (independent loads in flight), combined through LDS in slice order.
 __global__ __launch_bounds__(1024) void k_reduce_tables(const double* __restrict__ partial, int nblocks,
                                                         int C, int col0, int ncols,
-                                                        double* __restrict__ Ugc) {
+                                                        double* __restrict__ Ugc,
+                                                        const double* __restrict__ skip) {
     __shared__ double sm[16][64];
+    if (skip != nullptr && *skip != 0.0) return;   // speculative launch cancelled by k_tr_step
     const int ntab = C * ncols;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + tx;
@@ -770,7 +800,8 @@ __global__ __launch_bounds__(256) void k_vec_reduce(const double* __restrict__ g
 // out[slot[y][k]] (slot < 0: not written).  Fixed lane->row mapping: deterministic.
 struct FinishJob { int row0[2], nrows[2], slot[2][kNQ]; };
 __global__ void k_finish(const double* __restrict__ part, FinishJob job, int nq, int first_sum,
-                         double* __restrict__ out) {
+                         double* __restrict__ out, const double* __restrict__ skip) {
+    if (skip != nullptr && *skip != 0.0) return;   // speculative launch cancelled by k_tr_step
     const int y = blockIdx.x;
     const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (k >= nq) return;
@@ -1481,7 +1512,8 @@ __global__ __launch_bounds__(1024) void k_fill16(double* __restrict__ a, int64_t
         *reinterpret_cast<double2*>(a + 2 * e) = make_double2(v, v + 1.0);
 }
 
-__global__ void k_fill(double* __restrict__ a, int64_t n, double v) {
+__global__ void k_fill(double* __restrict__ a, int64_t n, double v, const double* __restrict__ skip) {
+    if (skip != nullptr && *skip != 0.0) return;   // speculative launch cancelled by k_tr_step
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n;
          e += (int64_t)gridDim.x * blockDim.x)
         a[e] = v;

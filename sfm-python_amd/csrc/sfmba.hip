@@ -136,6 +136,8 @@ struct sfmba_handle {
     double* h_x = nullptr;                   // pinned staging of the parameter vector
     size_t h_x_doubles = 0;
     hipEvent_t ev_handoff = nullptr;
+    const double* skip = nullptr;         // device flag gating speculative trial launches (sfmba_solve); else null
+    int pcg_hint = 0;                     // largest PCG iteration count a solve on this handle has needed
     bool solved = false;
     std::vector<const void*> lds_ready;      // kernels already opted in to 160 KiB dynamic LDS
     int last_pcg_iters = 0;
@@ -280,12 +282,12 @@ int launch_resjac_v(sfmba_handle* h, const double* x, const double* tab, int js,
         hipExtLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), (uint32_t)lds, h->stream, ev0, ev1, 0u, tab, pts,
                               (const int*)h->cam_idx.as<int>(), (const int*)h->pt_idx.as<int>(),
                               (const double*)h->uv.as<double>(), h->r[js].as<double>(), h->J[js].as<double>(),
-                              (int)h->N, h->ld, (int)h->C, h->K, h->part.as<double>());
+                              (int)h->N, h->ld, (int)h->C, h->K, h->part.as<double>(), h->skip);
     } else {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), lds, h->stream, tab, pts,
                            h->cam_idx.as<int>(), h->pt_idx.as<int>(), h->uv.as<double>(),
                            h->r[js].as<double>(), h->J[js].as<double>(), (int)h->N,
-                           h->ld, (int)h->C, h->K, h->part.as<double>());
+                           h->ld, (int)h->C, h->K, h->part.as<double>(), h->skip);
     }
     HIPCHK(h, hipGetLastError());
     return 0;
@@ -309,7 +311,7 @@ int launch_finish(sfmba_handle* h, const double* part, int nparts, int nq, int s
     FinishJob job{};
     job.row0[0] = 0; job.nrows[0] = nparts;
     for (int k = 0; k < kNQ; ++k) job.slot[0][k] = slot + k;
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64 * nq), 0, h->stream, part, job, nq, 0, h->scal());
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64 * nq), 0, h->stream, part, job, nq, 0, h->scal(), h->skip);
     HIPCHK(h, hipGetLastError());
     return 0;
 }
@@ -324,7 +326,8 @@ int launch_finish_slices(sfmba_handle* h, int q_lo, int q_hi) {
         job.slot[0][k] = kCamSlot + k;
         job.slot[1][k] = (k >= q_lo && k <= q_hi) ? kPointSlot[k] : -1;
     }
-    hipLaunchKernelGGL(k_finish, dim3(2), dim3(64 * kNQ), 0, h->stream, h->part.as<double>(), job, kNQ, 1, h->scal());
+    hipLaunchKernelGGL(k_finish, dim3(2), dim3(64 * kNQ), 0, h->stream, h->part.as<double>(), job, kNQ, 1, h->scal(),
+                       (const double*)nullptr);
     HIPCHK(h, hipGetLastError());
     return 0;
 }
@@ -341,19 +344,21 @@ int launch_normal_blocks(sfmba_handle* h) {
             hipLaunchKernelGGL(k_normal_blocks_lds, dim3(grid), dim3(kSweepThreads), lds, h->stream,
                                h->ranges.as<int2>(), h->n_ranges, obs_arrays(h), h->r[h->jcur].as<double>(),
                                h->V.as<double>(), h->gp.as<double>(), h->tables.as<double>(), (int)h->C,
-                               col0, ncols, ps == 0 ? 1 : 0);
+                               col0, ncols, ps == 0 ? 1 : 0, h->skip);
             HIPCHK(h, hipGetLastError());
             const int ntab = (int)h->C * ncols;
             hipLaunchKernelGGL(k_reduce_tables, dim3((ntab + 63) / 64), dim3(1024), 0, h->stream,
-                               h->tables.as<double>(), grid, (int)h->C, col0, ncols, h->Ugc());
+                               h->tables.as<double>(), grid, (int)h->C, col0, ncols, h->Ugc(), h->skip);
             HIPCHK(h, hipGetLastError());
         }
         return 0;
     }
-    HIPCHK(h, hipMemsetAsync(h->Ugc(), 0, sizeof(double) * 27 * h->C, h->stream));
+    hipLaunchKernelGGL(k_fill, dim3(grid_1d(27 * h->C, 256, 2048)), dim3(256), 0, h->stream, h->Ugc(),
+                       (int64_t)(27 * h->C), 0.0, h->skip);
+    HIPCHK(h, hipGetLastError());
     hipLaunchKernelGGL(k_normal_blocks, dim3(grid), dim3(kSweepThreads), 0, h->stream,
                        h->ranges.as<int2>(), h->n_ranges, obs_arrays(h), h->r[h->jcur].as<double>(),
-                       h->V.as<double>(), h->gp.as<double>(), h->Ugc());
+                       h->V.as<double>(), h->gp.as<double>(), h->Ugc(), h->skip);
     HIPCHK(h, hipGetLastError());
     return 0;
 }
@@ -1111,19 +1116,20 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
     int status = -1;
     double step_norm = 0.0, actual_reduction = 0.0, g_norm = 0.0, reg_term = 0.0;
     bool have_red = false;
-    int pcg_guess = 0;                                          // iterations the previous solve needed
+    int pcg_guess = h->pcg_hint;                                // iterations to enqueue without reading back
     int64_t pcg_breakdowns = 0;
     bool nb_valid = true;                                       // V, g_p, [U|g_c] (and, single-buffered, J and r) belong to h->x
     // Single-buffered Jacobian: the trial point is evaluated into the SAME J / r buffers the sweeps of
     // this iteration have just read, so K1's stores land on lines that are still resident in the
     // Infinity Cache instead of cold ones.  A rejected step leaves J / r describing the rejected point;
-    // nothing uses them before the next trial overwrites them, except the two rare exits handled below.
-    static const bool single_buffer = std::getenv("SFMBA_DOUBLE_BUFFER") == nullptr;
+    // nothing uses them before the next trial overwrites them, except the rare exits handled below.
+    const bool pcg_debug = std::getenv("SFMBA_DEBUG_PCG") != nullptr;
+    const int pcg_bias = std::getenv("SFMBA_PCG_GUESS_BIAS") ? std::atoi(std::getenv("SFMBA_PCG_GUESS_BIAS")) : 0;   // test hook
     if (opt.verbose >= 2) print_header();
 
     for (;;) {                                                  // trf.py:450
         if (!nb_valid) {                                        // a rejected trial overwrote the blocks and no
-            if (single_buffer) CHK(eval_jac(h->x, h->tab, h->jcur, true));   // step was accepted afterwards
+            CHK(eval_jac(h->x, h->tab, h->jcur, true));         // step was accepted afterwards
             CHK(launch_normal_blocks(h));                       // (nfev limit)
             CHK(exchange(h, h->Ugc(), 27 * C, 0));
             nb_valid = true;
@@ -1146,7 +1152,7 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
         CHK(pcg_start(h, opt));                                 // replaces lsmr, trf.py:477-480
         PcgCtrl hc{};
         if (pcg_guess > 0) {
-            CHK(pcg_enqueue(h, pcg_guess + 1));                 // speculative: no read-back (the count rarely grows)
+            CHK(pcg_enqueue(h, pcg_guess + 1));                 // speculative: no read-back; surplus launches are no-ops
         } else {
             CHK(pcg_finish_polling(h, opt, &hc));
         }
@@ -1158,18 +1164,57 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
             return 0;
         };
         CHK(tail());
-        if (pcg_guess > 0) {
-            HIPCHK(h, hipMemcpyAsync(h->h_scal + 40, h->ctrl.as<PcgCtrl>() + (h->pcg_L & 1), sizeof hc,
-                                     hipMemcpyDeviceToHost, h->stream));
-            CHK(fetch_scalars(h));                              // hand-off 1
-            memcpy(&hc, h->h_scal + 40, sizeof hc);
-            if (hc.done == 0) {                                 // guess too small: finish and redo the tail
-                CHK(pcg_finish_polling(h, opt, &hc));
-                CHK(tail());
-                CHK(fetch_scalars(h));
-            }
-        } else {
+
+        // ---- the first trial step is decided ON THE DEVICE (k_tr_step) and evaluated right away -------
+        // so that an outer iteration hands control to the host ONCE, after the trial cost is known.
+        auto enqueue_trial = [&](const double* coef_dev, double c1, double c2) -> int {
+            const int bc = (int)((C + 255) / 256);
+            hipLaunchKernelGGL(k_step_table, dim3(bc + grid_1d(3 * P, 256, 2048)), dim3(256), 0, h->stream, h->x,
+                               h->sg.as<double>(), h->p.as<double>(), c1, c2, coef_dev, (int)C, n, bc, h->x_new,
+                               h->tab_new, h->skip);
+            HIPCHK(h, hipGetLastError());
+            // the trial point is evaluated WITH its Jacobian, into the same buffers: when
+            // the step is accepted (the common case) nothing has to be recomputed
+            CHK(eval_jac(h->x_new, h->tab_new, h->jcur, true));
+            CHK(exchange(h, sc, 1, 0));
+            return 0;
+        };
+        auto handoff = [&](bool with_ctrl) -> int {
+            if (with_ctrl)
+                HIPCHK(h, hipMemcpyAsync(h->h_scal + 40, h->ctrl.as<PcgCtrl>() + (h->pcg_L & 1), sizeof hc,
+                                         hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipMemcpyAsync(h->h_scal, sc, sizeof(double) * kScalSlots, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipEventRecord(h->ev_handoff, h->stream));
+            // While the host waits, the GPU already builds the normal-equation blocks of the trial point
+            // (speculating on acceptance, the common case).  They overwrite V / g_p / [U|g_c], which a
+            // rejected step does not need: a retry only re-solves the 2-D model (host scalars) and
+            // re-applies k_step_table to x, D^2 g and p, all untouched.
+            CHK(launch_normal_blocks(h));
+            CHK(exchange(h, h->Ugc(), 27 * C, 0));
+            nb_valid = false;
+            CHK(wait_event(h, h->ev_handoff));
+            if (with_ctrl) memcpy(&hc, h->h_scal + 40, sizeof hc);
+            return 0;
+        };
+        const bool speculative = pcg_guess > 0;
+        hipLaunchKernelGGL(k_tr_step, dim3(1), dim3(64), 0, h->stream, sc, Delta,
+                           speculative ? (const PcgCtrl*)(h->ctrl.as<PcgCtrl>() + (h->pcg_L & 1)) : (const PcgCtrl*)nullptr);
+        HIPCHK(h, hipGetLastError());
+        h->skip = sc + 30;                                      // k_tr_step's verdict gates every launch below
+        int rc_trial = enqueue_trial(sc + 25, 0.0, 0.0);
+        if (rc_trial == 0) rc_trial = handoff(speculative);     // THE hand-off of this iteration
+        h->skip = nullptr;
+        CHK(rc_trial);
+        bool first_trial_ready = true;
+        if (speculative && hc.done == 0) {
+            // The PCG needed more iterations than were enqueued.  k_tr_step saw that on the device and
+            // cancelled the trial launches, so J, r and the normal blocks still describe x: finish the
+            // PCG (host-polled), redo the tail and take the host-driven path below.
+            nb_valid = true;
+            CHK(pcg_finish_polling(h, opt, &hc));
+            CHK(tail());
             CHK(fetch_scalars(h));
+            first_trial_ready = false;
         }
         // hc.done == 3: the CG recurrences lost positive definiteness (rounding, typically on a converged
         // system whose right-hand side is noise).  The iterate of the last good step is kept -- it is
@@ -1183,77 +1228,43 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
         if (opt.verbose >= 2) print_iter(iteration, nfev, cost, have_red, actual_reduction, step_norm, g_norm);
         if (status != -1 || nfev >= max_nfev || (opt.max_iter > 0 && iteration >= opt.max_iter)) break;
         pcg_total += hc.iters;
-        pcg_guess = hc.iters;
+        if (pcg_debug)
+            fprintf(stderr, "sfmba: iteration %lld: PCG enqueued %d, needed %d%s\n", (long long)iteration,
+                    speculative ? pcg_guess + 1 : 0, hc.iters, speculative && !first_trial_ready ? " (miss)" : "");
+        // Next guess: the largest recent count, forgotten by one iteration per outer iteration.  A surplus
+        // iteration costs two empty launches (~10 us); a miss costs a hand-off per polled batch.
+        h->pcg_hint = std::max(hc.iters, h->pcg_hint - 1);
+        pcg_guess = std::max(1, h->pcg_hint + pcg_bias);
         reg_term = h->h_scal[kRegSlot];
 
-        const double a11 = qsum(h, 1);                          // |g_h|^2
         const double x_norm = std::sqrt(qsum(h, 3));
-        const double b11 = qsum(h, 4);                          // |D^2 g|^2
-        const double G11 = h->h_scal[1], G12 = h->h_scal[2], G22 = h->h_scal[3];
-        const double a12 = qsum(h, 5), a22 = qsum(h, 6), b12 = qsum(h, 7), b22 = qsum(h, 8);
-        // 2-D subspace span(g_h, gn_h), orthonormalised by Gram-Schmidt (trf.py:481-485)
-        const double s11 = std::sqrt(a11);
-        const double r12 = a12 / s11;
-        const double r22sq = a22 - r12 * r12;
-        const bool two_d = r22sq > 1e-28 * a22 && r22sq > 0.0;
-        const double r22 = two_d ? std::sqrt(r22sq) : 1.0;
-        double B[3], gS[2] = {s11, 0.0};
-        B[0] = G11 / a11;
-        if (two_d) {
-            B[1] = (G12 / s11 - r12 * G11 / a11) / r22;
-            B[2] = (G22 - 2.0 * r12 * G12 / s11 + r12 * r12 * G11 / a11) / (r22 * r22);
-        } else {                                                // gn_h parallel to g_h: 1-D model
-            B[1] = 0.0; B[2] = 1.0;
-        }
+        const TrModel model = tr_build_model(h->h_scal[1], h->h_scal[2], h->h_scal[3], qsum(h, 1), qsum(h, 5),
+                                             qsum(h, 6), qsum(h, 4), qsum(h, 7), qsum(h, 8));
 
         actual_reduction = -1.0;
         double cost_new = cost;
-        const int jalt = single_buffer ? h->jcur : (h->jcur ^ 1);
         while (actual_reduction <= 0.0 && nfev < max_nfev) {    // trf.py:488
-            double pS[2];
-            solve_trust_region_2d(B, gS, Delta, pS);
-            if (!two_d) pS[1] = 0.0;
-            const double predicted = -(0.5 * (B[0] * pS[0] * pS[0] + 2.0 * B[1] * pS[0] * pS[1] + B[2] * pS[1] * pS[1]) +
-                                       gS[0] * pS[0] + gS[1] * pS[1]);
-            // step_h = c1 g_h + c2 gn_h ; step = D step_h = c1 D^2 g + c2 p
-            const double c2 = two_d ? pS[1] / r22 : 0.0;
-            const double c1 = (pS[0] - (two_d ? pS[1] * r12 / r22 : 0.0)) / s11;
-            const double step_h_norm = std::sqrt(pS[0] * pS[0] + pS[1] * pS[1]);
-            {
-                const int bc = (int)((C + 255) / 256);
-                hipLaunchKernelGGL(k_step_table, dim3(bc + grid_1d(3 * P, 256, 2048)), dim3(256), 0, h->stream, h->x,
-                                   h->sg.as<double>(), h->p.as<double>(), c1, c2, (int)C, n, bc, h->x_new, h->tab_new);
-                HIPCHK(h, hipGetLastError());
+            TrStep st;
+            if (first_trial_ready) {                            // decided and evaluated on the device above
+                st.c1 = h->h_scal[25]; st.c2 = h->h_scal[26]; st.predicted = h->h_scal[27];
+                st.step_h_norm = h->h_scal[28]; st.step_norm = h->h_scal[29];
+                first_trial_ready = false;
+            } else {                                            // retry after a rejected step (or fallback)
+                st = tr_solve_step(model, Delta);
+                CHK(enqueue_trial(nullptr, st.c1, st.c2));
+                CHK(handoff(false));
             }
-            // the trial point is evaluated WITH its Jacobian into the spare buffer set: when the step is
-            // accepted (the common case) nothing has to be recomputed
-            CHK(eval_jac(h->x_new, h->tab_new, jalt, true));
-            CHK(exchange(h, sc, 1, 0));
-            HIPCHK(h, hipMemcpyAsync(h->h_scal, sc, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(h, hipEventRecord(h->ev_handoff, h->stream));
-            // While the host waits for the trial cost, the GPU already builds the normal-equation
-            // blocks of the trial point (speculating on acceptance, the common case).  They overwrite
-            // V / g_p / [U|g_c], which a rejected step does not need: a retry only re-solves the 2-D
-            // model (host scalars) and re-applies k_step_table to x, D^2 g and p, all untouched.
-            const int jkeep = h->jcur;
-            h->jcur = jalt;
-            const int rc_nb = launch_normal_blocks(h);
-            const int rc_ex = rc_nb == 0 ? exchange(h, h->Ugc(), 27 * C, 0) : rc_nb;
-            h->jcur = jkeep;
-            CHK(rc_ex);
-            nb_valid = false;
-            CHK(wait_event(h, h->ev_handoff));                  // hand-off 2
             ++nfev;
             cost_new = 0.5 * h->h_scal[0];
             if (!std::isfinite(cost_new)) {                     // trf.py:504-506
-                Delta = 0.25 * step_h_norm;
+                Delta = 0.25 * st.step_h_norm;
                 continue;
             }
             actual_reduction = cost - cost_new;
             double ratio;
-            const double Delta_new = update_tr_radius(Delta, actual_reduction, predicted, step_h_norm,
-                                                      step_h_norm > 0.95 * Delta, &ratio);
-            step_norm = std::sqrt(std::max(0.0, c1 * c1 * b11 + 2.0 * c1 * c2 * b12 + c2 * c2 * b22));
+            const double Delta_new = update_tr_radius(Delta, actual_reduction, st.predicted, st.step_h_norm,
+                                                      st.step_h_norm > 0.95 * Delta, &ratio);
+            step_norm = st.step_norm;
             const int term = check_termination(actual_reduction, cost, step_norm, x_norm, ratio, opt.ftol, opt.xtol);
             if (term != 0) { status = term; break; }
             Delta = Delta_new;
@@ -1262,8 +1273,8 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
         if (actual_reduction > 0.0) {                           // trf.py:528
             std::swap(h->x, h->x_new);
             std::swap(h->tab, h->tab_new);
-            h->jcur = jalt;                                     // J, f and the normal blocks of the accepted
-            nb_valid = true;                                    // point are already there / in flight
+            nb_valid = true;                                    // J, f and the normal blocks of the accepted
+                                                                // point are already there / in flight
             cost = cost_new;
             ++njev;
             CHK(launch_update_scale(h, 0));                     // enqueued only; read with the next hand-off
@@ -1281,7 +1292,7 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
         }
     }
     if (status == -1) status = 0;
-    if (single_buffer && !nb_valid) {                           // last trial was rejected: result.fun is f(x)
+    if (!nb_valid) {                                            // last trial was not accepted: result.fun is f(x)
         int np = 0;
         CHK((launch_resjac<false, true>(h, h->x, h->tab, h->jcur, &np)));
     }
