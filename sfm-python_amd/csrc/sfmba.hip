@@ -1211,6 +1211,11 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
             // cancelled the trial launches, so J, r and the normal blocks still describe x: finish the
             // PCG (host-polled), redo the tail and take the host-driven path below.
             nb_valid = true;
+            if (opt.profile && !evs.empty()) {                  // the cancelled launch is not a K1 timing sample
+                (void)hipEventDestroy(evs.back().first);
+                (void)hipEventDestroy(evs.back().second);
+                evs.pop_back();
+            }
             CHK(pcg_finish_polling(h, opt, &hc));
             CHK(tail());
             CHK(fetch_scalars(h));

@@ -305,6 +305,27 @@ def test_rejected_steps_and_nfev_limit_follow_the_oracle(orc):
         assert np.abs(r - res.fun).max() < 1e-8            # result.fun belongs to result.x
 
 
+def test_speculative_pcg_miss_changes_nothing(monkeypatch):
+    """The PCG iterations of an outer iteration are enqueued from a guess, with the first trial step
+    decided on the device behind them.  When the guess is too small the device cancels the trial and
+    the host finishes the PCG by polling: the outcome must be the one of a run whose guesses sufficed.
+    (SFMBA_PCG_GUESS_BIAS shifts the guess; -5 makes every speculative batch fall short.)"""
+    import sfmba
+    for pb in (sfmba.make_config("cfg2"), sfmba.make_problem(6, 80, 500, seed=5, x0_noise=0.2)):
+        runs = []
+        for bias in ("0", "-5", "4"):
+            monkeypatch.setenv("SFMBA_PCG_GUESS_BIAS", bias)
+            runs.append(sfmba.least_squares(sfmba.compute_residuals, pb.x0, x_scale="jac", ftol=1e-10,
+                                            method="trf", args=pb.args))
+        a = runs[0]
+        for b in runs[1:]:
+            assert (a.status, a.nfev, a.njev, a.pcg_iterations) == (b.status, b.nfev, b.njev, b.pcg_iterations)
+            assert abs(a.cost - b.cost) <= 1e-10 * a.cost
+            assert np.abs(a.x - b.x).max() <= 1e-7 * np.abs(a.x).max()     # atomics: summation order varies
+            r = sfmba.compute_residuals(b.x, *pb.args)
+            assert np.abs(r - b.fun).max() < 1e-8
+
+
 def test_cfg3_full_loop_vs_oracle(orc):
     """BASELINE config 3 (200 cameras / 20k points / 200k observations): the full Schur-LM loop on the
     GPU against the oracle's."""
