@@ -1041,6 +1041,17 @@ __global__ __launch_bounds__(64) void k_prep(double* __restrict__ sc, double Del
 // boundary, count > 64 a single point with that many observations.  wsteps[wave] = (first step, number
 // of steps).  With the step list known, the index loads of step s+1 are issued while step s computes,
 // so a step costs one memory round trip (its Jacobian blocks) instead of three dependent ones.
+// row k of the packed-upper-triangle 6x6 block m times r (block-Jacobi preconditioner)
+__device__ __forceinline__ double minv_row(const double* m, const double* r, int k) {
+    double z = 0.0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int a = k < j ? k : j, b = k < j ? j : k;
+        z += m[a * 6 - a * (a - 1) / 2 + (b - a)] * r[j];       // packed upper triangle
+    }
+    return z;
+}
+
 struct StepTable {
     const int2* __restrict__ wsteps;
     const int2* __restrict__ steps;
@@ -1048,15 +1059,135 @@ struct StepTable {
     int n_waves;
 };
 
-template <int ACC, int MODE>
+//
+// FUSED (ACC 1, MODE 0, C <= blockDim.x): the launch is a whole PCG iteration.  Its prologue performs the
+// update that k_pcg_update would have done after the PREVIOUS launch's product -- every workgroup
+// redundantly, one thread per camera, from the complete old vector set, leaving the new u directly in
+// the LDS table the sweep reads -- and stores only its own few cameras into the other vector set.
+// Launch L reads the product from accumulator L % 3, flushes its own into (L + 1) % 3 and clears
+// (L + 2) % 3 for the launch after it: nothing a workgroup reads is written during the same launch, so
+// no inter-workgroup synchronisation is needed.  ctrl.pad says whether a product is pending (it is
+// not on the first launch after k_pcg_init).  Returns at once when the solve has finished.
+struct PcgFused {
+    const double* __restrict__ Dc;
+    const double* __restrict__ Minv;
+    double* __restrict__ vecs;
+    PcgCtrl* __restrict__ ctrl2;
+};
+
+template <int ACC, int MODE, bool FUSED = false>
 __global__ __launch_bounds__(kSweepThreads) void k_schur_sweep(
     StepTable st, ObsArrays o, const double* __restrict__ vin,
     const double* __restrict__ Vinv, const double* __restrict__ zin, double* __restrict__ acc, int C,
-    const PcgCtrl* __restrict__ ctrl2, int L, int c_lo, int c_hi) {
+    const PcgCtrl* __restrict__ ctrl2, int L, int c_lo, int c_hi, PcgFused pf) {
     extern __shared__ __align__(16) double smem[];
+    static_assert(!FUSED || (ACC == 1 && MODE == 0), "the fused PCG launch keeps v and acc in LDS");
     constexpr bool LDS_ACC = ACC == 1;
     const int n6 = 6 * C;
-    if (ctrl2 != nullptr) {
+    if (FUSED) {
+        __shared__ double red[16];
+        __shared__ double bcast[2];
+        const PcgCtrl ci = pf.ctrl2[L & 1];
+        PcgCtrl* __restrict__ cout = pf.ctrl2 + ((L + 1) & 1);
+        const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
+        if (ci.done != 0) {                                       // grid-uniform
+            if (writer) *cout = ci;
+            return;
+        }
+        const int cam = threadIdx.x;
+        const bool has = cam < C;
+        const int slice = (C + (int)gridDim.x - 1) / (int)gridDim.x;
+        const bool own = has && cam >= (int)blockIdx.x * slice && cam < ((int)blockIdx.x + 1) * slice;
+        const int set = ci.iters & 1;
+        const double* __restrict__ vold = pf.vecs + (size_t)set * kPcgVecs * n6;
+        double* __restrict__ vnew = pf.vecs + (size_t)(set ^ 1) * kPcgVecs * n6;
+        const double* __restrict__ acc_in = acc + (size_t)(L % 3) * n6;
+        double* __restrict__ acc_clear = acc + (size_t)((L + 2) % 3) * n6;
+        acc += (size_t)((L + 1) % 3) * n6;                        // this launch's product goes here
+        double uu[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        if (ci.pad == 0) {                                        // first launch: u_0 comes from k_pcg_init
+            if (has) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) uu[k] = vold[kPcgU * n6 + (size_t)k * C + cam];
+            }
+            if (writer) { PcgCtrl co = ci; co.pad = 1; *cout = co; }
+        } else {
+            double ue[6], we[6];
+            double d[1] = {0.0};
+            if (has) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const size_t e = (size_t)k * C + cam;
+                    ue[k] = vold[kPcgU * n6 + e];
+                    we[k] = acc_in[e] + pf.Dc[e] * ue[k];
+                    d[0] += we[k] * ue[k];
+                }
+            }
+            block_sum<1>(d, red);
+            if (threadIdx.x == 0) bcast[0] = d[0];
+            __syncthreads();
+            const double delta = bcast[0];
+            const double gamma = ci.rz;
+            const double beta = ci.iters == 0 ? 0.0 : gamma / ci.rz_prev;
+            const double den = delta - (ci.iters == 0 ? 0.0 : beta * gamma / ci.alpha_prev);
+            const double alpha = gamma / den;
+            if (!(den > 0.0) || !isfinite(alpha)) {                // S not SPD / NaN: uniform in the grid
+                if (writer) { PcgCtrl co = ci; co.done = 3; *cout = co; }
+                return;
+            }
+            double t[1] = {0.0};
+            if (has) {
+                double rr[6], ss[6], m[21];
+#pragma unroll
+                for (int n = 0; n < 21; ++n) m[n] = pf.Minv[(size_t)n * C + cam];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const size_t e = (size_t)k * C + cam;
+                    ss[k] = we[k] + beta * vold[kPcgS * n6 + e];
+                    rr[k] = vold[kPcgR * n6 + e] - alpha * ss[k];
+                }
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    uu[k] = minv_row(m, rr, k);
+                    t[0] += uu[k] * rr[k];
+                }
+                if (own) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        const size_t e = (size_t)k * C + cam;
+                        const double pk = ue[k] + beta * vold[kPcgP * n6 + e];
+                        vnew[kPcgP * n6 + e] = pk;
+                        vnew[kPcgX * n6 + e] = vold[kPcgX * n6 + e] + alpha * pk;
+                        vnew[kPcgR * n6 + e] = rr[k];
+                        vnew[kPcgS * n6 + e] = ss[k];
+                        vnew[kPcgU * n6 + e] = uu[k];
+                    }
+                }
+            }
+            block_sum<1>(t, red);
+            if (threadIdx.x == 0) bcast[1] = t[0];
+            __syncthreads();
+            const double rz = bcast[1];
+            int done = 0;
+            if (!(rz > ci.tol2 * ci.rz0)) done = 1;               // also catches NaN
+            else if (ci.iters + 1 >= ci.max_iters) done = 2;
+            if (writer) {
+                PcgCtrl co = ci;
+                co.rz_prev = ci.rz; co.alpha_prev = alpha; co.rz = rz; co.iters = ci.iters + 1; co.done = done;
+                *cout = co;
+            }
+            if (done != 0) return;                                // grid-uniform
+        }
+        if (has) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                smem[6 * cam + k] = uu[k];
+                smem[n6 + 6 * cam + k] = 0.0;
+                if (own) acc_clear[(size_t)k * C + cam] = 0.0;
+            }
+        }
+        __syncthreads();
+    } else if (ctrl2 != nullptr) {
         // inside the PCG: `vin` is the base of the ping-pong vector sets, `acc` the base of the two
         // accumulators; the control block of this launch (written by the previous kernel) says which
         const PcgCtrl* __restrict__ ctrl = ctrl2 + (L & 1);
@@ -1077,7 +1208,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_schur_sweep(
 
     double* s_v = smem;
     double* s_acc = (ACC == 2) ? smem : smem + n6;
-    if (LDS_ACC) {
+    if (LDS_ACC && !FUSED) {
         for (int e = threadIdx.x; e < n6; e += blockDim.x) {       // e = k*C + c (global, coalesced)
             const int k = e / C, cc = e - k * C;
             s_v[6 * cc + k] = (MODE == 0) ? vin[e] : 0.0;
@@ -1230,18 +1361,9 @@ __global__ __launch_bounds__(kSweepThreads) void k_schur_sweep(
 // complete old vector set, and stores only its own slice of the cameras into the other set.  Control
 // blocks alternate as well (read ctrl2[L&1], written ctrl2[(L+1)&1] by block 0 only), so no workgroup
 // can observe a value written during its own launch.
-__device__ __forceinline__ double minv_row(const double* m, const double* r, int k) {
-    double z = 0.0;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        const int a = k < j ? k : j, b = k < j ? j : k;
-        z += m[a * 6 - a * (a - 1) / 2 + (b - a)] * r[j];       // packed upper triangle
-    }
-    return z;
-}
 
 // Start: rhs = -g_c - acc0 (acc0 = -sum W e from the MODE 1 sweep), x = 0, r = rhs, u = Minv r,
-// p = s = 0 in set 0; both accumulators zeroed; ctrl2[0] initialised.  Single workgroup.
+// p = s = 0 in set 0; all three accumulators zeroed; ctrl2[0] initialised.  Single workgroup.
 __global__ __launch_bounds__(1024) void k_pcg_init(const double* __restrict__ Ugc,
                                                    double* __restrict__ acc,
                                                    const double* __restrict__ Minv, int C,
@@ -1261,7 +1383,7 @@ __global__ __launch_bounds__(1024) void k_pcg_init(const double* __restrict__ Ug
         for (int k = 0; k < 6; ++k) {
             const size_t e = (size_t)k * C + c;
             rr[k] = -Ugc[(size_t)c * 27 + 21 + k] - acc[e];
-            acc[e] = 0.0; acc[n6 + e] = 0.0;
+            acc[e] = 0.0; acc[n6 + e] = 0.0; acc[2 * n6 + e] = 0.0;
             xk[e] = 0.0; pk[e] = 0.0; sk[e] = 0.0;
             rk[e] = rr[k];
         }

@@ -126,7 +126,7 @@ struct sfmba_handle {
     DevBuf Dc, Minv, vecs, vtmp, vcm;               // camera-sized, plane-major [k][C]; vecs = 2 sets x (x r p s u)
     DevBuf part, ctrl, tables;
     DevBuf arena_own;
-    double* arena = nullptr;                 // [acc0 6C | acc1 6C | Ugc 27C | 32 scalars]
+    double* arena = nullptr;                 // [acc0 6C | acc1 6C | acc2 6C | Ugc 27C | 32 scalars]
     int64_t arena_doubles = 0;
     sfmba_allreduce_fn ar_fn = nullptr;
     void* ar_ctx = nullptr;
@@ -137,6 +137,7 @@ struct sfmba_handle {
     size_t h_x_doubles = 0;
     hipEvent_t ev_handoff = nullptr;
     const double* skip = nullptr;         // device flag gating speculative trial launches (sfmba_solve); else null
+    bool pcg_fused = false;               // PCG update fused into the sweep launch (acc_mode 1, C <= 1024)
     int pcg_hint = 0;                     // largest PCG iteration count a solve on this handle has needed
     bool solved = false;
     std::vector<const void*> lds_ready;      // kernels already opted in to 160 KiB dynamic LDS
@@ -147,9 +148,9 @@ struct sfmba_handle {
     double* tab = nullptr;
     double* tab_new = nullptr;
 
-    double* acc() const { return arena; }    // two accumulators (PCG ping-pong); [0] also serves the rhs sweep
-    double* Ugc() const { return arena + 12 * C; }
-    double* scal() const { return arena + 39 * C; }
+    double* acc() const { return arena; }    // three accumulators (PCG rotation); [0] also serves the rhs sweep
+    double* Ugc() const { return arena + 18 * C; }
+    double* scal() const { return arena + 45 * C; }
     int pcg_L = 0;                           // launches (sweep+update pairs) since pcg_start
     int red_bc = 1, red_grid = 2;            // block split of the parameter-vector reductions
 };
@@ -371,10 +372,24 @@ template <int ACC, int MODE>
 int launch_schur_sweep_v(sfmba_handle* h, const double* vin, const double* zin, const PcgCtrl* ctrl2, int L,
                          size_t lds, int c_lo, int c_hi) {
     const int grid = (h->n_ranges + kWavesPerSweepBlock - 1) / kWavesPerSweepBlock;
-    auto kern = k_schur_sweep<ACC, MODE>;
+    auto kern = k_schur_sweep<ACC, MODE, false>;
     CHK(set_lds(h, kern, lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), lds, h->stream, step_table(h), obs_arrays(h), vin,
-                       h->Vinv.as<double>(), zin, h->acc(), (int)h->C, ctrl2, L, c_lo, c_hi);
+                       h->Vinv.as<double>(), zin, h->acc(), (int)h->C, ctrl2, L, c_lo, c_hi, PcgFused{});
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+// one whole PCG iteration per launch (update of the previous product in the prologue, then the sweep)
+int launch_pcg_fused(sfmba_handle* h, int L) {
+    const int grid = (h->n_ranges + kWavesPerSweepBlock - 1) / kWavesPerSweepBlock;
+    const size_t lds = sizeof(double) * 12 * (size_t)h->C;
+    auto kern = k_schur_sweep<1, 0, true>;
+    CHK(set_lds(h, kern, lds));
+    PcgFused pf{h->Dc.as<double>(), h->Minv.as<double>(), h->vecs.as<double>(), h->ctrl.as<PcgCtrl>()};
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), lds, h->stream, step_table(h), obs_arrays(h),
+                       (const double*)h->vecs.as<double>(), h->Vinv.as<double>(), (const double*)nullptr, h->acc(),
+                       (int)h->C, (const PcgCtrl*)h->ctrl.as<PcgCtrl>(), L, 0, (int)h->C, pf);
     HIPCHK(h, hipGetLastError());
     return 0;
 }
@@ -543,6 +558,12 @@ int pcg_enqueue(sfmba_handle* h, int count) {
     PcgCtrl* ctrl2 = h->ctrl.as<PcgCtrl>();
     for (int k = 0; k < count; ++k) {
         const int L = h->pcg_L;
+        if (h->pcg_fused) {
+            CHK(launch_pcg_fused(h, L));
+            CHK(exchange(h, h->acc() + (size_t)((L + 1) % 3) * 6 * h->C, 6 * h->C, 0));
+            h->pcg_L = L + 1;
+            continue;
+        }
         CHK(launch_schur_sweep<0>(h, h->vecs.as<double>(), nullptr, ctrl2, L));
         CHK(exchange(h, h->acc() + (size_t)(L & 1) * 6 * h->C, 6 * h->C, 0));   // set == L & 1 until done
         hipLaunchKernelGGL(k_pcg_update, dim3(kPcgUpdateBlocks), dim3(1024), 0, h->stream, h->acc(),
@@ -565,7 +586,7 @@ int pcg_read(sfmba_handle* h, PcgCtrl* hc) {
 // poll until the device reports the PCG finished
 int pcg_finish_polling(sfmba_handle* h, const sfmba_options& opt, PcgCtrl* hc) {
     const int every = std::max(1, opt.pcg_check_every);
-    const int cap = pcg_max_iters(h, opt) + every;
+    const int cap = pcg_max_iters(h, opt) + every + 1;
     int launched = 0;
     for (;;) {
         CHK(pcg_enqueue(h, every));
@@ -669,7 +690,7 @@ int sfmba_set_precision(sfmba_handle* h, int32_t storage_bits) {
     return 0;
 }
 
-int64_t sfmba_exchange_doubles(int64_t n_cameras) { return 39 * n_cameras + kScalSlots; }   // kScalSlots = 32
+int64_t sfmba_exchange_doubles(int64_t n_cameras) { return 45 * n_cameras + kScalSlots; }   // kScalSlots = 32
 
 int sfmba_set_exchange(sfmba_handle* h, void* arena, int64_t arena_doubles, sfmba_allreduce_fn fn,
                        void* ctx, int64_t n_obs_total) {
@@ -821,6 +842,8 @@ int sfmba_set_problem(sfmba_handle* h, int64_t C, int64_t P, int64_t N, const in
         if (m == 0 || m == 2 || (m == 1 && h->lds_acc)) h->acc_mode = m;
         if (const char* r = std::getenv("SFMBA_ACC_RANGE")) h->acc_range = std::max(1, std::min(h->acc_range, std::atoi(r)));
     }
+    h->pcg_fused = h->acc_mode == 1 && C <= kSweepThreads;
+    if (const char* e = std::getenv("SFMBA_PCG_FUSED")) h->pcg_fused = h->pcg_fused && std::atoi(e) != 0;   // test hook
     {   // normal-block LDS tables: as many column passes as the 27 columns need (a pass costs ~25 us
         // per million observations, the global-atomics fallback ~1300 us); atomics only past ~20k cameras
         const size_t budget = kLdsDynMax;
@@ -1152,7 +1175,9 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
         CHK(pcg_start(h, opt));                                 // replaces lsmr, trf.py:477-480
         PcgCtrl hc{};
         if (pcg_guess > 0) {
-            CHK(pcg_enqueue(h, pcg_guess + 1));                 // speculative: no read-back; surplus launches are no-ops
+            // speculative: no read-back; surplus launches are no-ops.  Fused launches apply the update of
+            // iteration k in launch k + 1, so k iterations need k + 1 launches; one spare either way.
+            CHK(pcg_enqueue(h, pcg_guess + (h->pcg_fused ? 2 : 1)));
         } else {
             CHK(pcg_finish_polling(h, opt, &hc));
         }
@@ -1235,7 +1260,7 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
         pcg_total += hc.iters;
         if (pcg_debug)
             fprintf(stderr, "sfmba: iteration %lld: PCG enqueued %d, needed %d%s\n", (long long)iteration,
-                    speculative ? pcg_guess + 1 : 0, hc.iters, speculative && !first_trial_ready ? " (miss)" : "");
+                    speculative ? pcg_guess + (h->pcg_fused ? 2 : 1) : 0, hc.iters, speculative && !first_trial_ready ? " (miss)" : "");
         // Next guess: the largest recent count, forgotten by one iteration per outer iteration.  A surplus
         // iteration costs two empty launches (~10 us); a miss costs a hand-off per polled batch.
         h->pcg_hint = std::max(hc.iters, h->pcg_hint - 1);

@@ -47,7 +47,7 @@ class _StubBackend:
         self.cb = None
 
     def exchange_doubles(self):
-        return 39 * self.n_cameras + 32
+        return 45 * self.n_cameras + 32
 
     def set_exchange(self, ptr, n, cb, n_obs_total):
         self.base, self.n, self.cb, self.n_obs_total = ptr, n, cb, n_obs_total
@@ -66,27 +66,27 @@ def _worker(rank, world, port, q):
         ex = sdist.Exchange(stub, n_obs_local=loc.n_obs)
         assert ex.n_obs_total == pb.n_obs and stub.n_obs_total == pb.n_obs
         # local normal-equation blocks with the oracle, packed as the library packs them:
-        # arena = [acc0 6C | acc1 6C | Ugc 27C | scalars 32]
+        # arena = [acc0 6C | acc1 6C | acc2 6C | Ugc 27C | scalars 32]
         r, Jc, Jp = orc.jacobian_blocks(loc.x0, *loc.args)
         nb = orc.normal_blocks(r, Jc, Jp, C, loc.n_points, loc.camera_indices, loc.point_indices)
         iu = np.triu_indices(6)
         ugc = np.concatenate([nb.U[:, iu[0], iu[1]], nb.gc], axis=1)           # (C,27)
-        ex.arena[12 * C:39 * C] = torch.from_numpy(ugc.ravel())
-        ex.arena[39 * C + 0] = float(np.sum(r * r))                            # cost slot
-        ex.arena[39 * C + 12] = float(np.abs(nb.gp).max())                     # max|g| slot
-        stub.cb(stub.base + 8 * 12 * C, 27 * C, 0)                              # sum
-        stub.cb(stub.base + 8 * 39 * C, 12, 0)
-        stub.cb(stub.base + 8 * (39 * C + 12), 1, 1)                           # max
+        ex.arena[18 * C:45 * C] = torch.from_numpy(ugc.ravel())
+        ex.arena[45 * C + 0] = float(np.sum(r * r))                            # cost slot
+        ex.arena[45 * C + 12] = float(np.abs(nb.gp).max())                     # max|g| slot
+        stub.cb(stub.base + 8 * 18 * C, 27 * C, 0)                              # sum
+        stub.cb(stub.base + 8 * 45 * C, 12, 0)
+        stub.cb(stub.base + 8 * (45 * C + 12), 1, 1)                           # max
         with pytest.raises(ValueError):
-            stub.cb(stub.base + 8 * (39 * C + 10), 100, 0)                     # outside the arena
+            stub.cb(stub.base + 8 * (45 * C + 10), 100, 0)                     # outside the arena
         if rank == 0:
             rg, Jcg, Jpg = orc.jacobian_blocks(pb.x0, *pb.args)
             nbg = orc.normal_blocks(rg, Jcg, Jpg, C, pb.n_points, pb.camera_indices, pb.point_indices)
             ref = np.concatenate([nbg.U[:, iu[0], iu[1]], nbg.gc], axis=1).ravel()
-            got = ex.arena[12 * C:39 * C].numpy()
+            got = ex.arena[18 * C:45 * C].numpy()
             q.put(dict(ok_blocks=bool(np.allclose(got, ref, rtol=1e-12, atol=1e-9 * np.abs(ref).max())),
-                       cost=float(ex.arena[39 * C]), cost_ref=float(np.sum(rg * rg)),
-                       gmax=float(ex.arena[39 * C + 12]), gmax_ref=float(np.abs(nbg.gp).max()),
+                       cost=float(ex.arena[45 * C]), cost_ref=float(np.sum(rg * rg)),
+                       gmax=float(ex.arena[45 * C + 12]), gmax_ref=float(np.abs(nbg.gp).max()),
                        calls=ex.n_calls))
     finally:
         td.destroy_process_group()

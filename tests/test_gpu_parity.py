@@ -326,6 +326,24 @@ def test_speculative_pcg_miss_changes_nothing(monkeypatch):
             assert np.abs(r - b.fun).max() < 1e-8
 
 
+def test_fused_pcg_launch_equals_sweep_plus_update(monkeypatch):
+    """With v and the accumulator in LDS and at most 1024 cameras, a PCG iteration is ONE launch (the
+    update of the previous product runs in the sweep's prologue, three rotating accumulators).  It must
+    walk through the same iterates as the two-kernel form (SFMBA_PCG_FUSED=0, read at set_problem)."""
+    import sfmba
+    for pb in (sfmba.make_config("cfg2"), sfmba.make_problem(300, 4000, 30000, seed=3),
+               sfmba.make_problem(6, 80, 500, seed=5, x0_noise=0.2), sfmba.make_problem(1024, 3000, 20000, seed=8)):
+        runs = []
+        for flag in ("1", "0"):
+            monkeypatch.setenv("SFMBA_PCG_FUSED", flag)
+            runs.append(sfmba.least_squares(sfmba.compute_residuals, pb.x0, x_scale="jac", ftol=1e-10,
+                                            method="trf", args=pb.args))
+        a, b = runs
+        assert (a.status, a.nfev, a.njev, a.pcg_iterations) == (b.status, b.nfev, b.njev, b.pcg_iterations)
+        assert abs(a.cost - b.cost) <= 1e-10 * a.cost
+        assert np.abs(a.x - b.x).max() <= 1e-7 * np.abs(a.x).max()         # atomics: summation order varies
+
+
 def test_cfg3_full_loop_vs_oracle(orc):
     """BASELINE config 3 (200 cameras / 20k points / 200k observations): the full Schur-LM loop on the
     GPU against the oracle's."""

@@ -15,3 +15,11 @@ for r in seg:
 print("kernels", len(seg), "span us %.1f busy us %.1f" % ((prev - t0) / 1e3, busy / 1e3))
 print("gaps > 2us:", len(gaps), "total %.1f us" % sum(g for g, _ in gaps))
 for g, n in gaps: print("   %.1f before %s" % (g, n))
+import collections, re
+tot = collections.defaultdict(lambda: [0, 0.0])
+for r in seg:
+    name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").replace("sfmba::", "")
+    tot[name][0] += 1; tot[name][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+print("per kernel in this solve:")
+for n, (c, t) in sorted(tot.items(), key=lambda kv: -kv[1][1]):
+    print("  %-40s %4d calls %8.1f us  %5.1f %%" % (n[:40], c, t, 100 * t / (busy / 1e3)))
