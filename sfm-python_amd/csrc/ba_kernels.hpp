@@ -1003,7 +1003,7 @@ __global__ void k_cam_prep(const double* __restrict__ Ugc, const double* __restr
 
 // Everything between the Cauchy product and the reduced right-hand side in one launch: the
 // regularisation term from the exchange scalars (every thread evaluates the same few flops, block 0
-// publishes it in scalar slot 13), blocks [0, bc): one camera per thread (Dc, Minv, acc0 = 0),
+// publishes it in scalar slot 13), blocks [0, bc): one camera per thread (Dc, Minv, acc0 = acc1 = 0),
 // blocks [bc, grid): one point per thread (Vinv, e).
 __global__ __launch_bounds__(64) void k_prep(double* __restrict__ sc, double Delta, double reg_min,
                                              const double* __restrict__ Ugc, const double* __restrict__ V,
@@ -1017,7 +1017,7 @@ __global__ __launch_bounds__(64) void k_prep(double* __restrict__ sc, double Del
         const int c = blockIdx.x * blockDim.x + threadIdx.x;
         if (c >= C) return;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) acc0[(size_t)k * C + c] = 0.0;
+        for (int k = 0; k < 6; ++k) { acc0[(size_t)k * C + c] = 0.0; acc0[(size_t)(6 + k) * C + c] = 0.0; }
         cam_prep_one(Ugc, si, nullptr, C, c, reg, Dc, Minv);
         return;
     }
@@ -1066,13 +1066,17 @@ struct StepTable {
 // the LDS table the sweep reads -- and stores only its own few cameras into the other vector set.
 // Launch L reads the product from accumulator L % 3, flushes its own into (L + 1) % 3 and clears
 // (L + 2) % 3 for the launch after it: nothing a workgroup reads is written during the same launch, so
-// no inter-workgroup synchronisation is needed.  ctrl.pad says whether a product is pending (it is
-// not on the first launch after k_pcg_init).  Returns at once when the solve has finished.
+// no inter-workgroup synchronisation is needed.  Launch 0 does k_pcg_init's work instead of an update
+// (accumulator 0 holds the reduced right-hand side term, accumulator 1 must be zero: k_prep clears
+// both).  Returns at once when the solve has finished.
 struct PcgFused {
     const double* __restrict__ Dc;
     const double* __restrict__ Minv;
+    const double* __restrict__ Ugc;      // launch 0 builds the right-hand side from g_c and accumulator 0
     double* __restrict__ vecs;
     PcgCtrl* __restrict__ ctrl2;
+    double tol;
+    int max_iters;
 };
 
 template <int ACC, int MODE, bool FUSED = false>
@@ -1087,41 +1091,88 @@ __global__ __launch_bounds__(kSweepThreads) void k_schur_sweep(
     if (FUSED) {
         __shared__ double red[16];
         __shared__ double bcast[2];
-        const PcgCtrl ci = pf.ctrl2[L & 1];
+        // Until the solve finishes, launch L >= 1 sees iters == L - 1, so every address below follows from
+        // L alone and all vector loads of the prologue are in flight together.
         PcgCtrl* __restrict__ cout = pf.ctrl2 + ((L + 1) & 1);
         const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
-        if (ci.done != 0) {                                       // grid-uniform
-            if (writer) *cout = ci;
-            return;
-        }
         const int cam = threadIdx.x;
         const bool has = cam < C;
         const int slice = (C + (int)gridDim.x - 1) / (int)gridDim.x;
         const bool own = has && cam >= (int)blockIdx.x * slice && cam < ((int)blockIdx.x + 1) * slice;
-        const int set = ci.iters & 1;
+        const int set = L == 0 ? 0 : (L - 1) & 1;
         const double* __restrict__ vold = pf.vecs + (size_t)set * kPcgVecs * n6;
-        double* __restrict__ vnew = pf.vecs + (size_t)(set ^ 1) * kPcgVecs * n6;
+        double* __restrict__ vnew = pf.vecs + (size_t)(L == 0 ? 0 : set ^ 1) * kPcgVecs * n6;
         const double* __restrict__ acc_in = acc + (size_t)(L % 3) * n6;
         double* __restrict__ acc_clear = acc + (size_t)((L + 2) % 3) * n6;
         acc += (size_t)((L + 1) % 3) * n6;                        // this launch's product goes here
         double uu[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        if (ci.pad == 0) {                                        // first launch: u_0 comes from k_pcg_init
+        double m[21];
+        PcgCtrl ci;
+        if (L != 0) {
+            ci = pf.ctrl2[L & 1];
+            if (ci.done != 0) {                                   // grid-uniform; before any other load is issued
+                if (writer) *cout = ci;
+                return;
+            }
+        }
+        if (has) {
+#pragma unroll
+            for (int n = 0; n < 21; ++n) m[n] = pf.Minv[(size_t)n * C + cam];
+        }
+        if (L == 0) {
+            // start of a solve (k_pcg_init's work): rhs = -g_c - acc0 (acc0 = -sum W e from the MODE 1
+            // sweep), x = p = s = 0, r = rhs, u = Minv r
+            double rr[6];
+            double t[1] = {0.0};
             if (has) {
 #pragma unroll
-                for (int k = 0; k < 6; ++k) uu[k] = vold[kPcgU * n6 + (size_t)k * C + cam];
+                for (int k = 0; k < 6; ++k) rr[k] = -pf.Ugc[(size_t)cam * 27 + 21 + k] - acc_in[(size_t)k * C + cam];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    uu[k] = minv_row(m, rr, k);
+                    t[0] += uu[k] * rr[k];
+                }
+                if (own) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        const size_t e = (size_t)k * C + cam;
+                        vnew[kPcgX * n6 + e] = 0.0; vnew[kPcgP * n6 + e] = 0.0; vnew[kPcgS * n6 + e] = 0.0;
+                        vnew[kPcgR * n6 + e] = rr[k];
+                        vnew[kPcgU * n6 + e] = uu[k];
+                    }
+                }
             }
-            if (writer) { PcgCtrl co = ci; co.pad = 1; *cout = co; }
+            block_sum<1>(t, red);
+            if (threadIdx.x == 0) bcast[1] = t[0];
+            __syncthreads();
+            const double rz = bcast[1];
+            const int done = (rz > 0.0) ? 0 : (rz == 0.0 ? 1 : 3);
+            if (writer) {
+                PcgCtrl c0;
+                c0.rz = rz; c0.rz0 = rz; c0.tol2 = pf.tol * pf.tol; c0.rz_prev = 1.0; c0.alpha_prev = 1.0;
+                c0.iters = 0; c0.max_iters = pf.max_iters; c0.done = done; c0.pad = 1;
+#ifdef SFMBA_STAMPS
+                for (int k = 0; k < 16; ++k) c0.stamp[k] = 0;
+#endif
+                *cout = c0;
+            }
+            if (done != 0) return;                                // grid-uniform
         } else {
-            double ue[6], we[6];
-            double d[1] = {0.0};
+            double ue[6], we[6], so[6], ro[6];
             if (has) {
 #pragma unroll
                 for (int k = 0; k < 6; ++k) {
                     const size_t e = (size_t)k * C + cam;
                     ue[k] = vold[kPcgU * n6 + e];
                     we[k] = acc_in[e] + pf.Dc[e] * ue[k];
-                    d[0] += we[k] * ue[k];
+                    so[k] = vold[kPcgS * n6 + e];
+                    ro[k] = vold[kPcgR * n6 + e];
                 }
+            }
+            double d[1] = {0.0};
+            if (has) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) d[0] += we[k] * ue[k];
             }
             block_sum<1>(d, red);
             if (threadIdx.x == 0) bcast[0] = d[0];
@@ -1137,14 +1188,11 @@ __global__ __launch_bounds__(kSweepThreads) void k_schur_sweep(
             }
             double t[1] = {0.0};
             if (has) {
-                double rr[6], ss[6], m[21];
-#pragma unroll
-                for (int n = 0; n < 21; ++n) m[n] = pf.Minv[(size_t)n * C + cam];
+                double rr[6], ss[6];
 #pragma unroll
                 for (int k = 0; k < 6; ++k) {
-                    const size_t e = (size_t)k * C + cam;
-                    ss[k] = we[k] + beta * vold[kPcgS * n6 + e];
-                    rr[k] = vold[kPcgR * n6 + e] - alpha * ss[k];
+                    ss[k] = we[k] + beta * so[k];
+                    rr[k] = ro[k] - alpha * ss[k];
                 }
 #pragma unroll
                 for (int k = 0; k < 6; ++k) {
@@ -1155,6 +1203,8 @@ __global__ __launch_bounds__(kSweepThreads) void k_schur_sweep(
 #pragma unroll
                     for (int k = 0; k < 6; ++k) {
                         const size_t e = (size_t)k * C + cam;
+                        // p and x of the few cameras this workgroup stores are read late: keeping them in
+                        // registers from the top would spill
                         const double pk = ue[k] + beta * vold[kPcgP * n6 + e];
                         vnew[kPcgP * n6 + e] = pk;
                         vnew[kPcgX * n6 + e] = vold[kPcgX * n6 + e] + alpha * pk;

@@ -137,6 +137,7 @@ struct sfmba_handle {
     size_t h_x_doubles = 0;
     hipEvent_t ev_handoff = nullptr;
     const double* skip = nullptr;         // device flag gating speculative trial launches (sfmba_solve); else null
+    double pcg_tol = 0.0; int pcg_cap = 0; // options of the running PCG (fused launch 0 writes the control block)
     bool pcg_fused = false;               // PCG update fused into the sweep launch (acc_mode 1, C <= 1024)
     int pcg_hint = 0;                     // largest PCG iteration count a solve on this handle has needed
     bool solved = false;
@@ -386,7 +387,8 @@ int launch_pcg_fused(sfmba_handle* h, int L) {
     const size_t lds = sizeof(double) * 12 * (size_t)h->C;
     auto kern = k_schur_sweep<1, 0, true>;
     CHK(set_lds(h, kern, lds));
-    PcgFused pf{h->Dc.as<double>(), h->Minv.as<double>(), h->vecs.as<double>(), h->ctrl.as<PcgCtrl>()};
+    PcgFused pf{h->Dc.as<double>(), h->Minv.as<double>(), h->Ugc(), h->vecs.as<double>(), h->ctrl.as<PcgCtrl>(),
+                h->pcg_tol, h->pcg_cap};
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), lds, h->stream, step_table(h), obs_arrays(h),
                        (const double*)h->vecs.as<double>(), h->Vinv.as<double>(), (const double*)nullptr, h->acc(),
                        (int)h->C, (const PcgCtrl*)h->ctrl.as<PcgCtrl>(), L, 0, (int)h->C, pf);
@@ -545,6 +547,12 @@ int pcg_max_iters(const sfmba_handle* h, const sfmba_options& opt) {
 
 // x = 0, r = rhs, u = Minv r (acc0 holds the reduced right-hand side term of the MODE 1 sweep)
 int pcg_start(sfmba_handle* h, const sfmba_options& opt) {
+    h->pcg_L = 0;
+    if (h->pcg_fused) {                   // launch 0 of the fused form initialises the solve itself
+        h->pcg_tol = opt.pcg_tol;
+        h->pcg_cap = pcg_max_iters(h, opt);
+        return 0;
+    }
     hipLaunchKernelGGL(k_pcg_init, dim3(1), dim3(1024), 0, h->stream, h->Ugc(), h->acc(), h->Minv.as<double>(),
                        (int)h->C, h->vecs.as<double>(), opt.pcg_tol, pcg_max_iters(h, opt), h->ctrl.as<PcgCtrl>());
     HIPCHK(h, hipGetLastError());
