@@ -799,9 +799,40 @@ __global__ __launch_bounds__(256) void k_vec_reduce(const double* __restrict__ g
 // block y handles the partial rows [row0[y], row0[y] + nrows[y]) and writes quantity k to
 // out[slot[y][k]] (slot < 0: not written).  Fixed lane->row mapping: deterministic.
 struct FinishJob { int row0[2], nrows[2], slot[2][kNQ]; };
+//
+// Mailbox: the hand-off of an outer iteration.  One wave copies the 32 exchange scalars and the PCG
+// control block into coherent host memory and raises a sequence number behind them; the host polls
+// that word instead of waiting on an event behind two blit copies.  mbox = [0..31] scalars,
+// [32..] control block, [63] sequence number.
+constexpr int kMboxCtrl = 32, kMboxSeq = 63;
+struct Mailbox {
+    double* __restrict__ host;            // device-visible address of the pinned block; null: no post
+    const double* __restrict__ sc;
+    const PcgCtrl* __restrict__ ctrl;
+    unsigned long long seq;
+};
+static_assert(kMboxCtrl + (int)((sizeof(PcgCtrl) + 7) / 8) <= kMboxSeq, "mailbox layout");
+
+__device__ __forceinline__ void post_mailbox(const Mailbox& mb) {     // one full wave
+    const int lane = threadIdx.x & 63;
+    if (lane < kMboxCtrl) mb.host[lane] = mb.sc[lane];
+    constexpr int nc = (int)((sizeof(PcgCtrl) + 7) / 8);
+    if (mb.ctrl != nullptr && lane >= kMboxCtrl && lane < kMboxCtrl + nc)
+        mb.host[lane] = reinterpret_cast<const double*>(mb.ctrl)[lane - kMboxCtrl];
+    __threadfence_system();
+    if (lane == 0)
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(mb.host + kMboxSeq), mb.seq, __ATOMIC_RELEASE,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ void k_post(Mailbox mb) { post_mailbox(mb); }
+
 __global__ void k_finish(const double* __restrict__ part, FinishJob job, int nq, int first_sum,
-                         double* __restrict__ out, const double* __restrict__ skip) {
-    if (skip != nullptr && *skip != 0.0) return;   // speculative launch cancelled by k_tr_step
+                         double* __restrict__ out, const double* __restrict__ skip, Mailbox mb) {
+    if (skip != nullptr && *skip != 0.0) {         // speculative launch cancelled by k_tr_step
+        if (mb.host != nullptr && blockIdx.x == 0 && threadIdx.x < 64) post_mailbox(mb);
+        return;
+    }
     const int y = blockIdx.x;
     const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (k >= nq) return;
@@ -817,6 +848,10 @@ __global__ void k_finish(const double* __restrict__ part, FinishJob job, int nq,
     }
     const int dst = job.slot[y][k];
     if (lane == 0 && dst >= 0) out[dst] = s;
+    if (mb.host != nullptr) {                      // single block (the host launches it that way)
+        __syncthreads();
+        if (threadIdx.x < 64) post_mailbox(mb);
+    }
 }
 
 // t1_i = J (D^2 g) per observation and sum |t1|^2 (the quadratic of the 1-D Cauchy problem,
@@ -1253,8 +1288,8 @@ __global__ __launch_bounds__(kSweepThreads) void k_schur_sweep(
     // indices of the first step are requested before the LDS tables are staged
     int2 cur = make_int2(0, 0);
     if (s < s_end) cur = st.steps[s];
-    int i = cur.x + lane, c = 0, p = 0, off = 0;
-    if (cur.y <= 64 && lane < cur.y) { c = o.cam_idx[i]; p = o.pt_idx[i]; off = st.run_off[i]; }
+    int i = cur.x + lane, c = 0, p = 0;
+    if (cur.y <= 64 && lane < cur.y) { c = o.cam_idx[i]; p = o.pt_idx[i]; }
 
     double* s_v = smem;
     double* s_acc = (ACC == 2) ? smem : smem + n6;
@@ -1308,8 +1343,8 @@ __global__ __launch_bounds__(kSweepThreads) void k_schur_sweep(
         int2 nxt = make_int2(0, 0);
         if (s + 1 < s_end) nxt = st.steps[s + 1];
         const int in_ = nxt.x + lane;
-        int cn = 0, pn = 0, offn = 0;
-        if (nxt.y <= 64 && lane < nxt.y) { cn = o.cam_idx[in_]; pn = o.pt_idx[in_]; offn = st.run_off[in_]; }
+        int cn = 0, pn = 0;
+        if (nxt.y <= 64 && lane < nxt.y) { cn = o.cam_idx[in_]; pn = o.pt_idx[in_]; }
 
         double jc[12], jp[6];
         if (cur.y > 64) {                          // one point with more than 64 observations
@@ -1360,20 +1395,24 @@ __global__ __launch_bounds__(kSweepThreads) void k_schur_sweep(
                     y[0] = jp[0] * t0 + jp[3] * t1; y[1] = jp[1] * t0 + jp[4] * t1;
                     y[2] = jp[2] * t0 + jp[5] * t1;
                 }
+                const int key = act ? p : -1 - lane;                  // run key = point index
 #ifndef SFMBA_ABLATE_SWEEP_SEGRED
-                seg_reduce<3>(y, act ? p : -1 - lane, lane);          // run key = point index
+                seg_reduce<3>(y, key, lane);
 #endif
                 z0 = vi[0] * y[0] + vi[1] * y[1] + vi[2] * y[2];      // meaningful on run heads
                 z1 = vi[1] * y[0] + vi[3] * y[1] + vi[4] * y[2];
                 z2 = vi[2] * y[0] + vi[4] * y[1] + vi[5] * y[2];
 #ifndef SFMBA_ABLATE_SWEEP_SEGRED
-                const int head = act ? lane - off : lane;
+                // first lane of the lane's run: the highest run start at or below it
+                const int prev = __shfl_up(key, 1);
+                const unsigned long long starts = __ballot(lane == 0 || prev != key);
+                const int head = 63 - __clzll((long long)(starts & (~0ull >> (63 - lane))));
                 z0 = __shfl(z0, head); z1 = __shfl(z1, head); z2 = __shfl(z2, head);
 #endif
             }
             if (act) scatter(jc, jp, c, t0, t1, z0, z1, z2);
         }
-        cur = nxt; i = in_; c = cn; p = pn; off = offn;
+        cur = nxt; i = in_; c = cn; p = pn;
         ++s;
     }
     if (ACC == 2) {

@@ -133,6 +133,10 @@ struct sfmba_handle {
     ncclComm_t comm = nullptr;               // native RCCL communicator (sfmba_comm_init)
     int64_t n_collectives = 0;
     double* h_scal = nullptr;                // pinned
+    double* mbox = nullptr;                  // coherent pinned block the device posts the hand-off into (Mailbox)
+    double* mbox_dev = nullptr;              // its device-visible address
+    unsigned long long mbox_seq = 0;
+    Mailbox post{};                          // set while the launch that ends a hand-off is enqueued; else empty
     double* h_x = nullptr;                   // pinned staging of the parameter vector
     size_t h_x_doubles = 0;
     hipEvent_t ev_handoff = nullptr;
@@ -262,6 +266,28 @@ int wait_event(sfmba_handle* h, hipEvent_t ev) {
     return 0;
 }
 
+// The hand-off of an outer iteration: the device posts scalars + PCG control block into the mailbox and
+// raises its sequence number (post_mailbox); the host polls that word.  The stream is queried only
+// every 2 ms, to notice a failed launch instead of spinning forever.
+int wait_mailbox(sfmba_handle* h, unsigned long long seq) {
+    unsigned long long* word = reinterpret_cast<unsigned long long*>(h->mbox + kMboxSeq);
+    double t_check = now_s() + 2e-3;
+    for (int spin = 0;; ++spin) {
+        if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) return 0;
+        __builtin_ia32_pause();
+        if ((spin & 63) != 63) continue;
+        const double t = now_s();
+        if (t < t_check) continue;
+        const hipError_t e = hipStreamQuery(h->stream);
+        if (e == hipSuccess) {                               // everything enqueued has run: the post is visible
+            if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) return 0;
+            return fail(h, -3, "hand-off mailbox was not written");
+        }
+        if (e != hipErrorNotReady) return fail(h, -3, "hipStreamQuery failed: %s", hipGetErrorString(e));
+        t_check = t + 2e-3;
+    }
+}
+
 // ---- kernel launch wrappers --------------------------------------------------------------------
 
 int launch_cam_table(sfmba_handle* h, const double* x, double* tab) {
@@ -313,7 +339,8 @@ int launch_finish(sfmba_handle* h, const double* part, int nparts, int nq, int s
     FinishJob job{};
     job.row0[0] = 0; job.nrows[0] = nparts;
     for (int k = 0; k < kNQ; ++k) job.slot[0][k] = slot + k;
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64 * nq), 0, h->stream, part, job, nq, 0, h->scal(), h->skip);
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64 * nq), 0, h->stream, part, job, nq, 0, h->scal(), h->skip,
+                       h->post);
     HIPCHK(h, hipGetLastError());
     return 0;
 }
@@ -329,7 +356,7 @@ int launch_finish_slices(sfmba_handle* h, int q_lo, int q_hi) {
         job.slot[1][k] = (k >= q_lo && k <= q_hi) ? kPointSlot[k] : -1;
     }
     hipLaunchKernelGGL(k_finish, dim3(2), dim3(64 * kNQ), 0, h->stream, h->part.as<double>(), job, kNQ, 1, h->scal(),
-                       (const double*)nullptr);
+                       (const double*)nullptr, Mailbox{});
     HIPCHK(h, hipGetLastError());
     return 0;
 }
@@ -661,9 +688,12 @@ int sfmba_create(sfmba_handle** out, int device_id) {
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return -3; }
     h->own_stream = true;
     if (hipHostMalloc((void**)&h->h_scal, sizeof(double) * 64, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&h->mbox, sizeof(double) * 64, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&h->mbox_dev, h->mbox, 0) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_handoff, hipEventDisableTiming) != hipSuccess) {
         (void)hipStreamDestroy(h->stream); delete h; return -4;
     }
+    memset(h->mbox, 0, sizeof(double) * 64);
     *out = h;
     return 0;
 }
@@ -675,6 +705,7 @@ void sfmba_destroy(sfmba_handle* h) {
     if (h->comm) { if (RcclApi* api = rccl_api()) (void)api->CommDestroy(h->comm); h->comm = nullptr; }
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     if (h->h_scal) (void)hipHostFree(h->h_scal);
+    if (h->mbox) (void)hipHostFree(h->mbox);
     if (h->h_x) (void)hipHostFree(h->h_x);
     if (h->ev_handoff) (void)hipEventDestroy(h->ev_handoff);
     delete h;
@@ -1093,6 +1124,7 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
     if (opt_in) opt = *opt_in; else sfmba_default_options(&opt);
     memset(out, 0, sizeof *out);
     h->solved = false;
+    h->skip = nullptr; h->post = Mailbox{};
     const double t_begin = now_s();
     const int64_t C = h->C, P = h->P, n = h->n;
     const int64_t max_nfev = opt.max_nfev > 0 ? opt.max_nfev : 100 * (6 * C + 3 * P);
@@ -1208,16 +1240,22 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
             HIPCHK(h, hipGetLastError());
             // the trial point is evaluated WITH its Jacobian, into the same buffers: when
             // the step is accepted (the common case) nothing has to be recomputed
-            CHK(eval_jac(h->x_new, h->tab_new, h->jcur, true));
+            // The cost reduction that ends the evaluation also posts the hand-off (scalars + PCG control
+            // block) into the host mailbox; with several ranks the post follows the all-reduce of the cost.
+            const Mailbox mb{h->mbox_dev, sc, h->ctrl.as<PcgCtrl>() + (h->pcg_L & 1), ++h->mbox_seq};
+            const bool ranks = h->comm != nullptr || h->ar_fn != nullptr;
+            if (!ranks) h->post = mb;
+            const int rc = eval_jac(h->x_new, h->tab_new, h->jcur, true);
+            h->post = Mailbox{};
+            CHK(rc);
             CHK(exchange(h, sc, 1, 0));
+            if (ranks) {
+                hipLaunchKernelGGL(k_post, dim3(1), dim3(64), 0, h->stream, mb);
+                HIPCHK(h, hipGetLastError());
+            }
             return 0;
         };
         auto handoff = [&](bool with_ctrl) -> int {
-            if (with_ctrl)
-                HIPCHK(h, hipMemcpyAsync(h->h_scal + 40, h->ctrl.as<PcgCtrl>() + (h->pcg_L & 1), sizeof hc,
-                                         hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(h, hipMemcpyAsync(h->h_scal, sc, sizeof(double) * kScalSlots, hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(h, hipEventRecord(h->ev_handoff, h->stream));
             // While the host waits, the GPU already builds the normal-equation blocks of the trial point
             // (speculating on acceptance, the common case).  They overwrite V / g_p / [U|g_c], which a
             // rejected step does not need: a retry only re-solves the 2-D model (host scalars) and
@@ -1225,8 +1263,9 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
             CHK(launch_normal_blocks(h));
             CHK(exchange(h, h->Ugc(), 27 * C, 0));
             nb_valid = false;
-            CHK(wait_event(h, h->ev_handoff));
-            if (with_ctrl) memcpy(&hc, h->h_scal + 40, sizeof hc);
+            CHK(wait_mailbox(h, h->mbox_seq));
+            memcpy(h->h_scal, h->mbox, sizeof(double) * kScalSlots);
+            if (with_ctrl) memcpy(&hc, h->mbox + kMboxCtrl, sizeof hc);
             return 0;
         };
         const bool speculative = pcg_guess > 0;
