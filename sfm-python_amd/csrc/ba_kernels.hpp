@@ -1090,7 +1090,6 @@ __device__ __forceinline__ double minv_row(const double* m, const double* r, int
 struct StepTable {
     const int2* __restrict__ wsteps;
     const int2* __restrict__ steps;
-    const unsigned char* __restrict__ run_off;    // offset of each observation inside its point's run (clipped to 255)
     int n_waves;
 };
 

@@ -116,7 +116,7 @@ struct sfmba_handle {
     int acc_mode = 1, acc_range = 0;         // operand placement of the Schur sweep (launch_schur_sweep)
     int nb_passes = 1;                       // column passes of the LDS normal-block tables; 0 = global atomics
 
-    DevBuf cam_idx, pt_idx, pt_ptr, uv, ranges, wsteps, steps, run_off;
+    DevBuf cam_idx, pt_idx, pt_ptr, uv, ranges, wsteps, steps;
     int n_steps = 0;
     DevBuf xa, xb, tabA, tabB, r[2], J[2], t1;   // J and r double-buffered: a trial step is
                                                        // evaluated into the spare set and swapped in on accept
@@ -228,7 +228,7 @@ ObsArrays obs_arrays(const sfmba_handle* h) {
 }
 
 StepTable step_table(const sfmba_handle* h) {
-    return StepTable{h->wsteps.as<int2>(), h->steps.as<int2>(), h->run_off.as<unsigned char>(), h->n_ranges};
+    return StepTable{h->wsteps.as<int2>(), h->steps.as<int2>(), h->n_ranges};
 }
 
 int grid_1d(int64_t n, int block, int cap) {
@@ -847,9 +847,6 @@ int sfmba_set_problem(sfmba_handle* h, int64_t C, int64_t P, int64_t N, const in
     // step table of the sweeps: per wave range, batches of <= 64 observations that end on a point
     // boundary; a point with more than 64 observations is one step of its own
     std::vector<int2> wsteps(ranges.size()), steps;
-    std::vector<unsigned char> run_off(h->ld, 0);
-    for (int64_t p = 0; p < P; ++p)
-        for (int64_t k = ptr[p]; k < ptr[p + 1]; ++k) run_off[k] = (unsigned char)std::min<int64_t>(255, k - ptr[p]);
     for (size_t w = 0; w < ranges.size(); ++w) {
         const int first = (int)steps.size();
         int64_t pos = ranges[w].x;
@@ -899,7 +896,6 @@ int sfmba_set_problem(sfmba_handle* h, int64_t C, int64_t P, int64_t N, const in
     HIPCHK(h, h->ranges.ensure(sizeof(int2) * std::max<size_t>(1, ranges.size())));
     HIPCHK(h, h->wsteps.ensure(sizeof(int2) * std::max<size_t>(1, wsteps.size())));
     HIPCHK(h, h->steps.ensure(sizeof(int2) * std::max<size_t>(1, steps.size())));
-    HIPCHK(h, h->run_off.ensure(ld));
     HIPCHK(h, h->xa.ensure(sizeof(double) * h->n));
     HIPCHK(h, h->xb.ensure(sizeof(double) * h->n));
     HIPCHK(h, h->tabA.ensure(sizeof(double) * kCamTab * C));
@@ -953,7 +949,6 @@ int sfmba_set_problem(sfmba_handle* h, int64_t C, int64_t P, int64_t N, const in
         HIPCHK(h, hipMemcpyAsync(h->wsteps.p, wsteps.data(), sizeof(int2) * wsteps.size(), hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipMemcpyAsync(h->steps.p, steps.data(), sizeof(int2) * steps.size(), hipMemcpyHostToDevice, h->stream));
     }
-    HIPCHK(h, hipMemcpyAsync(h->run_off.p, run_off.data(), ld, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemsetAsync(h->arena, 0, sizeof(double) * (size_t)sfmba_exchange_doubles(C), h->stream));
     // points without observations are never written by the normal-block kernel: their blocks must be 0
     HIPCHK(h, hipMemsetAsync(h->V.p, 0, sizeof(double) * 6 * P, h->stream));
