@@ -102,6 +102,9 @@ def main():
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--exchange", default="native", choices=["native", "torch"],
                     help="native: RCCL called from C++ on the solver stream; torch: torch.distributed callback")
+    ap.add_argument("--no-direct", action="store_true",
+                    help="do not map the peers' staging buffers: every collective goes through --exchange "
+                         "(default: the direct xGMI all-reduce kernel serves them, --exchange is the fallback)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -150,6 +153,12 @@ def main():
                     a.exchange = "torch"
             if a.exchange == "torch":
                 ex = sdist.Exchange(be, n_obs_local=N, device="cuda")
+            link = None
+            if world > 1 and not a.no_direct:
+                link = sdist.DirectLink(be)
+                if not link.active and rank == 0:
+                    print("[bench] direct all-reduce unavailable (peer mapping or self-test failed); collectives "
+                          f"use the {a.exchange} transport", file=sys.stderr, flush=True)
 
         opt = be.default_options()
         opt.ftol, opt.xtol, opt.gtol = 1e-10, 1e-8, 1e-8           # the reference's ftol, scipy defaults
@@ -213,7 +222,8 @@ def main():
             "ms_per_step": 1e3 * elapsed / steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64" if a.storage_bits == 64 else "f64 arithmetic, f32 storage", "data": "synthetic",
-            "transport": None if td is None else a.exchange,
+            "transport": None if td is None else (f"direct xGMI all-reduce kernel ({be.p2p_calls()} collectives; "
+                                                  f"fallback {a.exchange})" if be.p2p_calls() > 0 else a.exchange),
             "config": {"workload": f"{a.workload}: {C} cameras / {P} points / {N} observations per GPU shard, "
                                    f"shared cameras, seed 0 (SURVEY.md 8d generator)",
                        "solver": "TRF (scipy trf_no_bounds restated) + analytic Jacobian + Schur PCG, ftol=1e-10",

@@ -122,6 +122,21 @@ int  sfmba_comm_init(sfmba_handle* h, const void* id128, int32_t rank, int32_t w
                      int64_t n_obs_total);
 int  sfmba_comm_destroy(sfmba_handle* h);
 
+/* Direct all-reduce over peer-mapped device memory (xGMI inside a node), used in preference to RCCL or
+ * the callback for every exchanged vector once attached: the solver reduces a dozen small vectors (a few
+ * scalars to 27*n_cameras doubles) per iteration, which is latency, not bandwidth.  Collective set-up,
+ * after sfmba_set_problem and sfmba_comm_init / sfmba_set_exchange on every rank:
+ *   sfmba_p2p_export  allocates this rank's staging buffer and returns its 64-byte hipIpcMemHandle_t;
+ *   (the caller all-gathers the handles over any channel, rank order)
+ *   sfmba_p2p_attach  maps the peers' buffers and runs a two-round self-test all-reduce; returns -5
+ *                     and detaches when mapping or the self-test fails (the previous transport stays).
+ * All ranks must attach or none: agree on the minimum of the return codes and call sfmba_p2p_detach on
+ * every rank if any failed.  world <= 16.  Results are summed in rank order: bitwise equal on all ranks. */
+int  sfmba_p2p_export(sfmba_handle* h, int32_t world, void* handle64_out);
+int  sfmba_p2p_attach(sfmba_handle* h, const void* handles_world_x_64, int32_t rank, int32_t world);
+int  sfmba_p2p_detach(sfmba_handle* h);
+int64_t sfmba_p2p_calls(const sfmba_handle* h);      /* collectives served by the direct path so far */
+
 /* ---- compute_residuals (bundle_adjustment.py:35-42) ----------------------------------------- */
 /* x: (6C+3P) float64 -> r_out: (2N) float64, interleaved x,y in the caller's observation order. */
 int  sfmba_residuals(sfmba_handle* h, const double* x, double* r_out);

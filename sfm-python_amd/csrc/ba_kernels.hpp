@@ -1717,6 +1717,81 @@ __global__ void k_transpose6(const double* __restrict__ planes, int C, double* _
 }
 
 // streaming-store ceiling probe: 16 B per lane, grid-stride
+// ---------------------------------------------------------------------------------------------
+// Direct all-reduce over peer-mapped memory (xGMI).  The vectors this solver reduces are small (a few
+// scalars up to 27 C doubles) and there are a dozen of them per outer iteration, so latency is all that
+// matters.  Every rank owns a staging buffer that its peers map through hipIpc:
+//     flags[2][W] (one 128-byte line each)   data[2][W][stride]
+// One launch per collective: (1) every workgroup copies its slice of the local vector into slot
+// [parity][rank] of EVERY rank's buffer (remote stores travel the xGMI links in parallel); the last
+// workgroup to finish raises flag [parity][rank] = seq on every rank; (2) every workgroup waits until
+// all W flags of its own buffer carry seq and sums its slice over the W slots IN RANK ORDER, so all
+// ranks obtain bitwise the same result.  Parity alternates per performed call: a rank can only reach call
+// n+2 after every peer has finished reading call n.  The wait gives up after `timeout` ticks of the
+// 100 MHz wall clock and raises *error, so the grid always drains.
+// All ranks must issue the same sequence of calls (they do: the host loop is replicated).
+constexpr int kP2pMaxRanks = 16;
+constexpr int kP2pFlagStride = 16;            // uint64 words between two flags (128 bytes)
+constexpr int kP2pMaxBlocks = 32;             // waiting workgroups must all be resident
+struct P2pArgs {
+    double* data[kP2pMaxRanks];               // data region of every rank's staging buffer (own included)
+    unsigned long long* flags[kP2pMaxRanks];
+    int rank, world;
+    long long stride;                         // doubles per slot
+    unsigned long long* seq;                  // local: number of collectives performed so far (device-side, so that
+                                              // collectives cancelled on the device do not advance the parity)
+    const int* cancel;                        // optional: non-zero -> this collective is void on EVERY rank (it
+                                              // follows a PCG launch that did nothing); return at once
+    unsigned* ticket;                         // local: arrival counter of this launch's workgroups
+    unsigned* error;                          // local: set to 1 on timeout
+    long long timeout;
+};
+
+__global__ __launch_bounds__(256) void k_p2p_allreduce(double* __restrict__ vec, int count, int op, P2pArgs a) {
+    __shared__ unsigned s_last;
+    if (a.cancel != nullptr && *a.cancel != 0) return;        // grid-uniform, identical on all ranks
+    const int tid = threadIdx.x;
+    const unsigned long long seq = *a.seq + 1ull;             // the last workgroup to arrive publishes it
+    const int par = (int)(seq & 1ull);
+    const int per = (count + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int lo = (int)blockIdx.x * per, hi = min(count, lo + per);
+    for (int q = 0; q < a.world; ++q) {
+        double* dst = a.data[q] + ((size_t)par * a.world + a.rank) * a.stride;
+        for (int e = lo + tid; e < hi; e += blockDim.x)
+            __hip_atomic_store(dst + e, vec[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) s_last = (atomicAdd(a.ticket, 1u) == gridDim.x - 1) ? 1u : 0u;
+    __syncthreads();
+    if (s_last != 0u) {
+        __threadfence_system();
+        if (tid < a.world)
+            __hip_atomic_store(a.flags[tid] + ((size_t)par * a.world + a.rank) * kP2pFlagStride, seq,
+                               __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (tid == 0) { *a.ticket = 0u; *a.seq = seq; }
+    }
+    if (tid < a.world) {
+        const unsigned long long* f = a.flags[a.rank] + ((size_t)par * a.world + tid) * kP2pFlagStride;
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+            if (wall_clock64() - t0 > a.timeout) { atomicExch(a.error, 1u); break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    __syncthreads();
+    __threadfence_system();
+    const double* slots = a.data[a.rank] + (size_t)par * a.world * a.stride;
+    for (int e = lo + tid; e < hi; e += blockDim.x) {
+        double s = __hip_atomic_load(slots + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (int q = 1; q < a.world; ++q) {
+            const double v = __hip_atomic_load(slots + (size_t)q * a.stride + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            s = (op == 0) ? s + v : fmax(s, v);
+        }
+        vec[e] = s;
+    }
+}
+
 __global__ __launch_bounds__(1024) void k_fill16(double* __restrict__ a, int64_t n2, double v) {
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n2; e += (int64_t)gridDim.x * blockDim.x)
         *reinterpret_cast<double2*>(a + 2 * e) = make_double2(v, v + 1.0);

@@ -132,6 +132,19 @@ struct sfmba_handle {
     void* ar_ctx = nullptr;
     ncclComm_t comm = nullptr;               // native RCCL communicator (sfmba_comm_init)
     int64_t n_collectives = 0;
+    // direct all-reduce over peer-mapped staging buffers (k_p2p_allreduce); preferred over RCCL / the
+    // callback for every vector that fits a slot
+    struct P2p {
+        bool ready = false;
+        int rank = 0, world = 0;
+        int64_t stride = 0;                  // doubles per slot
+        void* own = nullptr;                 // this rank's staging buffer (flags, then data)
+        void* opened[kP2pMaxRanks] = {};     // peers' buffers as mapped here (null for own)
+        double* data[kP2pMaxRanks] = {};
+        unsigned long long* flags[kP2pMaxRanks] = {};
+        unsigned* words = nullptr;           // [0] ticket, [1] error, [2..3] uint64 count of performed collectives
+        int64_t calls = 0;
+    } p2p;
     double* h_scal = nullptr;                // pinned
     double* mbox = nullptr;                  // coherent pinned block the device posts the hand-off into (Mailbox)
     double* mbox_dev = nullptr;              // its device-visible address
@@ -195,7 +208,36 @@ int enter(sfmba_handle* h) {
 
 // All-reduce `count` doubles of the exchange arena in place over the ranks, on the handle's stream:
 // natively with RCCL when a communicator is set, else through the host callback, else a no-op.
-int exchange(sfmba_handle* h, double* ptr, int64_t count, int op) {
+void p2p_release(sfmba_handle* h);
+bool multi_rank(const sfmba_handle* h) { return h->p2p.ready || h->comm != nullptr || h->ar_fn != nullptr; }
+
+constexpr size_t kP2pFlagBytes = sizeof(unsigned long long) * 2 * kP2pMaxRanks * kP2pFlagStride;
+
+int p2p_allreduce(sfmba_handle* h, double* ptr, int64_t count, int op, const int* cancel) {
+    auto& p = h->p2p;
+    P2pArgs a{};
+    for (int q = 0; q < p.world; ++q) { a.data[q] = p.data[q]; a.flags[q] = p.flags[q]; }
+    a.rank = p.rank; a.world = p.world; a.stride = p.stride;
+    a.seq = reinterpret_cast<unsigned long long*>(p.words + 2);
+    a.cancel = cancel;
+    a.ticket = p.words; a.error = p.words + 1;
+    a.timeout = 300000000ll;                              // 3 s of the 100 MHz wall clock
+    const int grid = (int)std::min<int64_t>(kP2pMaxBlocks, std::max<int64_t>(1, (count + 511) / 512));
+    hipLaunchKernelGGL(k_p2p_allreduce, dim3(grid), dim3(256), 0, h->stream, ptr, (int)count, op, a);
+    HIPCHK(h, hipGetLastError());
+    ++p.calls;
+    return 0;
+}
+
+// `cancel` (device pointer, may be null): when it reads non-zero the collective is void on every rank -- it
+// follows a PCG launch that did nothing.  Only the direct path can act on it; RCCL and the callback reduce
+// the stale vector, which is harmless.
+int exchange(sfmba_handle* h, double* ptr, int64_t count, int op, const int* cancel = nullptr) {
+    if (h->p2p.ready && count <= h->p2p.stride) {
+        CHK(p2p_allreduce(h, ptr, count, op, cancel));
+        ++h->n_collectives;
+        return 0;
+    }
     if (h->comm) {
         RcclApi* api = rccl_api();
         const ncclResult_t rc = api->AllReduce(ptr, ptr, (size_t)count, ncclDouble, op == 0 ? ncclSum : ncclMax,
@@ -595,12 +637,14 @@ int pcg_enqueue(sfmba_handle* h, int count) {
         const int L = h->pcg_L;
         if (h->pcg_fused) {
             CHK(launch_pcg_fused(h, L));
-            CHK(exchange(h, h->acc() + (size_t)((L + 1) % 3) * 6 * h->C, 6 * h->C, 0));
+            // a launch that found the solve finished (or finished it) produced no product: its control block
+            // (written to slot (L+1)&1) says so
+            CHK(exchange(h, h->acc() + (size_t)((L + 1) % 3) * 6 * h->C, 6 * h->C, 0, &ctrl2[(L + 1) & 1].done));
             h->pcg_L = L + 1;
             continue;
         }
         CHK(launch_schur_sweep<0>(h, h->vecs.as<double>(), nullptr, ctrl2, L));
-        CHK(exchange(h, h->acc() + (size_t)(L & 1) * 6 * h->C, 6 * h->C, 0));   // set == L & 1 until done
+        CHK(exchange(h, h->acc() + (size_t)(L & 1) * 6 * h->C, 6 * h->C, 0, &ctrl2[L & 1].done));   // set == L & 1 until done
         hipLaunchKernelGGL(k_pcg_update, dim3(kPcgUpdateBlocks), dim3(1024), 0, h->stream, h->acc(),
                            h->Dc.as<double>(), h->Minv.as<double>(), (int)h->C, h->vecs.as<double>(), ctrl2, L);
         HIPCHK(h, hipGetLastError());
@@ -703,6 +747,7 @@ void sfmba_destroy(sfmba_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->comm) { if (RcclApi* api = rccl_api()) (void)api->CommDestroy(h->comm); h->comm = nullptr; }
+    p2p_release(h);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     if (h->h_scal) (void)hipHostFree(h->h_scal);
     if (h->mbox) (void)hipHostFree(h->mbox);
@@ -790,6 +835,108 @@ int sfmba_comm_destroy(sfmba_handle* h) {
     return 0;
 }
 
+// ---- direct all-reduce over peer-mapped memory ---------------------------------------------------------
+namespace {
+// unmap the peers; this rank's own buffer stays allocated (peers may still be storing into it)
+void p2p_close_peers(sfmba_handle* h) {
+    auto& p = h->p2p;
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (int q = 0; q < kP2pMaxRanks; ++q) {
+        if (p.opened[q]) (void)hipIpcCloseMemHandle(p.opened[q]);
+        p.opened[q] = nullptr; p.data[q] = nullptr; p.flags[q] = nullptr;
+    }
+    p.ready = false;
+}
+void p2p_release(sfmba_handle* h) {
+    auto& p = h->p2p;
+    p2p_close_peers(h);
+    if (p.own) (void)hipFree(p.own);
+    if (p.words) (void)hipFree(p.words);
+    p.own = nullptr; p.words = nullptr; p.ready = false; p.world = 0; p.stride = 0;
+}
+}  // namespace
+
+int sfmba_p2p_export(sfmba_handle* h, int32_t world, void* handle64_out) {
+    CHK(enter(h));
+    if (!h->have_problem) return fail(h, -1, "call sfmba_set_problem before sfmba_p2p_export");
+    if (!handle64_out || world < 1 || world > kP2pMaxRanks) return fail(h, -1, "bad arguments (1 <= world <= %d)", kP2pMaxRanks);
+    p2p_release(h);
+    auto& p = h->p2p;
+    p.world = world;
+    p.stride = (27 * h->C + 15) / 16 * 16;                // the largest vector exchanged: [U | g_c]
+    const size_t bytes = kP2pFlagBytes + sizeof(double) * 2 * (size_t)world * (size_t)p.stride;
+    // uncached device memory: remote stores land in HBM and local loads do not see stale cache lines
+    if (hipExtMallocWithFlags(&p.own, bytes, hipDeviceMallocUncached) != hipSuccess) {
+        p.own = nullptr; (void)hipGetLastError();
+        return fail(h, -5, "hipExtMallocWithFlags(uncached, %zu bytes) failed", bytes);
+    }
+    HIPCHK(h, hipMalloc((void**)&p.words, 4 * sizeof(unsigned)));
+    HIPCHK(h, hipMemset(p.own, 0, bytes));
+    HIPCHK(h, hipMemset(p.words, 0, 4 * sizeof(unsigned)));
+    HIPCHK(h, hipDeviceSynchronize());
+    hipIpcMemHandle_t mh;
+    if (hipIpcGetMemHandle(&mh, p.own) != hipSuccess) {
+        (void)hipGetLastError(); p2p_release(h);
+        return fail(h, -5, "hipIpcGetMemHandle failed");
+    }
+    static_assert(sizeof mh == 64, "hipIpcMemHandle_t is 64 bytes");
+    memcpy(handle64_out, &mh, sizeof mh);
+    return 0;
+}
+
+int sfmba_p2p_attach(sfmba_handle* h, const void* handles, int32_t rank, int32_t world) {
+    CHK(enter(h));
+    auto& p = h->p2p;
+    if (!p.own || world != p.world) return fail(h, -1, "sfmba_p2p_export(world) must precede sfmba_p2p_attach");
+    if (!handles || rank < 0 || rank >= world) return fail(h, -1, "bad arguments");
+    p.rank = rank;
+    for (int q = 0; q < world; ++q) {
+        void* base = p.own;
+        if (q != rank) {
+            hipIpcMemHandle_t mh;
+            memcpy(&mh, static_cast<const char*>(handles) + 64 * (size_t)q, sizeof mh);
+            if (hipIpcOpenMemHandle(&base, mh, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+                (void)hipGetLastError(); p2p_close_peers(h);
+                return fail(h, -5, "hipIpcOpenMemHandle failed for rank %d", q);
+            }
+            p.opened[q] = base;
+        }
+        p.flags[q] = static_cast<unsigned long long*>(base);
+        p.data[q] = reinterpret_cast<double*>(static_cast<char*>(base) + kP2pFlagBytes);
+    }
+    // Self-test, two rounds (both parities): rank r contributes (r+1)(i+1); the sum is exact in fp64.
+    const int nt = (int)std::min<int64_t>(6 * h->C, 2048);
+    std::vector<double> v(nt);
+    bool ok = true;
+    for (int round = 0; round < 2 && ok; ++round) {
+        for (int i = 0; i < nt; ++i) v[i] = (double)(rank + 1 + round) * (double)(i + 1);
+        HIPCHK(h, hipMemcpyAsync(h->acc(), v.data(), sizeof(double) * nt, hipMemcpyHostToDevice, h->stream));
+        CHK(p2p_allreduce(h, h->acc(), nt, 0, nullptr));
+        HIPCHK(h, hipMemcpyAsync(v.data(), h->acc(), sizeof(double) * nt, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        const double wsum = 0.5 * world * (world + 1) + (double)round * world;
+        for (int i = 0; i < nt; ++i) ok = ok && v[i] == wsum * (double)(i + 1);
+    }
+    unsigned words[2] = {0, 0};
+    HIPCHK(h, hipMemcpy(words, p.words, sizeof words, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemsetAsync(h->acc(), 0, sizeof(double) * nt, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (!ok || words[1] != 0) {
+        p2p_close_peers(h);                                // own buffer is freed by sfmba_p2p_detach, once all ranks agree
+        return fail(h, -5, "direct all-reduce self-test failed (%s)", words[1] ? "timeout waiting for a peer" : "wrong sum");
+    }
+    p.ready = true;
+    return 0;
+}
+
+int sfmba_p2p_detach(sfmba_handle* h) {
+    CHK(enter(h));
+    p2p_release(h);
+    return 0;
+}
+
+int64_t sfmba_p2p_calls(const sfmba_handle* h) { return h ? h->p2p.calls : 0; }
+
 int sfmba_set_problem(sfmba_handle* h, int64_t C, int64_t P, int64_t N, const int64_t* cam, const int64_t* pt,
                       const double* uv, const double* K) {
     CHK(enter(h));
@@ -810,6 +957,7 @@ int sfmba_set_problem(sfmba_handle* h, int64_t C, int64_t P, int64_t N, const in
         h->K.k[k] = K[k];
     }
     h->f32 = h->f32_next;
+    if (h->p2p.own && 27 * C > h->p2p.stride) p2p_release(h);     // slots too small for the new camera count
     h->C = C; h->P = P; h->N = N; h->n = 6 * C + 3 * P;
     h->N_total = N;
     h->ld = (N + 255) / 256 * 256;
@@ -1238,7 +1386,7 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
             // The cost reduction that ends the evaluation also posts the hand-off (scalars + PCG control
             // block) into the host mailbox; with several ranks the post follows the all-reduce of the cost.
             const Mailbox mb{h->mbox_dev, sc, h->ctrl.as<PcgCtrl>() + (h->pcg_L & 1), ++h->mbox_seq};
-            const bool ranks = h->comm != nullptr || h->ar_fn != nullptr;
+            const bool ranks = multi_rank(h);
             if (!ranks) h->post = mb;
             const int rc = eval_jac(h->x_new, h->tab_new, h->jcur, true);
             h->post = Mailbox{};
@@ -1371,7 +1519,14 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
 
     CHK(ensure_h_x(h));
     HIPCHK(h, hipMemcpyAsync(h->h_x, h->x, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+    if (h->p2p.ready)                                           // did a direct all-reduce give up waiting for a peer?
+        HIPCHK(h, hipMemcpyAsync(h->h_scal + 62, h->p2p.words + 1, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
     CHK(wait_stream(h));
+    if (h->p2p.ready) {
+        unsigned err = 0;
+        memcpy(&err, h->h_scal + 62, sizeof err);
+        if (err != 0) return fail(h, -5, "a direct all-reduce timed out waiting for a peer rank");
+    }
     memcpy(x_inout, h->h_x, sizeof(double) * n);
     const double t_end = now_s();
     if (!evs.empty()) {

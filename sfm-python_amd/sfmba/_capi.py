@@ -18,7 +18,8 @@ SYMBOLS = (
     "sfmba_set_problem", "sfmba_exchange_doubles", "sfmba_set_exchange", "sfmba_residuals",
     "sfmba_residual_jacobian", "sfmba_solve", "sfmba_get_fun_grad", "sfmba_time_kernel",
     "sfmba_normal_blocks", "sfmba_schur_matvec", "sfmba_comm_get_unique_id", "sfmba_comm_init",
-    "sfmba_comm_destroy", "sfmba_set_precision",
+    "sfmba_comm_destroy", "sfmba_set_precision", "sfmba_p2p_export", "sfmba_p2p_attach", "sfmba_p2p_detach",
+    "sfmba_p2p_calls",
 )
 
 
@@ -79,10 +80,16 @@ def load():
     lib.sfmba_comm_init.argtypes = [P, P, C.c_int32, C.c_int32, C.c_int64]
     lib.sfmba_comm_destroy.argtypes = [P]
     lib.sfmba_set_precision.argtypes = [P, C.c_int32]
+    lib.sfmba_p2p_export.argtypes = [P, C.c_int32, P]
+    lib.sfmba_p2p_attach.argtypes = [P, P, C.c_int32, C.c_int32]
+    lib.sfmba_p2p_detach.argtypes = [P]
+    lib.sfmba_p2p_calls.argtypes = [P]
+    lib.sfmba_p2p_calls.restype = C.c_int64
     for name in ("sfmba_set_stream", "sfmba_set_problem", "sfmba_set_exchange", "sfmba_residuals",
                  "sfmba_residual_jacobian", "sfmba_solve", "sfmba_get_fun_grad", "sfmba_time_kernel",
                  "sfmba_normal_blocks", "sfmba_schur_matvec", "sfmba_tr2d_solve", "sfmba_comm_get_unique_id",
-                 "sfmba_comm_init", "sfmba_comm_destroy", "sfmba_set_precision"):
+                 "sfmba_comm_init", "sfmba_comm_destroy", "sfmba_set_precision", "sfmba_p2p_export",
+                 "sfmba_p2p_attach", "sfmba_p2p_detach"):
         getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib

@@ -126,6 +126,26 @@ class Backend:
     def comm_destroy(self):
         self._check(self._lib.sfmba_comm_destroy(self._h))
 
+    # direct all-reduce over peer-mapped memory (include/sfmba.h: sfmba_p2p_*)
+    def p2p_export(self, world: int) -> bytes:
+        buf = C.create_string_buffer(64)
+        self._check(self._lib.sfmba_p2p_export(self._h, int(world), buf))
+        return buf.raw
+
+    def p2p_attach(self, handles: bytes, rank: int, world: int) -> int:
+        """Returns the C-ABI code (0 attached, -5 mapping or self-test failed) instead of raising: the
+        caller has to agree on the outcome with the other ranks first."""
+        if len(handles) != 64 * world:
+            raise ValueError("handles must hold world x 64 bytes")
+        buf = C.create_string_buffer(handles, len(handles))
+        return int(self._lib.sfmba_p2p_attach(self._h, buf, int(rank), int(world)))
+
+    def p2p_detach(self):
+        self._check(self._lib.sfmba_p2p_detach(self._h))
+
+    def p2p_calls(self) -> int:
+        return int(self._lib.sfmba_p2p_calls(self._h))
+
     # ------------------------------------------------------------------------------------------
     def residuals(self, x):
         x = _f64(x, (self.n_params,), "x")

@@ -133,3 +133,48 @@ class NativeComm:
         self.n_obs_total = int(round(float(tot.item())))
         self.rank, self.world = rank, world
         backend.comm_init(bytes(uid.cpu().numpy().tobytes()), rank, world, self.n_obs_total)
+
+
+class DirectLink:
+    """Latency path for the solver's collectives inside one node: every rank maps its peers' staging
+    buffers (hipIpc over ``torch.distributed`` as the bootstrap channel) and ``libsfmba.so`` all-reduces
+    with one small kernel per collective over xGMI instead of calling RCCL (``include/sfmba.h``:
+    ``sfmba_p2p_*``).  Create it AFTER :class:`NativeComm` or :class:`Exchange` (which stay as the
+    fallback transport and for vectors larger than a slot).  ``active`` is False when any rank could not
+    map a peer or failed the self-test: then every rank has detached and the previous transport serves.
+    ``SFMBA_P2P=0`` disables it."""
+
+    def __init__(self, backend, group=None):
+        import os
+        import torch
+        import torch.distributed as td
+        self.backend = backend
+        self.active = False
+        rank, world = td.get_rank(group), td.get_world_size(group)
+        if world < 2 or world > 16 or os.environ.get("SFMBA_P2P", "1") == "0":
+            return
+        dev = "cuda" if td.get_backend(group) == "nccl" else "cpu"
+        try:
+            mine, rc = backend.p2p_export(world), 0
+        except Exception:                                     # noqa: BLE001 -- agreed on below
+            mine, rc = bytes(64), -5
+        t = torch.frombuffer(bytearray(mine), dtype=torch.uint8).to(dev)
+        parts = [torch.zeros(64, dtype=torch.uint8, device=dev) for _ in range(world)]
+        td.all_gather(parts, t, group=group)
+        ok = torch.tensor([rc], dtype=torch.int32, device=dev)
+        td.all_reduce(ok, op=td.ReduceOp.MIN, group=group)
+        if int(ok.item()) == 0:
+            handles = b"".join(bytes(p.cpu().numpy().tobytes()) for p in parts)
+            rc = backend.p2p_attach(handles, rank, world)
+            ok = torch.tensor([rc], dtype=torch.int32, device=dev)
+            td.all_reduce(ok, op=td.ReduceOp.MIN, group=group)
+        if int(ok.item()) != 0:
+            backend.p2p_detach()
+            return
+        self.active = True
+
+    def close(self):
+        if self.active:
+            self.backend.p2p_detach()
+            self.active = False
+

@@ -557,7 +557,7 @@ def test_exchange_path_world1_nccl():
 
 # ---- a REAL two-rank run of the C++ solver: both ranks share the one GPU, collectives over gloo ------------
 
-def _two_rank_worker(rank, world, port, q):
+def _two_rank_worker(rank, world, port, q, direct=False):
     import torch
     import torch.distributed as td
     import sfmba
@@ -576,20 +576,68 @@ def _two_rank_worker(rank, world, port, q):
             be.set_stream(stream.cuda_stream)
             be.set_problem(*loc.args)
             ex = sdist.Exchange(be, n_obs_local=loc.n_obs, device="cuda")     # gloo all-reduces CUDA tensors
+            link = sdist.DirectLink(be) if direct else None                   # peers mapped through hipIpc
             opt = be.default_options()
             opt.ftol = 1e-10
             x, res, fun, grad = be.solve(loc.x0, opt)
             torch.cuda.synchronize()
+            x2 = be.solve(loc.x0, opt)[0] if direct else x                    # staging buffers are reusable
+        td.barrier()
+        direct_calls = be.p2p_calls()
+        if link is not None:
+            link_active = link.active
+            link.close()
+        else:
+            link_active = False
         xs = [None] * world
         td.all_gather_object(xs, x)
         if rank == 0:
             q.put(dict(x=sdist.merge_solutions(xs, shards, pb.n_cameras, pb.n_points),
                        cams_equal=all(np.array_equal(xi[:66], xs[0][:66]) for xi in xs),
                        status=int(res.status), nfev=int(res.nfev), cost=float(res.cost), rmse=float(res.rmse),
-                       calls=ex.n_calls))
+                       calls=ex.n_calls, direct_calls=direct_calls, link_active=link_active,
+                       again=float(np.abs(x2 - x).max())))
         be.close()
     finally:
         td.destroy_process_group()
+
+
+def _run_ranks(world, direct):
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, q, direct)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    return out
+
+
+def test_direct_allreduce_over_peer_mapped_memory():
+    """The latency path of the collectives (k_p2p_allreduce): ranks map each other's staging buffers through
+    hipIpc and all-reduce with one kernel per collective.  Here the ranks are 2 and 3 processes on the one
+    GPU (on a node they are one per GPU over xGMI; the code path is the same).  Every collective of the
+    solves must have gone through the direct path (the gloo callback stays registered but idle), cameras
+    bitwise replicated, result equal to the single-process solve."""
+    import sfmba
+    pb = sfmba.make_problem(11, 3000, 10000, seed=0)
+    ref = sfmba.least_squares(sfmba.compute_residuals, pb.x0, x_scale="jac", ftol=1e-10, method="trf",
+                              args=pb.args)
+    for world in (2, 3):
+        out = _run_ranks(world, direct=True)
+        assert out["link_active"], "peers could not be mapped or the self-test failed"
+        assert out["calls"] == 0 and out["direct_calls"] > 40
+        assert out["cams_equal"] and out["again"] <= 1e-7
+        assert (out["status"], out["nfev"]) == (ref.status, ref.nfev)
+        assert abs(out["cost"] - ref.cost) <= 1e-10 * ref.cost
+        assert np.abs(out["x"] - ref.x).max() <= 1e-6 * np.abs(ref.x).max()
 
 
 def test_two_rank_solve_on_one_gpu_gloo():
