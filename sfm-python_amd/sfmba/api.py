@@ -59,15 +59,8 @@ def _split_args(args):
     return args
 
 
-def create_sparsity_matrix(n_cameras, n_points, n_obs, camera_indices, point3d_indices,
-                           fixed_camera_indices=()):
-    """Same 0/1 ``lil_matrix`` (2 n_obs, 6 n_cameras + 3 n_points), dtype int, as the reference builds
-    with a Python loop (bundle_adjustment.py:9-15); built here from index arithmetic.  The solver only
-    reads its shape -- the block structure is implied by the index arrays."""
+def _build_sparsity(n_cameras, n_points, n_obs, ci, pi, fixed_camera_indices):
     from scipy.sparse import csr_matrix
-    ci = np.asarray(camera_indices, dtype=np.int64)
-    pi = np.asarray(point3d_indices, dtype=np.int64)
-    assert len(ci) == len(pi)
     fixed = np.isin(ci, np.asarray(list(fixed_camera_indices), dtype=np.int64))
     cols_c = ci[:, None] * 6 + np.arange(6)[None, :]
     cols_p = n_cameras * 6 + pi[:, None] * 3 + np.arange(3)[None, :]
@@ -81,6 +74,60 @@ def create_sparsity_matrix(n_cameras, n_points, n_obs, camera_indices, point3d_i
                    shape=(n_obs * 2, n_cameras * 6 + n_points * 3), dtype=int)
     M.data[:] = 1                                   # duplicated (cam, point) pairs still give 1
     return M.tolil()
+
+
+def _lazy_lil_class():
+    """lil_matrix whose row lists are built at first use.  The reference builds this matrix before every BA
+    call (sfm.py:264) only to hand it to ``least_squares``; this back end reads nothing but its shape, and
+    even the vectorised construction of 18 non-zeros per observation costs ~1.7 s at 1M observations -- five
+    hundred times the solve.  Anything that looks inside (``.rows``, ``.data``, conversions, arithmetic,
+    scipy's own ``least_squares``) triggers the construction and sees an ordinary ``lil_matrix``."""
+    global _LazyLil
+    if _LazyLil is None:
+        from scipy.sparse import lil_matrix
+
+        class LazyLil(lil_matrix):
+            def __init__(self, shape, builder):           # lil_matrix.__init__ is NOT called: no row lists yet
+                self._shape = (int(shape[0]), int(shape[1]))
+                self.dtype = np.dtype(int)
+                self.maxprint = 50
+                self._sfmba_builder = builder
+
+            def __getattr__(self, name):                  # only reached for attributes that do not exist yet
+                if name in ("rows", "data") and "_sfmba_builder" in self.__dict__:
+                    built = self.__dict__.pop("_sfmba_builder")()
+                    self.__dict__["rows"], self.__dict__["data"] = built.rows, built.data
+                    return self.__dict__[name]
+                raise AttributeError(name)
+
+            def __reduce__(self):                         # pickling / copy.deepcopy: as a plain lil_matrix
+                from scipy.sparse import lil_matrix as _lil
+                return (_lil, (self.tocsr(),))
+
+        _LazyLil = LazyLil
+    return _LazyLil
+
+
+_LazyLil = None
+
+
+def create_sparsity_matrix(n_cameras, n_points, n_obs, camera_indices, point3d_indices,
+                           fixed_camera_indices=(), lazy=True):
+    """Same 0/1 ``lil_matrix`` (2 n_obs, 6 n_cameras + 3 n_points), dtype int, as the reference builds
+    with a Python loop (bundle_adjustment.py:9-15); built here from index arithmetic, and (``lazy``) only
+    when something looks inside it: the solver reads its shape alone -- the block structure is implied by
+    the index arrays."""
+    ci = np.array(camera_indices, dtype=np.int64)           # copies: the pattern must not change if the
+    pi = np.array(point3d_indices, dtype=np.int64)          # caller's arrays do before it is built
+    assert len(ci) == len(pi)
+    fixed = tuple(fixed_camera_indices)
+
+    def build():
+        return _build_sparsity(n_cameras, n_points, n_obs, ci, pi, fixed)
+
+    if not lazy:
+        return build()
+    return _lazy_lil_class()((n_obs * 2, n_cameras * 6 + n_points * 3), build)
 
 
 def compute_residuals(x, n_cameras, n_points, camera_indices, point_indices, points_2d, K, device=0):

@@ -127,6 +127,38 @@ def test_create_sparsity_matrix_matches_reference_capture():
         assert np.all(M.data == 1)
 
 
+def test_sparsity_matrix_is_built_only_when_looked_into():
+    """The pattern object is a lil_matrix whose rows appear at first use (the solver reads its shape only):
+    equal to the eagerly built one, unaffected by later changes of the caller's index arrays, usable by
+    scipy itself, picklable."""
+    import copy
+    import pickle
+    import scipy.sparse as sp
+    from scipy.optimize import least_squares as scipy_least_squares
+    import sfmba
+    from oracle import ba_oracle as orc
+    pb = sfmba.make_problem(4, 30, 120, seed=11)
+    ci, pi = pb.camera_indices.copy(), pb.point_indices.copy()
+    eager = sfmba.create_sparsity_matrix(4, 30, 120, ci, pi, lazy=False)
+    assert type(eager) is sp.lil_matrix
+    lazy = sfmba.create_sparsity_matrix(4, 30, 120, ci, pi)
+    assert isinstance(lazy, sp.lil_matrix) and sp.issparse(lazy) and lazy.format == "lil"
+    assert lazy.shape == eager.shape and lazy.dtype == eager.dtype
+    assert "rows" not in lazy.__dict__                     # nothing built so far
+    ci[:] = 0                                              # the caller's arrays change afterwards
+    assert (lazy.tocsr() != eager.tocsr()).nnz == 0 and "rows" in lazy.__dict__
+    for clone in (pickle.loads(pickle.dumps(sfmba.create_sparsity_matrix(4, 30, 120, pb.camera_indices, pi))),
+                  copy.deepcopy(sfmba.create_sparsity_matrix(4, 30, 120, pb.camera_indices, pi))):
+        assert type(clone) is sp.lil_matrix and (clone.tocsr() != eager.tocsr()).nnz == 0
+    # scipy's own driver takes it as jac_sparsity (this is the reference's call with the CPU residual)
+    S = sfmba.create_sparsity_matrix(4, 30, 120, pb.camera_indices, pb.point_indices)
+    a = scipy_least_squares(orc.compute_residuals, pb.x0, jac_sparsity=S, x_scale="jac", ftol=1e-10,
+                            method="trf", args=pb.args, max_nfev=5)
+    b = scipy_least_squares(orc.compute_residuals, pb.x0, jac_sparsity=eager, x_scale="jac", ftol=1e-10,
+                            method="trf", args=pb.args, max_nfev=5)
+    assert a.nfev == b.nfev and np.array_equal(a.x, b.x)
+
+
 def test_pack_unpack_mirror_matches_scipy_rotations():
     import sfmba
     g = np.load(os.path.join(GOLDEN, "pack_cases.npz"))
