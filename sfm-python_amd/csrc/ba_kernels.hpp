@@ -112,6 +112,45 @@ __device__ __forceinline__ void block_sum(double (&v)[NQ], double* red) {
     }
 }
 
+constexpr int kNQ = 9;
+
+// Final sums of partial rows.  One wave per quantity; quantity k < first_sum is a max, else a sum;
+// slice y covers the partial rows [row0[y], row0[y] + nrows[y]) and writes quantity k to
+// out[slot[y][k]] (slot < 0: not written).  Fixed lane->row mapping: deterministic.
+struct FinishJob { int row0[2], nrows[2], slot[2][kNQ]; };
+
+__device__ __forceinline__ void finish_task(const double* __restrict__ part, const FinishJob& job, int y, int k,
+                                            int nq, int first_sum, double* __restrict__ out) {     // one wave
+    const int lane = threadIdx.x & 63;
+    const double* __restrict__ rows = part + (size_t)job.row0[y] * nq;
+    const int nparts = job.nrows[y];
+    double s = 0.0;
+    if (k < first_sum) {
+        for (int b = lane; b < nparts; b += 64) s = fmax(s, rows[(size_t)b * nq + k]);
+        s = wave_max(s);
+    } else {
+        for (int b = lane; b < nparts; b += 64) s += rows[(size_t)b * nq + k];
+        s = wave_sum(s);
+    }
+    const int dst = job.slot[y][k];
+    if (lane == 0 && dst >= 0) out[dst] = s;
+}
+
+// A finish job that rides along with another launch instead of being a ~5 us launch of its own: the
+// host appends ONE workgroup to the grid of a kernel that neither reads nor writes what the job touches,
+// and that workgroup does nothing but these sums (its waves share the ny x nq reductions).
+struct Piggyback {
+    const double* __restrict__ part;      // null: no rider
+    double* __restrict__ out;
+    FinishJob job;
+    int ny, nq, first_sum;
+};
+__device__ __forceinline__ void finish_in_block(const Piggyback& pb) {
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int t = w; t < pb.ny * pb.nq; t += nw)
+        finish_task(pb.part, pb.job, t / pb.nq, t % pb.nq, pb.nq, pb.first_sum, pb.out);
+}
+
 // Segmented reduction over a wave whose keys are sorted: afterwards the first lane of every run of
 // equal keys holds the sum over its run.  All 64 lanes must call it.
 template <int NV>
@@ -194,7 +233,12 @@ __global__ void k_cam_table(const double* __restrict__ xc, int C, double* __rest
 // the 2-D model from the (rank-reduced) exchange scalars and solves it for the radius the host passed.
 // sc[25..31] = c1, c2, predicted reduction, |step_h|, |step|, skip flag, Delta used (slots 16..24 hold the
 // camera-slice sums).
-__global__ void k_tr_step(double* __restrict__ sc, double Delta, const PcgCtrl* __restrict__ ctrl) {
+__global__ void k_tr_step(double* __restrict__ sc, double Delta, const PcgCtrl* __restrict__ ctrl,
+                          Piggyback pb) {
+    if (pb.part != nullptr) {            // the last reduction the model needs (k_vec_reduce's sums), done here
+        finish_in_block(pb);
+        __syncthreads();
+    }
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     // The step is only meaningful when the speculatively enqueued PCG iterations sufficed.  If they did
     // not, raise the skip flag: every kernel of the trial evaluation behind this one returns at once,
@@ -698,12 +742,10 @@ __global__ __launch_bounds__(1024) void k_reduce_tables(const double* __restrict
 // [0, bc) of the grid cover the cameras, blocks [bc, grid) the points; one partial row per block.
 //   q0 = max|g|   q1 = sum (g/si)^2   q2 = sum (x si)^2   q3 = sum x^2   q4 = sum (g/si^2)^2
 //   q5 = sum g p  q6 = sum (p si)^2   q7 = sum (g/si^2) p q8 = sum p^2
-constexpr int kNQ = 9;
-
-__device__ __forceinline__ void slice_of_block(int bc, int64_t n6, int64_t n, int64_t& e0, int64_t& e1,
-                                               int& b, int& nb) {
+__device__ __forceinline__ void slice_of_block(int bc, int nblocks, int64_t n6, int64_t n, int64_t& e0,
+                                               int64_t& e1, int& b, int& nb) {
     if ((int)blockIdx.x < bc) { e0 = 0; e1 = n6; b = blockIdx.x; nb = bc; }
-    else { e0 = n6; e1 = n; b = blockIdx.x - bc; nb = gridDim.x - bc; }
+    else { e0 = n6; e1 = n; b = blockIdx.x - bc; nb = nblocks - bc; }
 }
 
 __device__ __forceinline__ void write_partials(double (&q)[kNQ], double* __restrict__ part) {
@@ -736,7 +778,7 @@ __global__ __launch_bounds__(256) void k_update_scale(const double* __restrict__
     const int diagV[3] = {0, 3, 5};
     int64_t e0, e1;
     int b, nb;
-    slice_of_block(bc, n6, n, e0, e1, b, nb);
+    slice_of_block(bc, (int)gridDim.x, n6, n, e0, e1, b, nb);
     double q[kNQ];
 #pragma unroll
     for (int k = 0; k < kNQ; ++k) q[k] = 0.0;
@@ -772,11 +814,13 @@ __global__ __launch_bounds__(256) void k_vec_reduce(const double* __restrict__ g
                                                     const double* __restrict__ x,
                                                     const double* __restrict__ sg,
                                                     const double* __restrict__ p, int C, int P, int bc,
-                                                    double* __restrict__ part) {
+                                                    double* __restrict__ part, Piggyback pb) {
+    const int nwork = pb.part != nullptr ? (int)gridDim.x - 1 : (int)gridDim.x;
+    if ((int)blockIdx.x == nwork) { finish_in_block(pb); return; }      // rider block: another kernel's sums
     const int64_t n6 = 6 * (int64_t)C, n = n6 + 3 * (int64_t)P;
     int64_t e0, e1;
     int b, nb;
-    slice_of_block(bc, n6, n, e0, e1, b, nb);
+    slice_of_block(bc, nwork, n6, n, e0, e1, b, nb);
     double q[kNQ];
 #pragma unroll
     for (int k = 0; k < kNQ; ++k) q[k] = 0.0;
@@ -795,10 +839,6 @@ __global__ __launch_bounds__(256) void k_vec_reduce(const double* __restrict__ g
     write_partials(q, part);
 }
 
-// Final sums of partial rows.  One wave per quantity; quantity k < first_sum is a max, else a sum;
-// block y handles the partial rows [row0[y], row0[y] + nrows[y]) and writes quantity k to
-// out[slot[y][k]] (slot < 0: not written).  Fixed lane->row mapping: deterministic.
-struct FinishJob { int row0[2], nrows[2], slot[2][kNQ]; };
 //
 // Mailbox: the hand-off of an outer iteration.  One wave copies the 32 exchange scalars and the PCG
 // control block into coherent host memory and raises a sequence number behind them; the host polls
@@ -833,21 +873,8 @@ __global__ void k_finish(const double* __restrict__ part, FinishJob job, int nq,
         if (mb.host != nullptr && blockIdx.x == 0 && threadIdx.x < 64) post_mailbox(mb);
         return;
     }
-    const int y = blockIdx.x;
-    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (k >= nq) return;
-    const double* __restrict__ rows = part + (size_t)job.row0[y] * nq;
-    const int nparts = job.nrows[y];
-    double s = 0.0;
-    if (k < first_sum) {
-        for (int b = lane; b < nparts; b += 64) s = fmax(s, rows[(size_t)b * nq + k]);
-        s = wave_max(s);
-    } else {
-        for (int b = lane; b < nparts; b += 64) s += rows[(size_t)b * nq + k];
-        s = wave_sum(s);
-    }
-    const int dst = job.slot[y][k];
-    if (lane == 0 && dst >= 0) out[dst] = s;
+    const int k = threadIdx.x >> 6;
+    if (k < nq) finish_task(part, job, (int)blockIdx.x, k, nq, first_sum, out);
     if (mb.host != nullptr) {                      // single block (the host launches it that way)
         __syncthreads();
         if (threadIdx.x < 64) post_mailbox(mb);
@@ -860,16 +887,18 @@ template <bool LDS_VEC>
 __global__ __launch_bounds__(kSweepThreads) void k_jdot(ObsArrays o, const double* __restrict__ sgc,
                                                         const double* __restrict__ sgp, int N, int C,
                                                         double* __restrict__ t1,
-                                                        double* __restrict__ part) {
+                                                        double* __restrict__ part, Piggyback pb) {
     extern __shared__ __align__(16) double smem[];
     __shared__ double red[kWavesPerSweepBlock];
+    const int nwork = pb.part != nullptr ? (int)gridDim.x - 1 : (int)gridDim.x;
+    if ((int)blockIdx.x == nwork) { finish_in_block(pb); return; }      // rider block: another kernel's sums
     if (LDS_VEC) {
         for (int i = threadIdx.x; i < 6 * C; i += blockDim.x) smem[i] = sgc[i];
         __syncthreads();
     }
     const double* __restrict__ vc = LDS_VEC ? smem : sgc;
     double acc = 0.0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += nwork * blockDim.x) {
         double jc[12], jp[6];
         load_blocks(o, i, jc, jp);
         const double* a = vc + 6 * o.cam_idx[i];
@@ -913,9 +942,10 @@ __device__ __forceinline__ void chol3_inverse(const double* a /*upper 6*/, doubl
 
 // Regularisation of the damped Gauss-Newton step from the 1-D Cauchy problem along -g_h
 // (SCIPY trf.py:471-475, common.py:251-322), evaluated from the exchange scalars by whoever needs it.
-__device__ __forceinline__ double reg_from_scalars(const double* __restrict__ sc, double Delta, double reg_min) {
+__device__ __forceinline__ double reg_from_scalars(const double* __restrict__ sc, double G11, double Delta,
+                                                   double reg_min) {
     const double a11 = sc[8] + sc[16 + 1];          // |g_h|^2: point slice (summed over ranks) + cameras
-    const double a = 0.5 * sc[1], b = -a11;         // sc[1] = G11 = |J_h g_h|^2
+    const double a = 0.5 * G11, b = -a11;           // G11 = |J_h g_h|^2
     double reg = reg_min;
     if (a11 > 0.0) {
         const double to_tr = Delta / sqrt(a11);
@@ -1045,8 +1075,22 @@ __global__ __launch_bounds__(64) void k_prep(double* __restrict__ sc, double Del
                                              const double* __restrict__ gp, const double* __restrict__ si,
                                              int C, int P, int bc, double* __restrict__ Dc,
                                              double* __restrict__ Minv, double* __restrict__ acc0,
-                                             double* __restrict__ Vinv, double* __restrict__ e) {
-    const double reg = reg_from_scalars(sc, Delta, reg_min);
+                                             double* __restrict__ Vinv, double* __restrict__ e,
+                                             const double* __restrict__ jd_part, int jd_n) {
+    // G11 = |J D^2 g|^2: either already in slot 1 (k_finish, then all-reduced over ranks) or summed here from
+    // k_jdot's per-workgroup partials -- every workgroup (one wave) repeats the same 256-term sum in
+    // k_finish's order, which is cheaper than a launch in between
+    double G11;
+    if (jd_part != nullptr) {
+        double s = 0.0;
+        for (int b = threadIdx.x; b < jd_n; b += 64) s += jd_part[b];
+        G11 = wave_sum(s);
+        G11 = __shfl(G11, 0);
+        if (blockIdx.x == 0 && threadIdx.x == 0) sc[1] = G11;
+    } else {
+        G11 = sc[1];
+    }
+    const double reg = reg_from_scalars(sc, G11, Delta, reg_min);
     if (blockIdx.x == 0 && threadIdx.x == 0) sc[13] = reg;
     if ((int)blockIdx.x < bc) {
         const int c = blockIdx.x * blockDim.x + threadIdx.x;

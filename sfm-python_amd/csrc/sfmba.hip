@@ -41,6 +41,10 @@ constexpr size_t kLdsDynMax = kLdsBytes - 512; // dynamic part; every kernel her
 //   device-local      [13]   : regularisation term of this iteration (k_prep)
 //   never exchanged   [16..24]: q0..q8 of the camera slice (replicated on every rank)
 constexpr int kScalSlots = 32;
+// Per-workgroup partial sums live in two halves of one buffer: A (k_update_scale, k_vec_reduce, the cost of
+// k_resjac) and B (k_jdot, k_backsub).  Consecutive producers alternate halves, so the final sums of one
+// producer can ride along with the NEXT producer's launch (Piggyback) without a race on the rows.
+constexpr int kPartRows = 2048;
 constexpr int kMaxSlot = 12, kRegSlot = 13, kCamSlot = 16;
 constexpr int kPointSlot[9] = {12, 8, 9, 10, 11, 4, 5, 6, 7};     // slot of q0..q8 of the point slice
 
@@ -171,6 +175,8 @@ struct sfmba_handle {
     double* scal() const { return arena + 45 * C; }
     int pcg_L = 0;                           // launches (sweep+update pairs) since pcg_start
     int red_bc = 1, red_grid = 2;            // block split of the parameter-vector reductions
+    double* partB() const { return part.as<double>() + (size_t)kPartRows * kNQ; }
+    bool pending_scale_sums = false;         // k_update_scale ran, its final sums ride with the next k_jdot
 };
 
 namespace {
@@ -389,7 +395,7 @@ int launch_finish(sfmba_handle* h, const double* part, int nparts, int nq, int s
 
 // the two-slice (cameras | points) reductions of k_update_scale / k_vec_reduce; the point slice
 // publishes only quantities [q_lo, q_hi] (the others keep their already rank-reduced values)
-int launch_finish_slices(sfmba_handle* h, int q_lo, int q_hi) {
+FinishJob slices_job(const sfmba_handle* h, int q_lo, int q_hi) {
     FinishJob job{};
     job.row0[0] = 0;         job.nrows[0] = h->red_bc;
     job.row0[1] = h->red_bc; job.nrows[1] = h->red_grid - h->red_bc;
@@ -397,6 +403,14 @@ int launch_finish_slices(sfmba_handle* h, int q_lo, int q_hi) {
         job.slot[0][k] = kCamSlot + k;
         job.slot[1][k] = (k >= q_lo && k <= q_hi) ? kPointSlot[k] : -1;
     }
+    return job;
+}
+Piggyback slices_rider(sfmba_handle* h, int q_lo, int q_hi) {
+    return Piggyback{h->part.as<double>(), h->scal(), slices_job(h, q_lo, q_hi), 2, kNQ, 1};
+}
+
+int launch_finish_slices(sfmba_handle* h, int q_lo, int q_hi) {
+    const FinishJob job = slices_job(h, q_lo, q_hi);
     hipLaunchKernelGGL(k_finish, dim3(2), dim3(64 * kNQ), 0, h->stream, h->part.as<double>(), job, kNQ, 1, h->scal(),
                        (const double*)nullptr, Mailbox{});
     HIPCHK(h, hipGetLastError());
@@ -484,21 +498,26 @@ int launch_schur_sweep(sfmba_handle* h, const double* vin, const double* zin, co
     return 0;
 }
 
+// partials -> half B.  When k_update_scale's final sums are still pending they ride along (one extra workgroup).
 int launch_jdot(sfmba_handle* h, int* nparts) {
     const int grid = grid_1d(h->N, kSweepThreads, h->n_cu);
     const double* sgc = h->sg.as<double>();
     const double* sgp = sgc + 6 * h->C;
+    Piggyback pb{};
+    if (h->pending_scale_sums) pb = slices_rider(h, 0, 4);
+    const int launch_grid = grid + (pb.part != nullptr ? 1 : 0);
     if (h->lds_vec) {
         const size_t lds = sizeof(double) * 6 * h->C;
         auto kern = k_jdot<true>;
         CHK(set_lds(h, kern, lds));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), lds, h->stream, obs_arrays(h), sgc, sgp,
-                           (int)h->N, (int)h->C, h->t1.as<double>(), h->part.as<double>());
+        hipLaunchKernelGGL(kern, dim3(launch_grid), dim3(kSweepThreads), lds, h->stream, obs_arrays(h), sgc, sgp,
+                           (int)h->N, (int)h->C, h->t1.as<double>(), h->partB(), pb);
     } else {
-        hipLaunchKernelGGL(k_jdot<false>, dim3(grid), dim3(kSweepThreads), 0, h->stream, obs_arrays(h),
-                           sgc, sgp, (int)h->N, (int)h->C, h->t1.as<double>(), h->part.as<double>());
+        hipLaunchKernelGGL(k_jdot<false>, dim3(launch_grid), dim3(kSweepThreads), 0, h->stream, obs_arrays(h),
+                           sgc, sgp, (int)h->N, (int)h->C, h->t1.as<double>(), h->partB(), pb);
     }
     HIPCHK(h, hipGetLastError());
+    h->pending_scale_sums = false;
     *nparts = grid;
     return 0;
 }
@@ -514,7 +533,7 @@ int launch_backsub(sfmba_handle* h, int* nparts) {
         CHK(set_lds(h, kern, lds));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), lds, h->stream, h->ranges.as<int2>(),
                            h->n_ranges, obs_arrays(h), h->vecs.as<double>(), dc, h->Vinv.as<double>(),
-                           h->gp.as<double>(), h->t1.as<double>(), dp, h->part.as<double>(), (int)h->C,
+                           h->gp.as<double>(), h->t1.as<double>(), dp, h->partB(), (int)h->C,
                            ctrl2, h->pcg_L);
     } else {
         hipLaunchKernelGGL(k_transpose6, dim3((6 * h->C + 255) / 256), dim3(256), 0, h->stream,
@@ -522,7 +541,7 @@ int launch_backsub(sfmba_handle* h, int* nparts) {
         hipLaunchKernelGGL(k_backsub<false>, dim3(grid), dim3(kSweepThreads), 0, h->stream,
                            h->ranges.as<int2>(), h->n_ranges, obs_arrays(h), h->vecs.as<double>(), dc,
                            h->Vinv.as<double>(), h->gp.as<double>(), h->t1.as<double>(), dp,
-                           h->part.as<double>(), (int)h->C, (const PcgCtrl*)nullptr, 0);
+                           h->partB(), (int)h->C, (const PcgCtrl*)nullptr, 0);
     }
     HIPCHK(h, hipGetLastError());
     *nparts = grid;
@@ -530,25 +549,37 @@ int launch_backsub(sfmba_handle* h, int* nparts) {
 }
 
 // column scale + gradient + q0..q4 of the new iterate (after the normal blocks are complete)
-int launch_update_scale(sfmba_handle* h, int first) {
+// `defer`: the final sums are left to ride with the next k_jdot launch (flush_scale_sums if none follows)
+int launch_update_scale(sfmba_handle* h, int first, bool defer = false) {
     hipLaunchKernelGGL(k_update_scale, dim3(h->red_grid), dim3(256), 0, h->stream, h->Ugc(), h->V.as<double>(),
                        h->gp.as<double>(), h->x, (int)h->C, (int)h->P, first, h->red_bc, h->si.as<double>(),
                        h->g.as<double>(), h->sg.as<double>(), h->part.as<double>());
     HIPCHK(h, hipGetLastError());
+    if (defer) { h->pending_scale_sums = true; return 0; }
     return launch_finish_slices(h, 0, 4);
 }
 
 // q0..q8 with the step vector p
-int launch_vec_reduce(sfmba_handle* h) {
-    hipLaunchKernelGGL(k_vec_reduce, dim3(h->red_grid), dim3(256), 0, h->stream, h->g.as<double>(),
+// One extra workgroup carries k_backsub's final sums (G12, G22: `nparts_backsub` rows of half B -> slots 2, 3).
+// `finish_own`: launch the final sums of this kernel too; otherwise k_tr_step does them (single rank).
+int launch_vec_reduce(sfmba_handle* h, int nparts_backsub, bool finish_own) {
+    Piggyback pb{h->partB(), h->scal(), FinishJob{}, 1, 2, 0};
+    pb.job.row0[0] = 0; pb.job.nrows[0] = nparts_backsub;
+    for (int k = 0; k < kNQ; ++k) { pb.job.slot[0][k] = 2 + k; pb.job.slot[1][k] = -1; }
+    hipLaunchKernelGGL(k_vec_reduce, dim3(h->red_grid + 1), dim3(256), 0, h->stream, h->g.as<double>(),
                        h->si.as<double>(), h->x, h->sg.as<double>(), h->p.as<double>(), (int)h->C, (int)h->P,
-                       h->red_bc, h->part.as<double>());
+                       h->red_bc, h->part.as<double>(), pb);
     HIPCHK(h, hipGetLastError());
-    return launch_finish_slices(h, 5, 8);
+    return finish_own ? launch_finish_slices(h, 5, 8) : 0;
 }
 
 // all-reduce freshly written exchange scalars over ranks (no-op on one GPU); stays on the stream.
 // Only slots written since their last reduction may be included.
+int flush_scale_sums(sfmba_handle* h) {         // no k_jdot follows the last k_update_scale: finish on its own
+    if (!h->pending_scale_sums) return 0;
+    h->pending_scale_sums = false;
+    return launch_finish_slices(h, 0, 4);
+}
 int exchange_linearise(sfmba_handle* h) {       // q1..q4 and max|g| of the point slice
     CHK(exchange(h, h->scal() + 8, 4, 0));
     CHK(exchange(h, h->scal() + kMaxSlot, 1, 1));
@@ -1069,7 +1100,7 @@ int sfmba_set_problem(sfmba_handle* h, int64_t C, int64_t P, int64_t N, const in
     HIPCHK(h, h->vcm.ensure(sizeof(double) * 6 * C));
     h->red_bc = grid_1d(6 * C, 256, 32);
     h->red_grid = h->red_bc + grid_1d(3 * P, 256, 992);
-    HIPCHK(h, h->part.ensure(sizeof(double) * (size_t)(2048 * kNQ)));
+    HIPCHK(h, h->part.ensure(sizeof(double) * (size_t)(2 * kPartRows * kNQ)));
     HIPCHK(h, h->ctrl.ensure(2 * sizeof(PcgCtrl)));
     if (h->nb_passes > 0) {
         const int per = (27 + h->nb_passes - 1) / h->nb_passes;
@@ -1268,6 +1299,7 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
     memset(out, 0, sizeof *out);
     h->solved = false;
     h->skip = nullptr; h->post = Mailbox{};
+    h->pending_scale_sums = false;
     const double t_begin = now_s();
     const int64_t C = h->C, P = h->P, n = h->n;
     const int64_t max_nfev = opt.max_nfev > 0 ? opt.max_nfev : 100 * (6 * C + 3 * P);
@@ -1341,16 +1373,25 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
             nb_valid = true;
         }
         // ---- enqueue the whole linear phase ---------------------------------------------------
+        // Final sums of per-workgroup partials are not launches of their own where a neighbour can carry
+        // them: k_update_scale's ride with k_jdot, k_backsub's with k_vec_reduce; on a single rank k_jdot's
+        // are repeated by every workgroup of k_prep and k_vec_reduce's are done by k_tr_step (with several
+        // ranks the all-reduce has to sit between producer and consumer, so those two stay launches).
+        const bool one_rank = !multi_rank(h);
         int np = 0;
+        const bool scale_sums_rode = h->pending_scale_sums;
         CHK(launch_jdot(h, &np));                               // t1 = J D^2 g, G11 = |t1|^2
-        CHK(launch_finish(h, h->part.as<double>(), np, 1, 1));
-        CHK(exchange(h, sc + 1, 1, 0));
+        if (scale_sums_rode) CHK(exchange_linearise(h));        // q1..q4, max|g| of the accepted point
+        if (!one_rank) {
+            CHK(launch_finish(h, h->partB(), np, 1, 1));
+            CHK(exchange(h, sc + 1, 1, 0));
+        }
         {   // regularisation (trf.py:471-475), Vinv/e per point, Dc/Minv per camera, acc0 = 0: one launch
             const int bc = (int)((C + 63) / 64), bp = (int)((P + 63) / 64);
             hipLaunchKernelGGL(k_prep, dim3(bc + bp), dim3(64), 0, h->stream, sc, Delta, opt.reg_min, h->Ugc(),
                                h->V.as<double>(), h->gp.as<double>(), h->si.as<double>(), (int)C, (int)P, bc,
                                h->Dc.as<double>(), h->Minv.as<double>(), h->acc(), h->Vinv.as<double>(),
-                               h->e.as<double>());
+                               h->e.as<double>(), one_rank ? (const double*)h->partB() : (const double*)nullptr, np);
             HIPCHK(h, hipGetLastError());
         }
         CHK(launch_schur_sweep<1>(h, nullptr, h->e.as<double>(), nullptr, 0));   // reduced rhs -> acc0
@@ -1364,14 +1405,15 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
         } else {
             CHK(pcg_finish_polling(h, opt, &hc));
         }
-        auto tail = [&]() -> int {                              // back-substitution + model products
+        // back-substitution + model products; `for_device_step`: k_tr_step follows and (single rank) does
+        // k_vec_reduce's final sums itself
+        auto tail = [&](bool for_device_step) -> int {
             CHK(launch_backsub(h, &np));
-            CHK(launch_finish(h, h->part.as<double>(), np, 2, 2));
-            CHK(launch_vec_reduce(h));
+            CHK(launch_vec_reduce(h, np, !(for_device_step && one_rank)));
             CHK(exchange_tail(h));
             return 0;
         };
-        CHK(tail());
+        CHK(tail(true));
 
         // ---- the first trial step is decided ON THE DEVICE (k_tr_step) and evaluated right away -------
         // so that an outer iteration hands control to the host ONCE, after the trial cost is known.
@@ -1412,8 +1454,9 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
             return 0;
         };
         const bool speculative = pcg_guess > 0;
-        hipLaunchKernelGGL(k_tr_step, dim3(1), dim3(64), 0, h->stream, sc, Delta,
-                           speculative ? (const PcgCtrl*)(h->ctrl.as<PcgCtrl>() + (h->pcg_L & 1)) : (const PcgCtrl*)nullptr);
+        hipLaunchKernelGGL(k_tr_step, dim3(1), dim3(one_rank ? 1024 : 64), 0, h->stream, sc, Delta,
+                           speculative ? (const PcgCtrl*)(h->ctrl.as<PcgCtrl>() + (h->pcg_L & 1)) : (const PcgCtrl*)nullptr,
+                           one_rank ? slices_rider(h, 5, 8) : Piggyback{});
         HIPCHK(h, hipGetLastError());
         h->skip = sc + 30;                                      // k_tr_step's verdict gates every launch below
         int rc_trial = enqueue_trial(sc + 25, 0.0, 0.0);
@@ -1432,7 +1475,7 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
                 evs.pop_back();
             }
             CHK(pcg_finish_polling(h, opt, &hc));
-            CHK(tail());
+            CHK(tail(false));
             CHK(fetch_scalars(h));
             first_trial_ready = false;
         }
@@ -1497,14 +1540,18 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
                                                                 // point are already there / in flight
             cost = cost_new;
             ++njev;
-            CHK(launch_update_scale(h, 0));                     // enqueued only; read with the next hand-off
-            CHK(exchange_linearise(h));
+            CHK(launch_update_scale(h, 0, /*defer=*/true));     // its final sums ride with the next k_jdot and
+                                                                // are read with the next hand-off
         } else {
             step_norm = 0.0;
             actual_reduction = 0.0;
         }
         ++iteration;
         if (status != -1) {                                     // terminated inside the step loop
+            if (h->pending_scale_sums) {                        // no k_jdot follows
+                CHK(flush_scale_sums(h));
+                CHK(exchange_linearise(h));
+            }
             CHK(fetch_scalars(h));
             g_norm = std::max(h->h_scal[kMaxSlot], h->h_scal[kCamSlot + 0]);
             if (opt.verbose >= 2) print_iter(iteration, nfev, cost, have_red, actual_reduction, step_norm, g_norm);
