@@ -152,7 +152,31 @@ __device__ __forceinline__ void finish_in_block(const Piggyback& pb) {
 }
 
 // Segmented reduction over a wave whose keys are sorted: afterwards the first lane of every run of
-// equal keys holds the sum over its run.  All 64 lanes must call it.
+// equal keys holds the sum over its run (other lanes: partial sums).  All 64 lanes must call it.
+//
+// Cross-lane traffic goes through DPP and v_readlane, i.e. the VALU, not through ds_bpermute: the sweeps
+// already load the LDS pipe with per-camera gathers and ds_add_f64, and the 6 x (1 + 2 NV) bpermutes of a
+// shuffle-based reduction came to more LDS-pipe time than everything else in those kernels together.
+//   rows of 16 lanes: suffix sums by row_shl:1,2,4,8 (lane i reads lane i+n of its row); a lane adds only
+//   when the key n lanes up equals its own -- keys are sorted, so everything between belongs to the run;
+//   across rows: from the top row down, the first lane of the next row (by then complete) is broadcast with
+//   v_readlane and added by the lanes of this row that carry its key.
+template <int CTRL>
+__device__ __forceinline__ int dpp_int(int x) {        // source lane out of the row: 0
+    return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_double(double x) {
+    const int lo = dpp_int<CTRL>(__double2loint(x)), hi = dpp_int<CTRL>(__double2hiint(x));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_double(double x, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
+    return __hiloint2double(hi, lo);
+}
+
+#if defined(SFMBA_SEGRED_SHFL)      // the shuffle form, kept for A/B timing
 template <int NV>
 __device__ __forceinline__ void seg_reduce(double (&v)[NV], int key, int lane) {
 #pragma unroll
@@ -166,6 +190,37 @@ __device__ __forceinline__ void seg_reduce(double (&v)[NV], int key, int lane) {
         }
     }
 }
+#else
+template <int NV, int N>
+__device__ __forceinline__ void seg_row_step(double (&v)[NV], int key, int lane) {
+    constexpr int kRowShl = 0x100;                     // DPP control: row_shl:N
+    const int k2 = dpp_int<kRowShl + N>(key);
+    const bool ok = ((lane & 15) + N < 16) && (k2 == key);
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+        const double o = dpp_double<kRowShl + N>(v[n]);
+        if (ok) v[n] += o;
+    }
+}
+template <int NV>
+__device__ __forceinline__ void seg_reduce(double (&v)[NV], int key, int lane) {
+    seg_row_step<NV, 1>(v, key, lane);
+    seg_row_step<NV, 2>(v, key, lane);
+    seg_row_step<NV, 4>(v, key, lane);
+    seg_row_step<NV, 8>(v, key, lane);
+#pragma unroll
+    for (int r = 2; r >= 0; --r) {
+        const int f = 16 * (r + 1);
+        const int kf = __builtin_amdgcn_readlane(key, f);
+        const bool ok = (lane >> 4) == r && key == kf;
+#pragma unroll
+        for (int n = 0; n < NV; ++n) {
+            const double c = readlane_double(v[n], f);
+            if (ok) v[n] += c;
+        }
+    }
+}
+#endif
 
 // fp32-STORAGE mode (BASELINE config 5): uv, r, t1 and the compact Jacobian are kept as floats, all
 // arithmetic and every accumulation stays fp64.  The Jacobian tile of 64 observations is then three
