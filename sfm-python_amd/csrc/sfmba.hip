@@ -315,15 +315,17 @@ int wait_event(sfmba_handle* h, hipEvent_t ev) {
 }
 
 // The hand-off of an outer iteration: the device posts scalars + PCG control block into the mailbox and
-// raises its sequence number (post_mailbox); the host polls that word.  The stream is queried only
-// every 2 ms, to notice a failed launch instead of spinning forever.
+// raises its sequence number (post_mailbox); the host polls that word.  A post normally arrives within
+// tens of microseconds; past 100 us the stream is queried between polls as well (every 20 us), which
+// notices a failed launch and makes the runtime push anything it may still be holding back.
 int wait_mailbox(sfmba_handle* h, unsigned long long seq) {
     unsigned long long* word = reinterpret_cast<unsigned long long*>(h->mbox + kMboxSeq);
-    double t_check = now_s() + 2e-3;
+    const double t0 = now_s();
+    double t_check = t0 + 100e-6;
     for (int spin = 0;; ++spin) {
         if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) return 0;
         __builtin_ia32_pause();
-        if ((spin & 63) != 63) continue;
+        if ((spin & 15) != 15) continue;
         const double t = now_s();
         if (t < t_check) continue;
         const hipError_t e = hipStreamQuery(h->stream);
@@ -332,7 +334,7 @@ int wait_mailbox(sfmba_handle* h, unsigned long long seq) {
             return fail(h, -3, "hand-off mailbox was not written");
         }
         if (e != hipErrorNotReady) return fail(h, -3, "hipStreamQuery failed: %s", hipGetErrorString(e));
-        t_check = t + 2e-3;
+        t_check = t + 20e-6;
     }
 }
 
