@@ -156,7 +156,6 @@ struct sfmba_handle {
     Mailbox post{};                          // set while the launch that ends a hand-off is enqueued; else empty
     double* h_x = nullptr;                   // pinned staging of the parameter vector
     size_t h_x_doubles = 0;
-    hipEvent_t ev_handoff = nullptr;
     const double* skip = nullptr;         // device flag gating speculative trial launches (sfmba_solve); else null
     double pcg_tol = 0.0; int pcg_cap = 0; // options of the running PCG (fused launch 0 writes the control block)
     bool pcg_fused = false;               // PCG update fused into the sweep launch (acc_mode 1, C <= 1024)
@@ -298,19 +297,6 @@ int wait_stream(sfmba_handle* h) {
         if (now_s() - t0 > 0.05) break;          // long wait: stop burning the core
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    return 0;
-}
-
-// Same, for a point in the middle of the stream (work enqueued behind it keeps running).
-int wait_event(sfmba_handle* h, hipEvent_t ev) {
-    const double t0 = now_s();
-    for (;;) {
-        const hipError_t e = hipEventQuery(ev);
-        if (e == hipSuccess) return 0;
-        if (e != hipErrorNotReady) return fail(h, -3, "hipEventQuery failed: %s", hipGetErrorString(e));
-        if (now_s() - t0 > 0.05) break;
-    }
-    HIPCHK(h, hipEventSynchronize(ev));
     return 0;
 }
 
@@ -766,8 +752,7 @@ int sfmba_create(sfmba_handle** out, int device_id) {
     h->own_stream = true;
     if (hipHostMalloc((void**)&h->h_scal, sizeof(double) * 64, hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&h->mbox, sizeof(double) * 64, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess ||
-        hipHostGetDevicePointer((void**)&h->mbox_dev, h->mbox, 0) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_handoff, hipEventDisableTiming) != hipSuccess) {
+        hipHostGetDevicePointer((void**)&h->mbox_dev, h->mbox, 0) != hipSuccess) {
         (void)hipStreamDestroy(h->stream); delete h; return -4;
     }
     memset(h->mbox, 0, sizeof(double) * 64);
@@ -785,7 +770,6 @@ void sfmba_destroy(sfmba_handle* h) {
     if (h->h_scal) (void)hipHostFree(h->h_scal);
     if (h->mbox) (void)hipHostFree(h->mbox);
     if (h->h_x) (void)hipHostFree(h->h_x);
-    if (h->ev_handoff) (void)hipEventDestroy(h->ev_handoff);
     delete h;
 }
 
