@@ -23,6 +23,7 @@
 #include <cstring>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "ba_kernels.hpp"
@@ -93,6 +94,22 @@ RcclApi* rccl_api() {
     return api.lib ? &api : nullptr;
 }
 
+// fn(begin, end, part) over [0, n) on a few host threads (set_problem's passes over the observation arrays;
+// small inputs stay on the calling thread)
+template <class Fn>
+void parallel_chunks(int64_t n, int max_parts, Fn fn) {
+    const int hw = (int)std::thread::hardware_concurrency();
+    const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(max_parts, hw > 0 ? hw : 1), n / 131072));
+    if (parts == 1) { fn((int64_t)0, n, 0); return; }
+    std::vector<std::thread> th;
+    const int64_t per = (n + parts - 1) / parts;
+    for (int t = 1; t < parts; ++t)
+        th.emplace_back([=] { fn(std::min<int64_t>(n, t * per), std::min<int64_t>(n, (t + 1) * per), t); });
+    fn((int64_t)0, std::min<int64_t>(n, per), 0);
+    for (auto& x : th) x.join();
+}
+constexpr int kHostParts = 8;
+
 double now_s() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -150,6 +167,8 @@ struct sfmba_handle {
         int64_t calls = 0;
     } p2p;
     double* h_scal = nullptr;                // pinned
+    void* h_stage = nullptr;                 // pinned staging of set_problem's uploads (grow-only)
+    size_t h_stage_bytes = 0;
     double* mbox = nullptr;                  // coherent pinned block the device posts the hand-off into (Mailbox)
     double* mbox_dev = nullptr;              // its device-visible address
     unsigned long long mbox_seq = 0;
@@ -597,6 +616,16 @@ int ensure_h_x(sfmba_handle* h) {
     return 0;
 }
 
+// pinned staging for the arrays set_problem uploads (an async copy from pageable memory is staged by the
+// runtime in small synchronous pieces: ~3 ms for the 32 MB of a 1M-observation problem)
+int ensure_stage(sfmba_handle* h, size_t bytes) {
+    if (h->h_stage && h->h_stage_bytes >= bytes) return 0;
+    if (h->h_stage) { (void)hipHostFree(h->h_stage); h->h_stage = nullptr; h->h_stage_bytes = 0; }
+    HIPCHK(h, hipHostMalloc(&h->h_stage, bytes, hipHostMallocDefault));
+    h->h_stage_bytes = bytes;
+    return 0;
+}
+
 int upload_x(sfmba_handle* h, const double* x_host) {
     CHK(ensure_h_x(h));
     HIPCHK(h, hipStreamSynchronize(h->stream));      // the staging buffer may still be in flight
@@ -770,6 +799,7 @@ void sfmba_destroy(sfmba_handle* h) {
     if (h->h_scal) (void)hipHostFree(h->h_scal);
     if (h->mbox) (void)hipHostFree(h->mbox);
     if (h->h_x) (void)hipHostFree(h->h_x);
+    if (h->h_stage) (void)hipHostFree(h->h_stage);
     delete h;
 }
 
@@ -957,6 +987,9 @@ int64_t sfmba_p2p_calls(const sfmba_handle* h) { return h ? h->p2p.calls : 0; }
 int sfmba_set_problem(sfmba_handle* h, int64_t C, int64_t P, int64_t N, const int64_t* cam, const int64_t* pt,
                       const double* uv, const double* K) {
     CHK(enter(h));
+    const bool timing = std::getenv("SFMBA_DEBUG_TIMING") != nullptr;
+    const double tp0 = now_s();
+    double tp1 = tp0, tp2 = tp0, tp3 = tp0;
     h->have_problem = false;
     h->solved = false;
     if (C <= 0 || P <= 0 || N <= 0) return fail(h, -1, "n_cameras, n_points, n_obs must be positive");
@@ -964,15 +997,28 @@ int sfmba_set_problem(sfmba_handle* h, int64_t C, int64_t P, int64_t N, const in
     if (N >= (int64_t)1 << 30 || 6 * C + 3 * P >= (int64_t)1 << 31)
         return fail(h, -1, "problem too large for 32-bit observation indices");
     bool sorted = true;
-    for (int64_t i = 0; i < N; ++i) {
-        if (cam[i] < 0 || cam[i] >= C) return fail(h, -1, "camera_indices[%lld]=%lld out of range [0,%lld)", (long long)i, (long long)cam[i], (long long)C);
-        if (pt[i] < 0 || pt[i] >= P) return fail(h, -1, "point_indices[%lld]=%lld out of range [0,%lld)", (long long)i, (long long)pt[i], (long long)P);
-        if (i > 0 && pt[i] < pt[i - 1]) sorted = false;
+    {   // bounds of every index (numpy's fancy indexing would raise IndexError in the reference) and order
+        int64_t bad[kHostParts];
+        bool unsorted[kHostParts] = {};
+        for (int t = 0; t < kHostParts; ++t) bad[t] = -1;
+        parallel_chunks(N, kHostParts, [&](int64_t b, int64_t e, int t) {
+            for (int64_t i = b; i < e; ++i) {
+                if ((cam[i] < 0 || cam[i] >= C || pt[i] < 0 || pt[i] >= P) && bad[t] < 0) bad[t] = i;
+                if (i > 0 && pt[i] < pt[i - 1]) unsorted[t] = true;
+            }
+        });
+        for (int t = 0; t < kHostParts; ++t) {
+            const int64_t i = bad[t];
+            if (i >= 0 && (cam[i] < 0 || cam[i] >= C)) return fail(h, -1, "camera_indices[%lld]=%lld out of range [0,%lld)", (long long)i, (long long)cam[i], (long long)C);
+            if (i >= 0) return fail(h, -1, "point_indices[%lld]=%lld out of range [0,%lld)", (long long)i, (long long)pt[i], (long long)P);
+            sorted = sorted && !unsorted[t];
+        }
     }
     for (int k = 0; k < 9; ++k) {
         if (!std::isfinite(K[k])) return fail(h, -1, "K is not finite");
         h->K.k[k] = K[k];
     }
+    tp1 = now_s();
     h->f32 = h->f32_next;
     if (h->p2p.own && 27 * C > h->p2p.stride) p2p_release(h);     // slots too small for the new camera count
     h->C = C; h->P = P; h->N = N; h->n = 6 * C + 3 * P;
@@ -985,15 +1031,34 @@ int sfmba_set_problem(sfmba_handle* h, int64_t C, int64_t P, int64_t N, const in
         std::iota(h->order.begin(), h->order.end(), (int64_t)0);
         std::stable_sort(h->order.begin(), h->order.end(), [&](int64_t a, int64_t b) { return pt[a] < pt[b]; });
     }
-    std::vector<int> ci(h->ld, 0), pi(h->ld, 0), ptr(P + 1, 0);
-    std::vector<double> uvs(2 * h->ld, 0.0);
-    for (int64_t k = 0; k < N; ++k) {
-        const int64_t s = sorted ? k : h->order[k];
-        ci[k] = (int)cam[s]; pi[k] = (int)pt[s];
-        uvs[2 * k] = uv[2 * s]; uvs[2 * k + 1] = uv[2 * s + 1];
-        ptr[pt[s] + 1]++;
-    }
-    for (int64_t p = 0; p < P; ++p) ptr[p + 1] += ptr[p];
+    // device-bound arrays are built directly in pinned memory:
+    // [uv 2 ld doubles | cam ld | pt ld | ptr P+1 ints | fp32 storage: uv once more as floats]
+    const size_t ldz = (size_t)h->ld;
+    HIPCHK(h, hipStreamSynchronize(h->stream));                  // a previous upload may still read the staging
+    const size_t stage_ints = 2 * ldz + (((size_t)P + 1 + 3) & ~(size_t)3);      // keeps what follows 16-byte aligned
+    CHK(ensure_stage(h, sizeof(double) * 2 * ldz + sizeof(int) * stage_ints + sizeof(float) * 2 * ldz));
+    double* uvs = static_cast<double*>(h->h_stage);
+    int* ci = reinterpret_cast<int*>(uvs + 2 * ldz);
+    int* pi = ci + ldz;
+    int* ptr = pi + ldz;
+    for (size_t k = (size_t)N; k < ldz; ++k) { ci[k] = 0; pi[k] = 0; uvs[2 * k] = 0.0; uvs[2 * k + 1] = 0.0; }
+    const int64_t* ord = sorted ? nullptr : h->order.data();
+    parallel_chunks(N, kHostParts, [&](int64_t b, int64_t e, int) {
+        for (int64_t k = b; k < e; ++k) {
+            const int64_t s = ord ? ord[k] : k;
+            ci[k] = (int)cam[s]; pi[k] = (int)pt[s];
+            uvs[2 * k] = uv[2 * s]; uvs[2 * k + 1] = uv[2 * s + 1];
+        }
+    });
+    // ptr[p] = first position whose point index is >= p (pi is non-decreasing now): every run start k writes
+    // the entries (pi[k-1], pi[k]], so the chunks touch disjoint parts of ptr
+    parallel_chunks(N, kHostParts, [&](int64_t b, int64_t e, int) {
+        for (int64_t k = b; k < e; ++k) {
+            const int lo = k == 0 ? -1 : pi[k - 1];
+            for (int q = lo + 1; q <= pi[k]; ++q) ptr[q] = (int)k;
+        }
+    });
+    for (int64_t q = (int64_t)pi[N - 1] + 1; q <= P; ++q) ptr[q] = (int)N;
     // wave ranges: cut at point boundaries, >= T observations each
     const int64_t total_waves = (int64_t)h->n_cu * kWavesPerSweepBlock;
     const int64_t T = std::max<int64_t>(64, (N + total_waves - 1) / total_waves);
@@ -1033,6 +1098,7 @@ int sfmba_set_problem(sfmba_handle* h, int64_t C, int64_t P, int64_t N, const in
         wsteps[w] = make_int2(first, (int)steps.size() - first);
     }
     h->n_steps = (int)steps.size();
+    tp2 = now_s();
     h->lds_tab = (size_t)C * kCamTab * sizeof(double) <= kLdsDynMax;
     h->lds_acc = (size_t)C * 12 * sizeof(double) <= kLdsDynMax;
     h->lds_vec = (size_t)C * 6 * sizeof(double) <= kLdsDynMax;
@@ -1099,15 +1165,15 @@ int sfmba_set_problem(sfmba_handle* h, int64_t C, int64_t P, int64_t N, const in
     h->x = h->xa.as<double>(); h->x_new = h->xb.as<double>();
     h->tab = h->tabA.as<double>(); h->tab_new = h->tabB.as<double>();
 
-    HIPCHK(h, hipMemcpyAsync(h->cam_idx.p, ci.data(), sizeof(int) * ld, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->pt_idx.p, pi.data(), sizeof(int) * ld, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->pt_ptr.p, ptr.data(), sizeof(int) * (P + 1), hipMemcpyHostToDevice, h->stream));
-    std::vector<float> uvf;
+    HIPCHK(h, hipMemcpyAsync(h->cam_idx.p, ci, sizeof(int) * ld, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->pt_idx.p, pi, sizeof(int) * ld, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->pt_ptr.p, ptr, sizeof(int) * (P + 1), hipMemcpyHostToDevice, h->stream));
     if (h->f32) {                            // integer pixels up to 2^24 are exact in fp32
-        uvf.assign(uvs.begin(), uvs.end());
-        HIPCHK(h, hipMemcpyAsync(h->uv.p, uvf.data(), sizeof(float) * 2 * ld, hipMemcpyHostToDevice, h->stream));
+        float* uvf = reinterpret_cast<float*>(ci + stage_ints);
+        for (size_t k = 0; k < 2 * ld; ++k) uvf[k] = (float)uvs[k];
+        HIPCHK(h, hipMemcpyAsync(h->uv.p, uvf, sizeof(float) * 2 * ld, hipMemcpyHostToDevice, h->stream));
     } else {
-        HIPCHK(h, hipMemcpyAsync(h->uv.p, uvs.data(), sizeof(double) * 2 * ld, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->uv.p, uvs, sizeof(double) * 2 * ld, hipMemcpyHostToDevice, h->stream));
     }
     if (!ranges.empty()) {
         HIPCHK(h, hipMemcpyAsync(h->ranges.p, ranges.data(), sizeof(int2) * ranges.size(), hipMemcpyHostToDevice, h->stream));
@@ -1121,7 +1187,11 @@ int sfmba_set_problem(sfmba_handle* h, int64_t C, int64_t P, int64_t N, const in
     HIPCHK(h, hipMemsetAsync(h->p.p, 0, sizeof(double) * h->n, h->stream));      // ... and their step is 0
     HIPCHK(h, hipMemsetAsync(h->r[0].p, 0, esz * 2 * ld, h->stream));
     HIPCHK(h, hipMemsetAsync(h->r[1].p, 0, esz * 2 * ld, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));     // host staging vectors go out of scope
+    tp3 = now_s();
+    HIPCHK(h, hipStreamSynchronize(h->stream));     // the staging buffer is reused by the next call
+    if (timing)
+        fprintf(stderr, "sfmba: set_problem  validate %.2f ms  build %.2f ms  allocate+enqueue %.2f ms  upload wait %.2f ms\n",
+                1e3 * (tp1 - tp0), 1e3 * (tp2 - tp1), 1e3 * (tp3 - tp2), 1e3 * (now_s() - tp3));
     h->have_problem = true;
     return 0;
 }
