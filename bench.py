@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg4", choices=["cfg2", "cfg3", "cfg4"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--settle", type=float, default=0.5,
+                    help="seconds of untimed solves before the warm-up steps (start-up transient of the GPU queue)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="use the collective path even at world size 1 (plumbing check)")
     ap.add_argument("--storage-bits", type=int, default=64, choices=[64, 32],
@@ -189,6 +191,12 @@ def main():
         # inside solves, the population `roofline.avg_launch_us` averages over.
         primed = {name: be.time_kernel(pb.x0, which, 50) for which, name in
                   ((2, "normal_blocks"), (3, "schur_sweep"))}
+        # Settle: on these boxes a process sees one or two ~45 ms stalls of its GPU queue during the first
+        # ~100 ms of activity (observed with SFMBA_DEBUG_STALLS=1; none later in 600-solve runs).  Untimed
+        # back-to-back solves for half a second keep that start-up transient out of the W + K steps below.
+        t_settle = time.perf_counter()
+        while time.perf_counter() - t_settle < a.settle:
+            run_iterations(5)
         run_iterations(max(1, a.warmup))
         barrier()
         t0 = time.perf_counter()
@@ -220,6 +228,7 @@ def main():
                     else "iterations/s (per shard, summed over GPUs)",
             "n_gpus": world, "steps": steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * elapsed / steps,
+            "settle_s": a.settle,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64" if a.storage_bits == 64 else "f64 arithmetic, f32 storage", "data": "synthetic",
             "transport": None if td is None else (f"direct xGMI all-reduce kernel ({be.p2p_calls()} collectives; "

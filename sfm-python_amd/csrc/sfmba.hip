@@ -307,15 +307,21 @@ int grid_1d(int64_t n, int block, int cap) {
 // Host/device hand-off: poll the stream instead of sleeping in hipStreamSynchronize.  The solver
 // hands control back to the host two to three times per outer iteration for ~30 us of GPU work each;
 // a blocking wait that parks the thread costs up to a millisecond per wake-up on an idle host.
+void report_stall(const char* where, double seconds) {          // SFMBA_DEBUG_STALLS=1: waits longer than 2 ms
+    static const bool on = std::getenv("SFMBA_DEBUG_STALLS") != nullptr;
+    if (on && seconds > 2e-3) fprintf(stderr, "sfmba: waited %.2f ms in %s\n", 1e3 * seconds, where);
+}
+
 int wait_stream(sfmba_handle* h) {
     const double t0 = now_s();
     for (;;) {
         const hipError_t e = hipStreamQuery(h->stream);
-        if (e == hipSuccess) return 0;
+        if (e == hipSuccess) { report_stall("wait_stream", now_s() - t0); return 0; }
         if (e != hipErrorNotReady) return fail(h, -3, "hipStreamQuery failed: %s", hipGetErrorString(e));
         if (now_s() - t0 > 0.05) break;          // long wait: stop burning the core
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    report_stall("wait_stream (blocking)", now_s() - t0);
     return 0;
 }
 
@@ -328,14 +334,14 @@ int wait_mailbox(sfmba_handle* h, unsigned long long seq) {
     const double t0 = now_s();
     double t_check = t0 + 100e-6;
     for (int spin = 0;; ++spin) {
-        if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) return 0;
+        if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) { report_stall("wait_mailbox", now_s() - t0); return 0; }
         __builtin_ia32_pause();
         if ((spin & 15) != 15) continue;
         const double t = now_s();
         if (t < t_check) continue;
         const hipError_t e = hipStreamQuery(h->stream);
         if (e == hipSuccess) {                               // everything enqueued has run: the post is visible
-            if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) return 0;
+            if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) { report_stall("wait_mailbox (stream idle)", now_s() - t0); return 0; }
             return fail(h, -3, "hand-off mailbox was not written");
         }
         if (e != hipErrorNotReady) return fail(h, -3, "hipStreamQuery failed: %s", hipGetErrorString(e));
@@ -1367,6 +1373,7 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
     h->jcur = 0;
     CHK(upload_x(h, x_inout));
     const double t_dev0 = now_s();
+    report_stall("upload_x", t_dev0 - t_begin);
 
     // Host/device hand-offs per outer iteration: ONE read-back after the whole linear phase
     // (Cauchy product, Schur PCG, back-substitution, Gram/dot reductions are enqueued without the
