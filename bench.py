@@ -195,8 +195,12 @@ def main():
         # ~100 ms of activity (observed with SFMBA_DEBUG_STALLS=1; none later in 600-solve runs).  Untimed
         # back-to-back solves for half a second keep that start-up transient out of the W + K steps below.
         t_settle = time.perf_counter()
-        while time.perf_counter() - t_settle < a.settle:
-            run_iterations(5)
+        if td is None:
+            while time.perf_counter() - t_settle < a.settle:
+                run_iterations(5)
+        else:                      # every solve is a sequence of collectives: all ranks must run the same number
+            for _ in range(int(round(a.settle * 100))):
+                run_iterations(5)
         run_iterations(max(1, a.warmup))
         barrier()
         t0 = time.perf_counter()
