@@ -1157,7 +1157,7 @@ int sfmba_set_problem(sfmba_handle* h, int64_t C, int64_t P, int64_t N, const in
     HIPCHK(h, h->vtmp.ensure(sizeof(double) * 6 * C));
     HIPCHK(h, h->vcm.ensure(sizeof(double) * 6 * C));
     h->red_bc = grid_1d(6 * C, 256, 32);
-    h->red_grid = h->red_bc + grid_1d(3 * P, 256, 992);
+    h->red_grid = h->red_bc + grid_1d(3 * P, 256, 224);   // <= 256 partial rows: k_tr_step sums them itself
     HIPCHK(h, h->part.ensure(sizeof(double) * (size_t)(2 * kPartRows * kNQ)));
     HIPCHK(h, h->ctrl.ensure(2 * sizeof(PcgCtrl)));
     if (h->nb_passes > 0) {
