@@ -1844,6 +1844,8 @@ struct P2pArgs {
     unsigned* ticket;                         // local: arrival counter of this launch's workgroups
     unsigned* error;                          // local: set to 1 on timeout
     long long timeout;
+    unsigned long long max_mask;              // bit e set: element e (< 64) is reduced with max although op is sum
+                                              // (lets one collective carry sums and a maximum)
 };
 
 __global__ __launch_bounds__(256) void k_p2p_allreduce(double* __restrict__ vec, int count, int op, P2pArgs a) {
@@ -1883,9 +1885,10 @@ __global__ __launch_bounds__(256) void k_p2p_allreduce(double* __restrict__ vec,
     const double* slots = a.data[a.rank] + (size_t)par * a.world * a.stride;
     for (int e = lo + tid; e < hi; e += blockDim.x) {
         double s = __hip_atomic_load(slots + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const bool use_max = op == 1 || (e < 64 && ((a.max_mask >> e) & 1ull) != 0ull);
         for (int q = 1; q < a.world; ++q) {
             const double v = __hip_atomic_load(slots + (size_t)q * a.stride + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            s = (op == 0) ? s + v : fmax(s, v);
+            s = use_max ? fmax(s, v) : s + v;
         }
         vec[e] = s;
     }

@@ -237,13 +237,15 @@ bool multi_rank(const sfmba_handle* h) { return h->p2p.ready || h->comm != nullp
 
 constexpr size_t kP2pFlagBytes = sizeof(unsigned long long) * 2 * kP2pMaxRanks * kP2pFlagStride;
 
-int p2p_allreduce(sfmba_handle* h, double* ptr, int64_t count, int op, const int* cancel) {
+int p2p_allreduce(sfmba_handle* h, double* ptr, int64_t count, int op, const int* cancel,
+                  unsigned long long max_mask = 0) {
     auto& p = h->p2p;
     P2pArgs a{};
     for (int q = 0; q < p.world; ++q) { a.data[q] = p.data[q]; a.flags[q] = p.flags[q]; }
     a.rank = p.rank; a.world = p.world; a.stride = p.stride;
     a.seq = reinterpret_cast<unsigned long long*>(p.words + 2);
     a.cancel = cancel;
+    a.max_mask = max_mask;
     a.ticket = p.words; a.error = p.words + 1;
     a.timeout = 300000000ll;                              // 3 s of the 100 MHz wall clock
     const int grid = (int)std::min<int64_t>(kP2pMaxBlocks, std::max<int64_t>(1, (count + 511) / 512));
@@ -1444,10 +1446,19 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
         int np = 0;
         const bool scale_sums_rode = h->pending_scale_sums;
         CHK(launch_jdot(h, &np));                               // t1 = J D^2 g, G11 = |t1|^2
-        if (scale_sums_rode) CHK(exchange_linearise(h));        // q1..q4, max|g| of the accepted point
         if (!one_rank) {
             CHK(launch_finish(h, h->partB(), np, 1, 1));
-            CHK(exchange(h, sc + 1, 1, 0));
+            if (scale_sums_rode && h->p2p.ready) {
+                // one collective for slots 1..12: G11 (fresh), q1..q4 (8..11, fresh) as sums and max|g| (12,
+                // fresh) as a maximum.  Slots 2..7 (G12, G22, q5..q8 of the previous iteration) are summed once
+                // more along the way; nothing reads them before k_backsub / k_vec_reduce rewrite them.
+                static_assert(kMaxSlot == 12, "mask below assumes the maximum sits at the end of the run");
+                CHK(p2p_allreduce(h, sc + 1, kMaxSlot, 0, nullptr, 1ull << (kMaxSlot - 1)));
+                ++h->n_collectives;
+            } else {
+                if (scale_sums_rode) CHK(exchange_linearise(h));    // q1..q4, max|g| of the accepted point
+                CHK(exchange(h, sc + 1, 1, 0));
+            }
         }
         {   // regularisation (trf.py:471-475), Vinv/e per point, Dc/Minv per camera, acc0 = 0: one launch
             const int bc = (int)((C + 63) / 64), bp = (int)((P + 63) / 64);
