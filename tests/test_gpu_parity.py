@@ -344,6 +344,22 @@ def test_fused_pcg_launch_equals_sweep_plus_update(monkeypatch):
         assert np.abs(a.x - b.x).max() <= 1e-7 * np.abs(a.x).max()         # atomics: summation order varies
 
 
+def test_full_solves_with_many_cameras_vs_oracle(orc):
+    """Camera counts past the single-launch PCG and the LDS-resident tables, end to end: 1300 cameras (camera
+    table of K1 read from L2, normal blocks in three column passes, sweep + k_pcg_update as two kernels) and
+    1800 (accumulator of a camera range in LDS, vector gathered from the camera-major copy)."""
+    import sfmba
+    for C, P, N in ((1300, 4000, 40000), (1800, 3000, 30000)):
+        pb = sfmba.make_problem(C, P, N, seed=21)
+        o = orc.trf_schur(pb.x0, *pb.args, ftol=1e-10, linear="pcg", pcg_tol=1e-3)
+        res = sfmba.least_squares(sfmba.compute_residuals, pb.x0, x_scale="jac", ftol=1e-10, method="trf",
+                                  args=pb.args)
+        assert res.status == o.status and (res.nfev, res.njev) == (o.nfev, o.njev)
+        assert abs(res.cost - o.cost) <= 1e-9 * o.cost
+        r = sfmba.compute_residuals(res.x, *pb.args)
+        assert np.abs(r - res.fun).max() < 1e-8
+
+
 def test_cfg3_full_loop_vs_oracle(orc):
     """BASELINE config 3 (200 cameras / 20k points / 200k observations): the full Schur-LM loop on the
     GPU against the oracle's."""
