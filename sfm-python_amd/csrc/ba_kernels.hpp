@@ -1221,6 +1221,16 @@ __global__ __launch_bounds__(kSweepThreads) void k_schur_sweep(
     static_assert(!FUSED || (ACC == 1 && MODE == 0), "the fused PCG launch keeps v and acc in LDS");
     constexpr bool LDS_ACC = ACC == 1;
     const int n6 = 6 * C;
+    // The wave's step list and the indices of its first step form a chain of three dependent loads that
+    // depends on nothing else: request it first, so that it overlaps the PCG prologue / the LDS staging.
+    const int wg = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    int s = 0, s_end = 0;
+    if (wg < st.n_waves) { const int2 w = st.wsteps[wg]; s = w.x; s_end = w.x + w.y; }
+    int2 cur = make_int2(0, 0);
+    if (s < s_end) cur = st.steps[s];
+    int i = cur.x + lane, c = 0, p = 0;
+    if (cur.y <= 64 && lane < cur.y) { c = o.cam_idx[i]; p = o.pt_idx[i]; }
     if (FUSED) {
         __shared__ double red[16];
         __shared__ double bcast[2];
@@ -1379,16 +1389,6 @@ __global__ __launch_bounds__(kSweepThreads) void k_schur_sweep(
         vin += (size_t)(set * kPcgVecs + (ACC == 2 ? kPcgUcm : kPcgU)) * n6;
         acc += (size_t)set * n6;
     }
-    const int wg = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    int s = 0, s_end = 0;
-    if (wg < st.n_waves) { const int2 w = st.wsteps[wg]; s = w.x; s_end = w.x + w.y; }
-    // indices of the first step are requested before the LDS tables are staged
-    int2 cur = make_int2(0, 0);
-    if (s < s_end) cur = st.steps[s];
-    int i = cur.x + lane, c = 0, p = 0;
-    if (cur.y <= 64 && lane < cur.y) { c = o.cam_idx[i]; p = o.pt_idx[i]; }
-
     double* s_v = smem;
     double* s_acc = (ACC == 2) ? smem : smem + n6;
     if (LDS_ACC && !FUSED) {
