@@ -247,6 +247,9 @@ def main():
                        "ms_per_solve": [round(1e3 * r[7], 3) for r in results],
                        "back_to_back_kernel_us": {k: round(v, 2) for k, v in primed.items()}},
             "final_rmse_px": full[0][1], "initial_rmse_px": full[0][2],
+            # time until the RMSE is final = wall time of a solve that ran to its ftol termination
+            "time_to_final_rmse_ms": (round(1e3 * sorted(r[7] for r in full)[len(full) // 2], 3)
+                                      if any(r[6] != 0 for r in results) else None),
             "roofline": {"kernel": "k_resjac (residual + 2x6/2x3 Jacobian sweep)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None,

@@ -112,6 +112,19 @@ __device__ __forceinline__ void block_sum(double (&v)[NQ], double* red) {
     }
 }
 
+// Block-wide sum of one value per thread, result on EVERY thread, one barrier: each wave leaves its sum in
+// `slots` (an array no other reduction of the kernel uses, so nothing has to be fenced before the write) and
+// every thread adds the slots in the same fixed order.
+__device__ __forceinline__ double block_sum_all(double v, double* slots) {
+    const int nw = (blockDim.x + 63) >> 6;
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) slots[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int k = 0; k < nw; ++k) s += slots[k];
+    return s;
+}
+
 constexpr int kNQ = 9;
 
 // Final sums of partial rows.  One wave per quantity; quantity k < first_sum is a max, else a sum;
@@ -1232,8 +1245,8 @@ __global__ __launch_bounds__(kSweepThreads) void k_schur_sweep(
     int i = cur.x + lane, c = 0, p = 0;
     if (cur.y <= 64 && lane < cur.y) { c = o.cam_idx[i]; p = o.pt_idx[i]; }
     if (FUSED) {
-        __shared__ double red[16];
-        __shared__ double bcast[2];
+        __shared__ double red_a[16];
+        __shared__ double red_b[16];
         // Until the solve finishes, launch L >= 1 sees iters == L - 1, so every address below follows from
         // L alone and all vector loads of the prologue are in flight together.
         PcgCtrl* __restrict__ cout = pf.ctrl2 + ((L + 1) & 1);
@@ -1285,10 +1298,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_schur_sweep(
                     }
                 }
             }
-            block_sum<1>(t, red);
-            if (threadIdx.x == 0) bcast[1] = t[0];
-            __syncthreads();
-            const double rz = bcast[1];
+            const double rz = block_sum_all(t[0], red_b);
             const int done = (rz > 0.0) ? 0 : (rz == 0.0 ? 1 : 3);
             if (writer) {
                 PcgCtrl c0;
@@ -1317,10 +1327,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_schur_sweep(
 #pragma unroll
                 for (int k = 0; k < 6; ++k) d[0] += we[k] * ue[k];
             }
-            block_sum<1>(d, red);
-            if (threadIdx.x == 0) bcast[0] = d[0];
-            __syncthreads();
-            const double delta = bcast[0];
+            const double delta = block_sum_all(d[0], red_a);
             const double gamma = ci.rz;
             const double beta = ci.iters == 0 ? 0.0 : gamma / ci.rz_prev;
             const double den = delta - (ci.iters == 0 ? 0.0 : beta * gamma / ci.alpha_prev);
@@ -1357,10 +1364,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_schur_sweep(
                     }
                 }
             }
-            block_sum<1>(t, red);
-            if (threadIdx.x == 0) bcast[1] = t[0];
-            __syncthreads();
-            const double rz = bcast[1];
+            const double rz = block_sum_all(t[0], red_b);
             int done = 0;
             if (!(rz > ci.tol2 * ci.rz0)) done = 1;               // also catches NaN
             else if (ci.iters + 1 >= ci.max_iters) done = 2;
