@@ -128,8 +128,9 @@ int  sfmba_comm_destroy(sfmba_handle* h);
  * after sfmba_set_problem and sfmba_comm_init / sfmba_set_exchange on every rank:
  *   sfmba_p2p_export  allocates this rank's staging buffer and returns its 64-byte hipIpcMemHandle_t;
  *   (the caller all-gathers the handles over any channel, rank order)
- *   sfmba_p2p_attach  maps the peers' buffers and runs a two-round self-test all-reduce; returns -5
- *                     and detaches when mapping or the self-test fails (the previous transport stays).
+ *   sfmba_p2p_attach  maps the peers' buffers and runs a 24-round self-test (the three message sizes of
+ *                     the solver, chains of back-to-back collectives); returns -5 and detaches when
+ *                     mapping or the self-test fails (the previous transport stays).
  * All ranks must attach or none: agree on the minimum of the return codes and call sfmba_p2p_detach on
  * every rank if any failed.  world <= 16.  Results are summed in rank order: bitwise equal on all ranks. */
 int  sfmba_p2p_export(sfmba_handle* h, int32_t world, void* handle64_out);

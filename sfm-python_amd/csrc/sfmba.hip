@@ -959,22 +959,28 @@ int sfmba_p2p_attach(sfmba_handle* h, const void* handles, int32_t rank, int32_t
         p.flags[q] = static_cast<unsigned long long*>(base);
         p.data[q] = reinterpret_cast<double*>(static_cast<char*>(base) + kP2pFlagBytes);
     }
-    // Self-test, two rounds (both parities): rank r contributes (r+1)(i+1); the sum is exact in fp64.
-    const int nt = (int)std::min<int64_t>(6 * h->C, 2048);
-    std::vector<double> v(nt);
+    // Self-test: 24 rounds over the three message sizes the solver uses (a few scalars, 6 C, 27 C), each a
+    // chain of one to three back-to-back collectives on the same vector (parity and sequence protocol without
+    // the host in between).  Rank r contributes (r + 1 + round)(i mod 97 + 1): every sum is exact in fp64.
+    const int64_t sizes[3] = {7, 6 * h->C, std::min<int64_t>(27 * h->C, p.stride)};
+    std::vector<double> v((size_t)sizes[2]);
+    double* dev = h->arena;                                    // 45 C + 32 doubles: room for 27 C
     bool ok = true;
-    for (int round = 0; round < 2 && ok; ++round) {
-        for (int i = 0; i < nt; ++i) v[i] = (double)(rank + 1 + round) * (double)(i + 1);
-        HIPCHK(h, hipMemcpyAsync(h->acc(), v.data(), sizeof(double) * nt, hipMemcpyHostToDevice, h->stream));
-        CHK(p2p_allreduce(h, h->acc(), nt, 0, nullptr));
-        HIPCHK(h, hipMemcpyAsync(v.data(), h->acc(), sizeof(double) * nt, hipMemcpyDeviceToHost, h->stream));
+    for (int round = 0; round < 24 && ok; ++round) {
+        const int nt = (int)sizes[round % 3], chain = 1 + round % 3;
+        for (int i = 0; i < nt; ++i) v[i] = (double)(rank + 1 + round) * (double)(i % 97 + 1);
+        HIPCHK(h, hipMemcpyAsync(dev, v.data(), sizeof(double) * nt, hipMemcpyHostToDevice, h->stream));
+        for (int k = 0; k < chain; ++k) CHK(p2p_allreduce(h, dev, nt, 0, nullptr));
+        HIPCHK(h, hipMemcpyAsync(v.data(), dev, sizeof(double) * nt, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        const double wsum = 0.5 * world * (world + 1) + (double)round * world;
-        for (int i = 0; i < nt; ++i) ok = ok && v[i] == wsum * (double)(i + 1);
+        double wsum = 0.5 * world * (world + 1) + (double)round * world;
+        for (int k = 1; k < chain; ++k) wsum *= world;
+        for (int i = 0; i < nt; ++i) ok = ok && v[i] == wsum * (double)(i % 97 + 1);
     }
+    const int nt = (int)sizes[2];
     unsigned words[2] = {0, 0};
     HIPCHK(h, hipMemcpy(words, p.words, sizeof words, hipMemcpyDeviceToHost));
-    HIPCHK(h, hipMemsetAsync(h->acc(), 0, sizeof(double) * nt, h->stream));
+    HIPCHK(h, hipMemsetAsync(dev, 0, sizeof(double) * nt, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (!ok || words[1] != 0) {
         p2p_close_peers(h);                                // own buffer is freed by sfmba_p2p_detach, once all ranks agree
