@@ -222,7 +222,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "k1_traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            if tj.get("workload") == a.workload and a.storage_bits == 64:
+            if str(tj.get("workload", "")).split()[0] == a.workload and a.storage_bits == 64:
                 traffic = tj.get("hbm_bytes_per_launch")
         full = [r for r in results if r[6] != 0] or results
         line = {
