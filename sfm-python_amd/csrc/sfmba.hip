@@ -443,14 +443,15 @@ int launch_normal_blocks(sfmba_handle* h) {
             CHK(set_lds(h, k_normal_blocks_lds, lds));
             hipLaunchKernelGGL(k_normal_blocks_lds, dim3(grid), dim3(kSweepThreads), lds, h->stream,
                                h->ranges.as<int2>(), h->n_ranges, obs_arrays(h), h->r[h->jcur].as<double>(),
-                               h->V.as<double>(), h->gp.as<double>(), h->tables.as<double>(), (int)h->C,
+                               h->V.as<double>(), h->gp.as<double>(),
+                               h->tables.as<double>() + (size_t)ps * grid * ((size_t)h->C * per), (int)h->C,
                                col0, ncols, ps == 0 ? 1 : 0, h->skip);
             HIPCHK(h, hipGetLastError());
-            const int ntab = (int)h->C * ncols;
-            hipLaunchKernelGGL(k_reduce_tables, dim3((ntab + 63) / 64), dim3(1024), 0, h->stream,
-                               h->tables.as<double>(), grid, (int)h->C, col0, ncols, h->Ugc(), h->skip);
-            HIPCHK(h, hipGetLastError());
         }
+        // one reduction launch for the tables of all passes
+        hipLaunchKernelGGL(k_reduce_tables, dim3((27 * (int)h->C + 63) / 64), dim3(1024), 0, h->stream,
+                           h->tables.as<double>(), grid, (int)h->C, per, h->nb_passes, h->Ugc(), h->skip);
+        HIPCHK(h, hipGetLastError());
         return 0;
     }
     hipLaunchKernelGGL(k_fill, dim3(grid_1d(27 * h->C, 256, 2048)), dim3(256), 0, h->stream, h->Ugc(),
@@ -1171,7 +1172,7 @@ int sfmba_set_problem(sfmba_handle* h, int64_t C, int64_t P, int64_t N, const in
     if (h->nb_passes > 0) {
         const int per = (27 + h->nb_passes - 1) / h->nb_passes;
         const size_t nblk = (ranges.size() + kWavesPerSweepBlock - 1) / kWavesPerSweepBlock;
-        HIPCHK(h, h->tables.ensure(sizeof(double) * std::max<size_t>(1, nblk) * (size_t)C * per));
+        HIPCHK(h, h->tables.ensure(sizeof(double) * std::max<size_t>(1, nblk) * (size_t)C * per * (size_t)h->nb_passes));
     }
     HIPCHK(h, h->arena_own.ensure(sizeof(double) * (size_t)sfmba_exchange_doubles(C)));
     h->arena = h->arena_own.as<double>();
