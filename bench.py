@@ -90,7 +90,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="cfg4", choices=["cfg2", "cfg3", "cfg4"])
+    ap.add_argument("--workload", default="cfg4", choices=["cfg2", "cfg3", "cfg4", "cfg5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--settle", type=float, default=0.5,
                     help="seconds of untimed solves before the warm-up steps (start-up transient of the GPU queue)")
