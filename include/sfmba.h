@@ -103,6 +103,11 @@ int  sfmba_set_precision(sfmba_handle* h, int32_t storage_bits);
 int  sfmba_set_problem(sfmba_handle* h, int64_t n_cameras, int64_t n_points, int64_t n_obs,
                        const int64_t* camera_indices, const int64_t* point_indices,
                        const double* points_2d, const double* K);
+/* Same with the pixels as the reference holds them, (N,2) int64 (graph.py:112-113): saves the caller a
+ * converted copy. */
+int  sfmba_set_problem_i64(sfmba_handle* h, int64_t n_cameras, int64_t n_points, int64_t n_obs,
+                           const int64_t* camera_indices, const int64_t* point_indices,
+                           const int64_t* points_2d, const double* K);
 
 /* Observation sharding: this handle holds the local shard (its own points + their observations,
  * all cameras replicated); n_obs_total counts all shards.  `arena` is device memory of at least

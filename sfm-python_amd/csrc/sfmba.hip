@@ -999,8 +999,21 @@ int sfmba_p2p_detach(sfmba_handle* h) {
 
 int64_t sfmba_p2p_calls(const sfmba_handle* h) { return h ? h->p2p.calls : 0; }
 
+static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, const int64_t* cam, const int64_t* pt,
+                            const double* uv, const int64_t* uv_i64, const double* K);
+
 int sfmba_set_problem(sfmba_handle* h, int64_t C, int64_t P, int64_t N, const int64_t* cam, const int64_t* pt,
                       const double* uv, const double* K) {
+    return set_problem_impl(h, C, P, N, cam, pt, uv, nullptr, K);
+}
+
+int sfmba_set_problem_i64(sfmba_handle* h, int64_t C, int64_t P, int64_t N, const int64_t* cam, const int64_t* pt,
+                          const int64_t* uv, const double* K) {
+    return set_problem_impl(h, C, P, N, cam, pt, nullptr, uv, K);
+}
+
+static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, const int64_t* cam, const int64_t* pt,
+                            const double* uv, const int64_t* uv_i64, const double* K) {
     CHK(enter(h));
     const bool timing = std::getenv("SFMBA_DEBUG_TIMING") != nullptr;
     const double tp0 = now_s();
@@ -1008,7 +1021,7 @@ int sfmba_set_problem(sfmba_handle* h, int64_t C, int64_t P, int64_t N, const in
     h->have_problem = false;
     h->solved = false;
     if (C <= 0 || P <= 0 || N <= 0) return fail(h, -1, "n_cameras, n_points, n_obs must be positive");
-    if (!cam || !pt || !uv || !K) return fail(h, -1, "NULL array argument");
+    if (!cam || !pt || (!uv && !uv_i64) || !K) return fail(h, -1, "NULL array argument");
     if (N >= (int64_t)1 << 30 || 6 * C + 3 * P >= (int64_t)1 << 31)
         return fail(h, -1, "problem too large for 32-bit observation indices");
     bool sorted = true;
@@ -1062,7 +1075,8 @@ int sfmba_set_problem(sfmba_handle* h, int64_t C, int64_t P, int64_t N, const in
         for (int64_t k = b; k < e; ++k) {
             const int64_t s = ord ? ord[k] : k;
             ci[k] = (int)cam[s]; pi[k] = (int)pt[s];
-            uvs[2 * k] = uv[2 * s]; uvs[2 * k + 1] = uv[2 * s + 1];
+            if (uv) { uvs[2 * k] = uv[2 * s]; uvs[2 * k + 1] = uv[2 * s + 1]; }
+            else { uvs[2 * k] = (double)uv_i64[2 * s]; uvs[2 * k + 1] = (double)uv_i64[2 * s + 1]; }   // as numpy promotes
         }
     });
     // ptr[p] = first position whose point index is >= p (pi is non-decreasing now): every run start k writes

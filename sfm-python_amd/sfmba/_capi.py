@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("SFMBA_LIB") or os.path.join(_HERE, "libsfmba.so")   #
 # every symbol include/sfmba.h declares (tests check the library exports each of them)
 SYMBOLS = (
     "sfmba_create", "sfmba_destroy", "sfmba_last_error", "sfmba_default_options", "sfmba_set_stream",
-    "sfmba_set_problem", "sfmba_exchange_doubles", "sfmba_set_exchange", "sfmba_residuals",
+    "sfmba_set_problem", "sfmba_set_problem_i64", "sfmba_exchange_doubles", "sfmba_set_exchange", "sfmba_residuals",
     "sfmba_residual_jacobian", "sfmba_solve", "sfmba_get_fun_grad", "sfmba_time_kernel",
     "sfmba_normal_blocks", "sfmba_schur_matvec", "sfmba_comm_get_unique_id", "sfmba_comm_init",
     "sfmba_comm_destroy", "sfmba_set_precision", "sfmba_p2p_export", "sfmba_p2p_attach", "sfmba_p2p_detach",
@@ -65,6 +65,7 @@ def load():
     lib.sfmba_default_options.restype = None
     lib.sfmba_set_stream.argtypes = [P, P]
     lib.sfmba_set_problem.argtypes = [P, C.c_int64, C.c_int64, C.c_int64, P, P, P, P]
+    lib.sfmba_set_problem_i64.argtypes = [P, C.c_int64, C.c_int64, C.c_int64, P, P, P, P]
     lib.sfmba_exchange_doubles.argtypes = [C.c_int64]
     lib.sfmba_exchange_doubles.restype = C.c_int64
     lib.sfmba_set_exchange.argtypes = [P, P, C.c_int64, ALLREDUCE_FN, P, C.c_int64]
@@ -85,7 +86,7 @@ def load():
     lib.sfmba_p2p_detach.argtypes = [P]
     lib.sfmba_p2p_calls.argtypes = [P]
     lib.sfmba_p2p_calls.restype = C.c_int64
-    for name in ("sfmba_set_stream", "sfmba_set_problem", "sfmba_set_exchange", "sfmba_residuals",
+    for name in ("sfmba_set_stream", "sfmba_set_problem", "sfmba_set_problem_i64", "sfmba_set_exchange", "sfmba_residuals",
                  "sfmba_residual_jacobian", "sfmba_solve", "sfmba_get_fun_grad", "sfmba_time_kernel",
                  "sfmba_normal_blocks", "sfmba_schur_matvec", "sfmba_tr2d_solve", "sfmba_comm_get_unique_id",
                  "sfmba_comm_init", "sfmba_comm_destroy", "sfmba_set_precision", "sfmba_p2p_export",

@@ -71,11 +71,18 @@ class Backend:
         if ci.shape != pi.shape:
             raise ValueError("camera_indices and point_indices differ in length")
         n_obs = ci.shape[0]
-        uv = _f64(points_2d, (n_obs, 2), "points_2d")        # int pixels promoted as bundle_adjustment.py:41
         Kc = _f64(K, (3, 3), "K")
-        self._check(self._lib.sfmba_set_problem(self._h, int(n_cameras), int(n_points), n_obs,
-                                                _capi.ptr(ci), _capi.ptr(pi), _capi.ptr(uv),
-                                                _capi.ptr(Kc)))
+        p2 = np.asarray(points_2d)
+        if p2.dtype == np.int64 and p2.shape == (n_obs, 2) and p2.flags.c_contiguous:
+            # the reference's own pixel arrays (graph.py:112-113): handed over as they are
+            self._check(self._lib.sfmba_set_problem_i64(self._h, int(n_cameras), int(n_points), n_obs,
+                                                        _capi.ptr(ci), _capi.ptr(pi), _capi.ptr(p2),
+                                                        _capi.ptr(Kc)))
+        else:
+            uv = _f64(points_2d, (n_obs, 2), "points_2d")    # promoted as bundle_adjustment.py:41
+            self._check(self._lib.sfmba_set_problem(self._h, int(n_cameras), int(n_points), n_obs,
+                                                    _capi.ptr(ci), _capi.ptr(pi), _capi.ptr(uv),
+                                                    _capi.ptr(Kc)))
         self.n_cameras, self.n_points, self.n_obs = int(n_cameras), int(n_points), n_obs
         self._keep = []
 
