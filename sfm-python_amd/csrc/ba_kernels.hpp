@@ -1859,12 +1859,25 @@ struct P2pArgs {
     long long timeout;
     unsigned long long max_mask;              // bit e set: element e (< 64) is reduced with max although op is sum
                                               // (lets one collective carry sums and a maximum)
+    // Single-workgroup collectives (a few scalars) can also do the work around them, saving three launches per
+    // outer iteration: the final sums that produce the scalars (rider), and the hand-off post behind them.
+    Piggyback rider;                          // part == null: none
+    Mailbox post;                             // host == null: none
+    const double* skip;                       // speculative trial cancelled: no collective, but still post
 };
 
 __global__ __launch_bounds__(256) void k_p2p_allreduce(double* __restrict__ vec, int count, int op, P2pArgs a) {
     __shared__ unsigned s_last;
+    if (a.skip != nullptr && *a.skip != 0.0) {                // identical on all ranks: sequence number untouched
+        if (a.post.host != nullptr && blockIdx.x == 0 && threadIdx.x < 64) post_mailbox(a.post);
+        return;
+    }
     if (a.cancel != nullptr && *a.cancel != 0) return;        // grid-uniform, identical on all ranks
     const int tid = threadIdx.x;
+    if (a.rider.part != nullptr) {                            // (single workgroup) final sums that feed this collective
+        finish_in_block(a.rider);
+        __syncthreads();
+    }
     const unsigned long long seq = *a.seq + 1ull;             // the last workgroup to arrive publishes it
     const int par = (int)(seq & 1ull);
     const int per = (count + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -1904,6 +1917,10 @@ __global__ __launch_bounds__(256) void k_p2p_allreduce(double* __restrict__ vec,
             s = use_max ? fmax(s, v) : s + v;
         }
         vec[e] = s;
+    }
+    if (a.post.host != nullptr) {                             // (single workgroup) the reduced scalars go to the host
+        __syncthreads();
+        if (tid < 64) post_mailbox(a.post);
     }
 }
 

@@ -238,7 +238,8 @@ bool multi_rank(const sfmba_handle* h) { return h->p2p.ready || h->comm != nullp
 constexpr size_t kP2pFlagBytes = sizeof(unsigned long long) * 2 * kP2pMaxRanks * kP2pFlagStride;
 
 int p2p_allreduce(sfmba_handle* h, double* ptr, int64_t count, int op, const int* cancel,
-                  unsigned long long max_mask = 0) {
+                  unsigned long long max_mask = 0, const Piggyback* rider = nullptr, const Mailbox* post = nullptr,
+                  const double* skip = nullptr) {
     auto& p = h->p2p;
     P2pArgs a{};
     for (int q = 0; q < p.world; ++q) { a.data[q] = p.data[q]; a.flags[q] = p.flags[q]; }
@@ -246,6 +247,10 @@ int p2p_allreduce(sfmba_handle* h, double* ptr, int64_t count, int op, const int
     a.seq = reinterpret_cast<unsigned long long*>(p.words + 2);
     a.cancel = cancel;
     a.max_mask = max_mask;
+    if (rider) a.rider = *rider;
+    if (post) a.post = *post;
+    a.skip = skip;
+    if ((rider || post) && count > 512) return fail(h, -1, "rider / post need a single-workgroup collective");
     a.ticket = p.words; a.error = p.words + 1;
     a.timeout = 300000000ll;                              // 3 s of the 100 MHz wall clock
     const int grid = (int)std::min<int64_t>(kP2pMaxBlocks, std::max<int64_t>(1, (count + 511) / 512));
@@ -1403,9 +1408,10 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
     // host seeing intermediate values: the regularisation term is computed by k_prep on the device
     // and the PCG stops itself through its device-side control block) and ONE per trial step.
     std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
-    auto eval_jac = [&](const double* x, double* tab, int js, bool table_ready) -> int {   // K0 + K1, sum r^2 -> scalar 0
+    int np_cost = 0;                                                  // partial rows of the last K1 launch
+    auto eval_jac = [&](const double* x, double* tab, int js, bool table_ready, bool finish = true) -> int {   // K0 + K1, sum r^2 -> scalar 0
         if (!table_ready) CHK(launch_cam_table(h, x, tab));
-        int np = 0;
+        int& np = np_cost;
         if (opt.profile) {
             hipEvent_t a, b;
             HIPCHK(h, hipEventCreate(&a)); HIPCHK(h, hipEventCreate(&b));
@@ -1414,7 +1420,7 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
         } else {
             CHK((launch_resjac<true, true>(h, x, tab, js, &np)));
         }
-        CHK(launch_finish(h, h->part.as<double>(), np, 1, 0));
+        if (finish) CHK(launch_finish(h, h->part.as<double>(), np, 1, 0));
         return 0;
     };
     auto linearise = [&](int first) -> int {      // normal blocks, scale, gradient, q0..q4 at h->x
@@ -1467,19 +1473,22 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
         int np = 0;
         const bool scale_sums_rode = h->pending_scale_sums;
         CHK(launch_jdot(h, &np));                               // t1 = J D^2 g, G11 = |t1|^2
-        if (!one_rank) {
+        if (!one_rank && h->p2p.ready) {
+            // direct path: the collective's own workgroup first sums k_jdot's partials into slot 1, then reduces
+            // slots 1..12 over the ranks when an accepted step left fresh q1..q4 (8..11, sums) and max|g| (12, a
+            // maximum by the mask), G11 alone otherwise.  Slots 2..7 (G12, G22, q5..q8 of the previous iteration)
+            // are summed once more along the way; nothing reads them before k_backsub / k_vec_reduce rewrite them.
+            Piggyback pb{h->partB(), sc, FinishJob{}, 1, 1, 0};
+            pb.job.row0[0] = 0; pb.job.nrows[0] = np;
+            for (int k = 0; k < kNQ; ++k) { pb.job.slot[0][k] = 1 + k; pb.job.slot[1][k] = -1; }
+            static_assert(kMaxSlot == 12, "mask below assumes the maximum sits at the end of the run");
+            CHK(p2p_allreduce(h, sc + 1, scale_sums_rode ? kMaxSlot : 1, 0, nullptr,
+                              scale_sums_rode ? 1ull << (kMaxSlot - 1) : 0ull, &pb));
+            ++h->n_collectives;
+        } else if (!one_rank) {
             CHK(launch_finish(h, h->partB(), np, 1, 1));
-            if (scale_sums_rode && h->p2p.ready) {
-                // one collective for slots 1..12: G11 (fresh), q1..q4 (8..11, fresh) as sums and max|g| (12,
-                // fresh) as a maximum.  Slots 2..7 (G12, G22, q5..q8 of the previous iteration) are summed once
-                // more along the way; nothing reads them before k_backsub / k_vec_reduce rewrite them.
-                static_assert(kMaxSlot == 12, "mask below assumes the maximum sits at the end of the run");
-                CHK(p2p_allreduce(h, sc + 1, kMaxSlot, 0, nullptr, 1ull << (kMaxSlot - 1)));
-                ++h->n_collectives;
-            } else {
-                if (scale_sums_rode) CHK(exchange_linearise(h));    // q1..q4, max|g| of the accepted point
-                CHK(exchange(h, sc + 1, 1, 0));
-            }
+            if (scale_sums_rode) CHK(exchange_linearise(h));        // q1..q4, max|g| of the accepted point
+            CHK(exchange(h, sc + 1, 1, 0));
         }
         {   // regularisation (trf.py:471-475), Vinv/e per point, Dc/Minv per camera, acc0 = 0: one launch
             const int bc = (int)((C + 63) / 64), bp = (int)((P + 63) / 64);
@@ -1504,6 +1513,13 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
         // k_vec_reduce's final sums itself
         auto tail = [&](bool for_device_step) -> int {
             CHK(launch_backsub(h, &np));
+            if (!one_rank && h->p2p.ready) {                    // k_vec_reduce's sums inside the collective's workgroup
+                CHK(launch_vec_reduce(h, np, false));
+                const Piggyback pb = slices_rider(h, 5, 8);
+                CHK(p2p_allreduce(h, sc + 2, 6, 0, nullptr, 0, &pb));
+                ++h->n_collectives;
+                return 0;
+            }
             CHK(launch_vec_reduce(h, np, !(for_device_step && one_rank)));
             CHK(exchange_tail(h));
             return 0;
@@ -1524,6 +1540,17 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
             // block) into the host mailbox; with several ranks the post follows the all-reduce of the cost.
             const Mailbox mb{h->mbox_dev, sc, h->ctrl.as<PcgCtrl>() + (h->pcg_L & 1), ++h->mbox_seq};
             const bool ranks = multi_rank(h);
+            if (ranks && h->p2p.ready) {
+                // direct path: ONE single-workgroup launch sums K1's cost partials, reduces the cost over the
+                // ranks and posts the hand-off (or only posts, when k_tr_step cancelled the trial)
+                CHK(eval_jac(h->x_new, h->tab_new, h->jcur, true, /*finish=*/false));
+                Piggyback pb{h->part.as<double>(), sc, FinishJob{}, 1, 1, 0};
+                pb.job.row0[0] = 0; pb.job.nrows[0] = np_cost;
+                for (int k = 0; k < kNQ; ++k) { pb.job.slot[0][k] = k; pb.job.slot[1][k] = -1; }
+                CHK(p2p_allreduce(h, sc, 1, 0, nullptr, 0, &pb, &mb, h->skip));
+                ++h->n_collectives;
+                return 0;
+            }
             if (!ranks) h->post = mb;
             const int rc = eval_jac(h->x_new, h->tab_new, h->jcur, true);
             h->post = Mailbox{};
