@@ -157,8 +157,13 @@ def main():
                 ex = sdist.Exchange(be, n_obs_local=N, device="cuda")
             link = None
             if world > 1 and not a.no_direct:
-                link = sdist.DirectLink(be)
-                if not link.active and rank == 0:
+                try:
+                    link = sdist.DirectLink(be)
+                except Exception as exc:                      # noqa: BLE001 -- keep the run alive on the other transport
+                    print(f"[bench] direct all-reduce set-up raised ({exc}); continuing without it",
+                          file=sys.stderr, flush=True)
+                    link = None
+                if (link is None or not link.active) and rank == 0:
                     print("[bench] direct all-reduce unavailable (peer mapping or self-test failed); collectives "
                           f"use the {a.exchange} transport", file=sys.stderr, flush=True)
 
