@@ -18,7 +18,8 @@
  *
  * Return codes: 0 OK; -1 bad argument / shape / index out of range; -2 residuals not finite at x0
  * (scipy raises ValueError there, SCIPY/optimize/_lsq/least_squares.py:844-845); -3 HIP failure;
- * -4 out of memory; -5 collective (all-reduce callback) failure.  The solver outcome is NOT an error:
+ * -4 out of memory; -5 collective failure (RCCL, the all-reduce callback, peer mapping, or a direct
+ * all-reduce that gave up waiting for a peer).  The solver outcome is NOT an error:
  * it is sfmba_result.status, scipy's 0..4 (SCIPY/optimize/_lsq/least_squares.py:18-25).
  *
  * Threading: one handle is not thread-safe; distinct handles are independent; every entry point
