@@ -130,7 +130,8 @@ constexpr int kNQ = 9;
 // Final sums of partial rows.  One wave per quantity; quantity k < first_sum is a max, else a sum;
 // slice y covers the partial rows [row0[y], row0[y] + nrows[y]) and writes quantity k to
 // out[slot[y][k]] (slot < 0: not written).  Fixed lane->row mapping: deterministic.
-struct FinishJob { int row0[2], nrows[2], slot[2][kNQ]; };
+constexpr int kFinishCols = 10;      // widest partial row: k_backsub's (G12, G22, q5..q8 of the points, q5..q8 of the cameras)
+struct FinishJob { int row0[2], nrows[2], slot[2][kFinishCols]; };
 
 __device__ __forceinline__ void finish_task(const double* __restrict__ part, const FinishJob& job, int y, int k,
                                             int nq, int first_sum, double* __restrict__ out) {     // one wave
@@ -303,7 +304,7 @@ __global__ void k_cam_table(const double* __restrict__ xc, int C, double* __rest
 // camera-slice sums).
 __global__ void k_tr_step(double* __restrict__ sc, double Delta, const PcgCtrl* __restrict__ ctrl,
                           Piggyback pb) {
-    if (pb.part != nullptr) {            // the last reduction the model needs (k_vec_reduce's sums), done here
+    if (pb.part != nullptr) {            // the last reduction the model needs (k_backsub's partial rows), done here
         finish_in_block(pb);
         __syncthreads();
     }
@@ -886,35 +887,6 @@ __global__ __launch_bounds__(256) void k_update_scale(const double* __restrict__
     write_partials(q, part);
 }
 
-__global__ __launch_bounds__(256) void k_vec_reduce(const double* __restrict__ g,
-                                                    const double* __restrict__ si,
-                                                    const double* __restrict__ x,
-                                                    const double* __restrict__ sg,
-                                                    const double* __restrict__ p, int C, int P, int bc,
-                                                    double* __restrict__ part, Piggyback pb) {
-    const int nwork = pb.part != nullptr ? (int)gridDim.x - 1 : (int)gridDim.x;
-    if ((int)blockIdx.x == nwork) { finish_in_block(pb); return; }      // rider block: another kernel's sums
-    const int64_t n6 = 6 * (int64_t)C, n = n6 + 3 * (int64_t)P;
-    int64_t e0, e1;
-    int b, nb;
-    slice_of_block(bc, nwork, n6, n, e0, e1, b, nb);
-    double q[kNQ];
-#pragma unroll
-    for (int k = 0; k < kNQ; ++k) q[k] = 0.0;
-    for (int64_t e = e0 + b * (int64_t)blockDim.x + threadIdx.x; e < e1; e += (int64_t)nb * blockDim.x) {
-        const double ge = g[e], s = si[e], xe = x[e], sge = sg[e], pe = p[e];
-        q[0] = fmax(q[0], fabs(ge));
-        q[1] += (ge / s) * (ge / s);
-        q[2] += (xe * s) * (xe * s);
-        q[3] += xe * xe;
-        q[4] += sge * sge;
-        q[5] += ge * pe;
-        q[6] += (pe * s) * (pe * s);
-        q[7] += sge * pe;
-        q[8] += pe * pe;
-    }
-    write_partials(q, part);
-}
 
 //
 // Mailbox: the hand-off of an outer iteration.  One wave copies the 32 exchange scalars and the PCG
@@ -1705,17 +1677,21 @@ __global__ __launch_bounds__(1024) void k_pcg_update(double* __restrict__ acc,
     }
 }
 
-// Back-substitution dp = Vinv (-g_p - sum_i W_i^T dc) per point, fused with the products the 2-D
-// trust-region model needs (SCIPY trf.py:481-485): t2_i = J p (p = [dc; dp]),
-// part[block] = (sum t1.t2, sum t2.t2) with t1 = J D^2 g from k_jdot.
+// Back-substitution dp = Vinv (-g_p - sum_i W_i^T dc) per point, fused with everything the 2-D
+// trust-region model needs of the new step p = [dc; dp] (SCIPY trf.py:481-485): t2_i = J p with the Gram
+// sums G12 = sum t1.t2, G22 = sum t2.t2 (t1 = J D^2 g from k_jdot), and the four dot products
+// q5 = g.p, q6 = |p s|^2, q7 = (D^2 g).p, q8 = |p|^2 -- the point part where each dp is produced (run heads),
+// the camera part by workgroup 0.  part[block] = (G12, G22, q5..q8 points, q5..q8 cameras), kBacksubCols wide.
+constexpr int kBacksubCols = 10;
 template <bool LDS_VEC>
 __global__ __launch_bounds__(kSweepThreads) void k_backsub(
     const int2* __restrict__ ranges, int n_ranges, ObsArrays o, const double* __restrict__ dc_planes,
     double* __restrict__ dc, const double* __restrict__ Vinv, const double* __restrict__ gp,
     const double* __restrict__ t1, double* __restrict__ dp, double* __restrict__ part, int C,
-    const PcgCtrl* __restrict__ ctrl2, int L) {
+    const PcgCtrl* __restrict__ ctrl2, int L, const double* __restrict__ gvec,
+    const double* __restrict__ si, const double* __restrict__ sg) {
     extern __shared__ __align__(16) double smem[];
-    __shared__ double red[2 * kWavesPerSweepBlock];
+    __shared__ double red[kBacksubCols * kWavesPerSweepBlock];
     if (ctrl2 != nullptr)                      // dc_planes = base of the PCG vector sets: take x of the final set
         dc_planes += (size_t)((ctrl2[L & 1].iters & 1) * kPcgVecs + kPcgX) * 6 * C;
     // dc_planes: PCG solution, plane-major [6][C]; dc: camera-major [C][6] copy (already written by
@@ -1735,12 +1711,23 @@ __global__ __launch_bounds__(kSweepThreads) void k_backsub(
     int pos = 0, end = 0;
     if (wg < n_ranges) { const int2 rg = ranges[wg]; pos = rg.x; end = rg.y; }
     double g12 = 0.0, g22 = 0.0;
+    double qs[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};       // q5..q8: [0..3] points, [4..7] cameras
+    auto dots = [&](double* q, size_t e, double pe) {              // element e of the parameter vector, step pe
+        const double s = si[e];
+        q[0] += gvec[e] * pe; q[1] += (pe * s) * (pe * s); q[2] += sg[e] * pe; q[3] += pe * pe;
+    };
+    if (blockIdx.x == 0)                                           // camera slice (dc is camera-major like x)
+        for (int e = threadIdx.x; e < 6 * C; e += blockDim.x) dots(qs + 4, (size_t)e, vv[e]);
 
     auto jcv = [&](const double* jc, int c, double& t0, double& t1v) {
         const double* a = vv + 6 * c;
         t0 = 0.0; t1v = 0.0;
 #pragma unroll
         for (int k = 0; k < 6; ++k) { t0 += jc[k] * a[k]; t1v += jc[6 + k] * a[k]; }
+    };
+    auto point_dots = [&](int p, double z0, double z1, double z2) {
+        const size_t e = 6 * (size_t)C + 3 * (size_t)p;
+        dots(qs, e, z0); dots(qs, e + 1, z1); dots(qs, e + 2, z2);
     };
     auto solve_point = [&](int p, const double* y, double& z0, double& z1, double& z2) {
         const double* vi = Vinv + 6 * (size_t)p;
@@ -1781,6 +1768,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_backsub(
             y[0] = wave_sum(y[0]); y[1] = wave_sum(y[1]); y[2] = wave_sum(y[2]);
             double z0, z1, z2;
             solve_point(pp, y, z0, z1, z2);              // every lane writes the same values
+            if (lane == 0) point_dots(pp, z0, z1, z2);
             for (int j = pos + lane; j < run_end; j += 64) {
                 load_blocks(o, j, jc, jp);
                 double t0, t1v;
@@ -1800,21 +1788,26 @@ __global__ __launch_bounds__(kSweepThreads) void k_backsub(
             y[2] = jp[2] * t0 + jp[5] * t1v;
         }
         seg_reduce<3>(y, act ? sb : -1 - lane, lane);
-        if (act && i == sb) solve_point(p, y, z0, z1, z2);
+        if (act && i == sb) { solve_point(p, y, z0, z1, z2); point_dots(p, z0, z1, z2); }
         const int head = act ? lane - (i - sb) : lane;
         z0 = __shfl(z0, head); z1 = __shfl(z1, head); z2 = __shfl(z2, head);
         if (act) gram(i, jp, t0, t1v, z0, z1, z2);
         pos += n_take;
     }
-    g12 = wave_sum(g12);
-    g22 = wave_sum(g22);
-    if (lane == 0) { red[2 * (threadIdx.x >> 6)] = g12; red[2 * (threadIdx.x >> 6) + 1] = g22; }
+    double row[kBacksubCols];
+    row[0] = wave_sum(g12);
+    row[1] = wave_sum(g22);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) row[2 + k] = wave_sum(qs[k]);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < kBacksubCols; ++k) red[kBacksubCols * (threadIdx.x >> 6) + k] = row[k];
+    }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double a = 0.0, b = 0.0;
-        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) { a += red[2 * k]; b += red[2 * k + 1]; }
-        part[2 * (size_t)blockIdx.x] = a;
-        part[2 * (size_t)blockIdx.x + 1] = b;
+    if (threadIdx.x < kBacksubCols) {                   // one thread per column, waves added in fixed order
+        double a = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) a += red[kBacksubCols * w + threadIdx.x];
+        part[(size_t)kBacksubCols * blockIdx.x + threadIdx.x] = a;
     }
 }
 

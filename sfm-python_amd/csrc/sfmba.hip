@@ -34,7 +34,7 @@ using namespace sfmba;
 namespace {
 
 constexpr size_t kLdsBytes = 160 * 1024;       // gfx950: 160 KiB LDS per workgroup
-constexpr size_t kLdsDynMax = kLdsBytes - 512; // dynamic part; every kernel here has <= 512 B static LDS
+constexpr size_t kLdsDynMax = kLdsBytes - 2048; // dynamic part; every kernel here has <= 2 KiB static LDS (k_backsub: 1280 B)
 // Scalars at the end of the exchange arena (32 doubles):
 //   summed over ranks [0..11]: 0 sum r^2 | 1 G11 | 2 G12 | 3 G22 | 4..7 q5..q8 | 8..11 q1..q4 of the point
 //                              slice (grouped so that each phase all-reduces one contiguous run of fresh values)
@@ -42,7 +42,7 @@ constexpr size_t kLdsDynMax = kLdsBytes - 512; // dynamic part; every kernel her
 //   device-local      [13]   : regularisation term of this iteration (k_prep)
 //   never exchanged   [16..24]: q0..q8 of the camera slice (replicated on every rank)
 constexpr int kScalSlots = 32;
-// Per-workgroup partial sums live in two halves of one buffer: A (k_update_scale, k_vec_reduce, the cost of
+// Per-workgroup partial sums live in two halves of one buffer: A (k_update_scale, the cost of
 // k_resjac) and B (k_jdot, k_backsub).  Consecutive producers alternate halves, so the final sums of one
 // producer can ride along with the NEXT producer's launch (Piggyback) without a race on the rows.
 constexpr int kPartRows = 2048;
@@ -406,19 +406,20 @@ int launch_resjac(sfmba_handle* h, const double* x, const double* tab, int js, i
 int launch_finish(sfmba_handle* h, const double* part, int nparts, int nq, int slot) {
     FinishJob job{};
     job.row0[0] = 0; job.nrows[0] = nparts;
-    for (int k = 0; k < kNQ; ++k) job.slot[0][k] = slot + k;
+    for (int k = 0; k < kFinishCols; ++k) { job.slot[0][k] = slot + k; job.slot[1][k] = -1; }
     hipLaunchKernelGGL(k_finish, dim3(1), dim3(64 * nq), 0, h->stream, part, job, nq, 0, h->scal(), h->skip,
                        h->post);
     HIPCHK(h, hipGetLastError());
     return 0;
 }
 
-// the two-slice (cameras | points) reductions of k_update_scale / k_vec_reduce; the point slice
+// the two-slice (cameras | points) reduction of k_update_scale; the point slice
 // publishes only quantities [q_lo, q_hi] (the others keep their already rank-reduced values)
 FinishJob slices_job(const sfmba_handle* h, int q_lo, int q_hi) {
     FinishJob job{};
     job.row0[0] = 0;         job.nrows[0] = h->red_bc;
     job.row0[1] = h->red_bc; job.nrows[1] = h->red_grid - h->red_bc;
+    for (int k = 0; k < kFinishCols; ++k) { job.slot[0][k] = -1; job.slot[1][k] = -1; }
     for (int k = 0; k < kNQ; ++k) {
         job.slot[0][k] = kCamSlot + k;
         job.slot[1][k] = (k >= q_lo && k <= q_hi) ? kPointSlot[k] : -1;
@@ -555,14 +556,15 @@ int launch_backsub(sfmba_handle* h, int* nparts) {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), lds, h->stream, h->ranges.as<int2>(),
                            h->n_ranges, obs_arrays(h), h->vecs.as<double>(), dc, h->Vinv.as<double>(),
                            h->gp.as<double>(), h->t1.as<double>(), dp, h->partB(), (int)h->C,
-                           ctrl2, h->pcg_L);
+                           ctrl2, h->pcg_L, h->g.as<double>(), h->si.as<double>(), h->sg.as<double>());
     } else {
         hipLaunchKernelGGL(k_transpose6, dim3((6 * h->C + 255) / 256), dim3(256), 0, h->stream,
                            h->vecs.as<double>(), (int)h->C, dc, ctrl2, h->pcg_L);
         hipLaunchKernelGGL(k_backsub<false>, dim3(grid), dim3(kSweepThreads), 0, h->stream,
                            h->ranges.as<int2>(), h->n_ranges, obs_arrays(h), h->vecs.as<double>(), dc,
                            h->Vinv.as<double>(), h->gp.as<double>(), h->t1.as<double>(), dp,
-                           h->partB(), (int)h->C, (const PcgCtrl*)nullptr, 0);
+                           h->partB(), (int)h->C, (const PcgCtrl*)nullptr, 0, h->g.as<double>(),
+                           h->si.as<double>(), h->sg.as<double>());
     }
     HIPCHK(h, hipGetLastError());
     *nparts = grid;
@@ -581,17 +583,22 @@ int launch_update_scale(sfmba_handle* h, int first, bool defer = false) {
 }
 
 // q0..q8 with the step vector p
-// One extra workgroup carries k_backsub's final sums (G12, G22: `nparts_backsub` rows of half B -> slots 2, 3).
-// `finish_own`: launch the final sums of this kernel too; otherwise k_tr_step does them (single rank).
-int launch_vec_reduce(sfmba_handle* h, int nparts_backsub, bool finish_own) {
-    Piggyback pb{h->partB(), h->scal(), FinishJob{}, 1, 2, 0};
-    pb.job.row0[0] = 0; pb.job.nrows[0] = nparts_backsub;
-    for (int k = 0; k < kNQ; ++k) { pb.job.slot[0][k] = 2 + k; pb.job.slot[1][k] = -1; }
-    hipLaunchKernelGGL(k_vec_reduce, dim3(h->red_grid + 1), dim3(256), 0, h->stream, h->g.as<double>(),
-                       h->si.as<double>(), h->x, h->sg.as<double>(), h->p.as<double>(), (int)h->C, (int)h->P,
-                       h->red_bc, h->part.as<double>(), pb);
+// Final sums of k_backsub's partial rows (half B, kBacksubCols wide): G12, G22 -> slots 2, 3; q5..q8 of the
+// point slice -> 4..7 (the run exchange_tail reduces over ranks); q5..q8 of the camera slice -> 21..24.
+Piggyback backsub_rider(sfmba_handle* h, int nparts) {
+    Piggyback pb{h->partB(), h->scal(), FinishJob{}, 1, kBacksubCols, 0};
+    pb.job.row0[0] = 0; pb.job.nrows[0] = nparts;
+    for (int k = 0; k < kFinishCols; ++k) { pb.job.slot[0][k] = -1; pb.job.slot[1][k] = -1; }
+    for (int k = 0; k < 6; ++k) pb.job.slot[0][k] = 2 + k;
+    for (int k = 0; k < 4; ++k) pb.job.slot[0][6 + k] = kCamSlot + 5 + k;
+    return pb;
+}
+int launch_finish_backsub(sfmba_handle* h, int nparts) {
+    const Piggyback pb = backsub_rider(h, nparts);
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64 * kBacksubCols), 0, h->stream, pb.part, pb.job, kBacksubCols, 0,
+                       h->scal(), (const double*)nullptr, Mailbox{});
     HIPCHK(h, hipGetLastError());
-    return finish_own ? launch_finish_slices(h, 5, 8) : 0;
+    return 0;
 }
 
 // all-reduce freshly written exchange scalars over ranks (no-op on one GPU); stays on the stream.
@@ -1466,8 +1473,8 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
         }
         // ---- enqueue the whole linear phase ---------------------------------------------------
         // Final sums of per-workgroup partials are not launches of their own where a neighbour can carry
-        // them: k_update_scale's ride with k_jdot, k_backsub's with k_vec_reduce; on a single rank k_jdot's
-        // are repeated by every workgroup of k_prep and k_vec_reduce's are done by k_tr_step (with several
+        // them: k_update_scale's ride with k_jdot; on a single rank k_jdot's are repeated by every workgroup
+        // of k_prep and k_backsub's are done by k_tr_step (with several
         // ranks the all-reduce has to sit between producer and consumer, so those two stay launches).
         const bool one_rank = !multi_rank(h);
         int np = 0;
@@ -1477,7 +1484,7 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
             // direct path: the collective's own workgroup first sums k_jdot's partials into slot 1, then reduces
             // slots 1..12 over the ranks when an accepted step left fresh q1..q4 (8..11, sums) and max|g| (12, a
             // maximum by the mask), G11 alone otherwise.  Slots 2..7 (G12, G22, q5..q8 of the previous iteration)
-            // are summed once more along the way; nothing reads them before k_backsub / k_vec_reduce rewrite them.
+            // are summed once more along the way; nothing reads them before k_backsub's sums rewrite them.
             Piggyback pb{h->partB(), sc, FinishJob{}, 1, 1, 0};
             pb.job.row0[0] = 0; pb.job.nrows[0] = np;
             for (int k = 0; k < kNQ; ++k) { pb.job.slot[0][k] = 1 + k; pb.job.slot[1][k] = -1; }
@@ -1509,18 +1516,19 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
         } else {
             CHK(pcg_finish_polling(h, opt, &hc));
         }
-        // back-substitution + model products; `for_device_step`: k_tr_step follows and (single rank) does
-        // k_vec_reduce's final sums itself
+        // back-substitution + model products (all in k_backsub); `for_device_step`: k_tr_step follows and
+        // (single rank) sums k_backsub's partial rows itself
+        int np_tail = 0;
         auto tail = [&](bool for_device_step) -> int {
             CHK(launch_backsub(h, &np));
-            if (!one_rank && h->p2p.ready) {                    // k_vec_reduce's sums inside the collective's workgroup
-                CHK(launch_vec_reduce(h, np, false));
-                const Piggyback pb = slices_rider(h, 5, 8);
+            np_tail = np;
+            if (!one_rank && h->p2p.ready) {                    // the sums run inside the collective's workgroup
+                const Piggyback pb = backsub_rider(h, np);
                 CHK(p2p_allreduce(h, sc + 2, 6, 0, nullptr, 0, &pb));
                 ++h->n_collectives;
                 return 0;
             }
-            CHK(launch_vec_reduce(h, np, !(for_device_step && one_rank)));
+            if (!(for_device_step && one_rank)) CHK(launch_finish_backsub(h, np));
             CHK(exchange_tail(h));
             return 0;
         };
@@ -1578,7 +1586,7 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
         const bool speculative = pcg_guess > 0;
         hipLaunchKernelGGL(k_tr_step, dim3(1), dim3(one_rank ? 1024 : 64), 0, h->stream, sc, Delta,
                            speculative ? (const PcgCtrl*)(h->ctrl.as<PcgCtrl>() + (h->pcg_L & 1)) : (const PcgCtrl*)nullptr,
-                           one_rank ? slices_rider(h, 5, 8) : Piggyback{});
+                           one_rank ? backsub_rider(h, np_tail) : Piggyback{});
         HIPCHK(h, hipGetLastError());
         h->skip = sc + 30;                                      // k_tr_step's verdict gates every launch below
         int rc_trial = enqueue_trial(sc + 25, 0.0, 0.0);
