@@ -1681,7 +1681,7 @@ __global__ __launch_bounds__(1024) void k_pcg_update(double* __restrict__ acc,
 // trust-region model needs of the new step p = [dc; dp] (SCIPY trf.py:481-485): t2_i = J p with the Gram
 // sums G12 = sum t1.t2, G22 = sum t2.t2 (t1 = J D^2 g from k_jdot), and the four dot products
 // q5 = g.p, q6 = |p s|^2, q7 = (D^2 g).p, q8 = |p|^2 -- the point part where each dp is produced (run heads),
-// the camera part by workgroup 0.  part[block] = (G12, G22, q5..q8 points, q5..q8 cameras), kBacksubCols wide.
+// the camera part spread over the workgroups.  part[block] = (G12, G22, q5..q8 points, q5..q8 cameras), kBacksubCols wide.
 constexpr int kBacksubCols = 10;
 template <bool LDS_VEC>
 __global__ __launch_bounds__(kSweepThreads) void k_backsub(
@@ -1716,8 +1716,6 @@ __global__ __launch_bounds__(kSweepThreads) void k_backsub(
         const double s = si[e];
         q[0] += gvec[e] * pe; q[1] += (pe * s) * (pe * s); q[2] += sg[e] * pe; q[3] += pe * pe;
     };
-    if (blockIdx.x == 0)                                           // camera slice (dc is camera-major like x)
-        for (int e = threadIdx.x; e < 6 * C; e += blockDim.x) dots(qs + 4, (size_t)e, vv[e]);
 
     auto jcv = [&](const double* jc, int c, double& t0, double& t1v) {
         const double* a = vv + 6 * c;
@@ -1725,9 +1723,15 @@ __global__ __launch_bounds__(kSweepThreads) void k_backsub(
 #pragma unroll
         for (int k = 0; k < 6; ++k) { t0 += jc[k] * a[k]; t1v += jc[6 + k] * a[k]; }
     };
-    auto point_dots = [&](int p, double z0, double z1, double z2) {
-        const size_t e = 6 * (size_t)C + 3 * (size_t)p;
-        dots(qs, e, z0); dots(qs, e + 1, z1); dots(qs, e + 2, z2);
+    // point entries: g is g_p itself and D^2 g = g / s^2 exactly as k_update_scale formed it, so only the
+    // three scale entries have to be fetched
+    auto point_dots = [&](int p, const double* s3, double z0, double z1, double z2) {
+        const double z[3] = {z0, z1, z2};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double s_ = s3[k], ge = gp[3 * (size_t)p + k], pe = z[k];
+            qs[0] += ge * pe; qs[1] += (pe * s_) * (pe * s_); qs[2] += (ge / (s_ * s_)) * pe; qs[3] += pe * pe;
+        }
     };
     auto solve_point = [&](int p, const double* y, double& z0, double& z1, double& z2) {
         const double* vi = Vinv + 6 * (size_t)p;
@@ -1768,7 +1772,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_backsub(
             y[0] = wave_sum(y[0]); y[1] = wave_sum(y[1]); y[2] = wave_sum(y[2]);
             double z0, z1, z2;
             solve_point(pp, y, z0, z1, z2);              // every lane writes the same values
-            if (lane == 0) point_dots(pp, z0, z1, z2);
+            if (lane == 0) point_dots(pp, si + 6 * (size_t)C + 3 * (size_t)pp, z0, z1, z2);
             for (int j = pos + lane; j < run_end; j += 64) {
                 load_blocks(o, j, jc, jp);
                 double t0, t1v;
@@ -1781,18 +1785,27 @@ __global__ __launch_bounds__(kSweepThreads) void k_backsub(
         const bool act = lane < n_take;
         double t0 = 0.0, t1v = 0.0, z0 = 0.0, z1 = 0.0, z2 = 0.0;
         double y[3] = {0.0, 0.0, 0.0};
-        if (act) {
+        double s3[3] = {1.0, 1.0, 1.0};        // scale entries of the lane's point, requested with the blocks so
+        if (act) {                             // that the run head does not wait for them after the reduction
             load_blocks(o, i, jc, jp);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s3[k] = si[6 * (size_t)C + 3 * (size_t)p + k];
             jcv(jc, o.cam_idx[i], t0, t1v);
             y[0] = jp[0] * t0 + jp[3] * t1v; y[1] = jp[1] * t0 + jp[4] * t1v;
             y[2] = jp[2] * t0 + jp[5] * t1v;
         }
         seg_reduce<3>(y, act ? sb : -1 - lane, lane);
-        if (act && i == sb) { solve_point(p, y, z0, z1, z2); point_dots(p, z0, z1, z2); }
+        if (act && i == sb) { solve_point(p, y, z0, z1, z2); point_dots(p, s3, z0, z1, z2); }
         const int head = act ? lane - (i - sb) : lane;
         z0 = __shfl(z0, head); z1 = __shfl(z1, head); z2 = __shfl(z2, head);
         if (act) gram(i, jp, t0, t1v, z0, z1, z2);
         pos += n_take;
+    }
+    {   // camera slice (dc is camera-major like x), a few elements per workgroup so that none straggles;
+        // after the sweep, so that its four sums are not live across it
+        const int per = (6 * C + (int)gridDim.x - 1) / (int)gridDim.x;
+        const int e = (int)blockIdx.x * per + (int)threadIdx.x;
+        if ((int)threadIdx.x < per && e < 6 * C) dots(qs + 4, (size_t)e, vv[e]);
     }
     double row[kBacksubCols];
     row[0] = wave_sum(g12);
