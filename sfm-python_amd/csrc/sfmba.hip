@@ -192,7 +192,7 @@ struct sfmba_handle {
     double* Ugc() const { return arena + 18 * C; }
     double* scal() const { return arena + 45 * C; }
     int pcg_L = 0;                           // launches (sweep+update pairs) since pcg_start
-    int red_bc = 1, red_grid = 2;            // block split of the parameter-vector reductions
+    int red_bc = 1, red_grid = 2;            // block split of k_update_scale's reduction (cameras | points)
     double* partB() const { return part.as<double>() + (size_t)kPartRows * kNQ; }
     bool pending_scale_sums = false;         // k_update_scale ran, its final sums ride with the next k_jdot
 };
@@ -1192,7 +1192,7 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     HIPCHK(h, h->vtmp.ensure(sizeof(double) * 6 * C));
     HIPCHK(h, h->vcm.ensure(sizeof(double) * 6 * C));
     h->red_bc = grid_1d(6 * C, 256, 32);
-    h->red_grid = h->red_bc + grid_1d(3 * P, 256, 224);   // <= 256 partial rows: k_tr_step sums them itself
+    h->red_grid = h->red_bc + grid_1d(3 * P, 256, 992);   // <= 1024 partial rows, summed by k_jdot's rider workgroup
     HIPCHK(h, h->part.ensure(sizeof(double) * (size_t)(2 * kPartRows * kNQ)));
     HIPCHK(h, h->ctrl.ensure(2 * sizeof(PcgCtrl)));
     if (h->nb_passes > 0) {
