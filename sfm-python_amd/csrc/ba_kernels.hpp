@@ -79,10 +79,30 @@ struct PcgCtrl {
 #define SFMBA_STAMP(ctrl, k) do {} while (0)
 #endif
 
+// Cross-lane moves that stay in the VALU (DPP row shifts, v_readlane) instead of going through the LDS pipe
+// as ds_bpermute does; row_shl:N makes lane i read lane i+N of its 16-lane row (0 when that leaves the row).
+template <int CTRL>
+__device__ __forceinline__ int dpp_int(int x) {        // source lane out of the row: 0
+    return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_double(double x) {
+    const int lo = dpp_int<CTRL>(__double2loint(x)), hi = dpp_int<CTRL>(__double2hiint(x));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_double(double x, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
+    return __hiloint2double(hi, lo);
+}
+
+// Sum over the wave, result on every lane: suffix sums inside the four rows, then the four row totals.
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += dpp_double<0x101>(v);
+    v += dpp_double<0x102>(v);
+    v += dpp_double<0x104>(v);
+    v += dpp_double<0x108>(v);
+    return ((readlane_double(v, 0) + readlane_double(v, 16)) + readlane_double(v, 32)) + readlane_double(v, 48);
 }
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
@@ -175,20 +195,6 @@ __device__ __forceinline__ void finish_in_block(const Piggyback& pb) {
 //   when the key n lanes up equals its own -- keys are sorted, so everything between belongs to the run;
 //   across rows: from the top row down, the first lane of the next row (by then complete) is broadcast with
 //   v_readlane and added by the lanes of this row that carry its key.
-template <int CTRL>
-__device__ __forceinline__ int dpp_int(int x) {        // source lane out of the row: 0
-    return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true);
-}
-template <int CTRL>
-__device__ __forceinline__ double dpp_double(double x) {
-    const int lo = dpp_int<CTRL>(__double2loint(x)), hi = dpp_int<CTRL>(__double2hiint(x));
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double readlane_double(double x, int src) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(x), src);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
-    return __hiloint2double(hi, lo);
-}
 
 #if defined(SFMBA_SEGRED_SHFL)      // the shuffle form, kept for A/B timing
 template <int NV>
