@@ -1406,9 +1406,17 @@ __global__ __launch_bounds__(kSweepThreads) void k_schur_sweep(
     auto jcv = [&](const double* jc, int cc, double& t0, double& t1) {
         t0 = 0.0; t1 = 0.0;
         if (MODE == 0) {
-            const double* a = vv + cs * cc;
+            if (ACC == 1) {                        // LDS row of 48 bytes, 16-byte aligned: three 128-bit reads
+                const double2* a2 = reinterpret_cast<const double2*>(s_v + 6 * cc);
+                const double2 a01 = a2[0], a23 = a2[1], a45 = a2[2];
+                const double a[6] = {a01.x, a01.y, a23.x, a23.y, a45.x, a45.y};
 #pragma unroll
-            for (int k = 0; k < 6; ++k) { const double ak = a[ks * k]; t0 += jc[k] * ak; t1 += jc[6 + k] * ak; }
+                for (int k = 0; k < 6; ++k) { t0 += jc[k] * a[k]; t1 += jc[6 + k] * a[k]; }
+            } else {
+                const double* a = vv + cs * cc;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) { const double ak = a[ks * k]; t0 += jc[k] * ak; t1 += jc[6 + k] * ak; }
+            }
         }
     };
     auto scatter = [&](const double* jc, const double* jp, int cc, double t0, double t1, double z0,
