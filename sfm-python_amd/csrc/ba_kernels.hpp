@@ -956,7 +956,9 @@ __global__ __launch_bounds__(kSweepThreads) void k_jdot(ObsArrays o, const doubl
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += nwork * blockDim.x) {
         double jc[12], jp[6];
         load_blocks(o, i, jc, jp);
-        const double* a = vc + 6 * o.cam_idx[i];
+        const double2* a2 = reinterpret_cast<const double2*>(vc + 6 * o.cam_idx[i]);    // 16-byte aligned rows
+        const double2 a01 = a2[0], a23 = a2[1], a45 = a2[2];
+        const double a[6] = {a01.x, a01.y, a23.x, a23.y, a45.x, a45.y};
         const double* b = sgp + 3 * (size_t)o.pt_idx[i];
         double t0 = 0.0, t1v = 0.0;
 #pragma unroll
@@ -1732,7 +1734,10 @@ __global__ __launch_bounds__(kSweepThreads) void k_backsub(
     };
 
     auto jcv = [&](const double* jc, int c, double& t0, double& t1v) {
-        const double* a = vv + 6 * c;
+        // 48-byte rows, 16-byte aligned in both placements: three 128-bit reads
+        const double2* a2 = reinterpret_cast<const double2*>(vv + 6 * c);
+        const double2 a01 = a2[0], a23 = a2[1], a45 = a2[2];
+        const double a[6] = {a01.x, a01.y, a23.x, a23.y, a45.x, a45.y};
         t0 = 0.0; t1v = 0.0;
 #pragma unroll
         for (int k = 0; k < 6; ++k) { t0 += jc[k] * a[k]; t1v += jc[6 + k] * a[k]; }
