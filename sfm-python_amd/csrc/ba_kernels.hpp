@@ -791,29 +791,33 @@ __global__ __launch_bounds__(kSweepThreads) void k_normal_blocks_lds(
 // Ugc[c][col0 + k] = sum over workgroup tables, fixed order.  Block = 64 entries x 16 slices of the
 // workgroup axis (independent loads in flight), combined through LDS in slice order.
 __global__ __launch_bounds__(1024) void k_reduce_tables(const double* __restrict__ partial, int nblocks,
-                                                        int C, int per, int npasses,
+                                                        int C, int per, int only_pass,
                                                         double* __restrict__ Ugc,
                                                         const double* __restrict__ skip) {
-    // ONE launch for all column passes: pass q left its per-workgroup tables [nblocks][C * ncols_q] at
-    // partial + q * nblocks * C * per (ncols_q = per, except possibly the last pass).
+    // only_pass < 0: ONE launch for all column passes; pass q left its per-workgroup tables
+    // [nblocks][C * ncols_q] at partial + q * nblocks * C * per (ncols_q = per, except possibly the last pass).
+    // only_pass = q: the columns of pass q alone, whose tables start at `partial` (all passes reuse one buffer).
     __shared__ double sm[16][64];
     if (skip != nullptr && *skip != 0.0) return;   // speculative launch cancelled by k_tr_step
     const int nout = C * 27;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + tx;            // e = c * 27 + col
     double s = 0.0;
+    bool mine = false;
     if (e < nout) {
         const int c = e / 27, col = e - c * 27;
         const int q = col / per, colq = col - q * per;
         const int ncols = min(per, 27 - q * per);
         const size_t ntab = (size_t)C * ncols;
-        const double* __restrict__ src = partial + (size_t)q * nblocks * ((size_t)C * per) + (size_t)c * ncols + colq;
-        for (int b = ty; b < nblocks; b += 16) s += src[(size_t)b * ntab];
-        (void)npasses;
+        const double* __restrict__ src = partial + (only_pass < 0 ? (size_t)q * nblocks * ((size_t)C * per) : (size_t)0) +
+                                         (size_t)c * ncols + colq;
+        if (only_pass < 0 || q == only_pass)
+            for (int b = ty; b < nblocks; b += 16) s += src[(size_t)b * ntab];
+        mine = only_pass < 0 || q == only_pass;
     }
     sm[ty][tx] = s;
     __syncthreads();
-    if (ty == 0 && e < nout) {
+    if (ty == 0 && e < nout && mine) {
         double t = 0.0;
 #pragma unroll
         for (int k = 0; k < 16; ++k) t += sm[k][tx];

@@ -177,6 +177,8 @@ struct sfmba_handle {
     size_t h_x_doubles = 0;
     const double* skip = nullptr;         // device flag gating speculative trial launches (sfmba_solve); else null
     double pcg_tol = 0.0; int pcg_cap = 0; // options of the running PCG (fused launch 0 writes the control block)
+    bool nb_one_reduce = false;           // SFMBA_NB_ONE_REDUCE=1: keep the tables of all normal-block passes and reduce them
+                                          // in one launch (1.4 us less, but 27 MB more between two K1 launches: K1 +1.6 us)
     bool pcg_fused = false;               // PCG update fused into the sweep launch (acc_mode 1, C <= 1024)
     int pcg_hint = 0;                     // largest PCG iteration count a solve on this handle has needed
     bool solved = false;
@@ -450,14 +452,20 @@ int launch_normal_blocks(sfmba_handle* h) {
             hipLaunchKernelGGL(k_normal_blocks_lds, dim3(grid), dim3(kSweepThreads), lds, h->stream,
                                h->ranges.as<int2>(), h->n_ranges, obs_arrays(h), h->r[h->jcur].as<double>(),
                                h->V.as<double>(), h->gp.as<double>(),
-                               h->tables.as<double>() + (size_t)ps * grid * ((size_t)h->C * per), (int)h->C,
-                               col0, ncols, ps == 0 ? 1 : 0, h->skip);
+                               h->tables.as<double>() + (h->nb_one_reduce ? (size_t)ps * grid * ((size_t)h->C * per) : (size_t)0),
+                               (int)h->C, col0, ncols, ps == 0 ? 1 : 0, h->skip);
+            HIPCHK(h, hipGetLastError());
+            if (!h->nb_one_reduce) {          // all passes reuse one table buffer: reduce each before the next
+                hipLaunchKernelGGL(k_reduce_tables, dim3((27 * (int)h->C + 63) / 64), dim3(1024), 0, h->stream,
+                                   h->tables.as<double>(), grid, (int)h->C, per, ps, h->Ugc(), h->skip);
+                HIPCHK(h, hipGetLastError());
+            }
+        }
+        if (h->nb_one_reduce) {               // one reduction launch for the tables of all passes
+            hipLaunchKernelGGL(k_reduce_tables, dim3((27 * (int)h->C + 63) / 64), dim3(1024), 0, h->stream,
+                               h->tables.as<double>(), grid, (int)h->C, per, -1, h->Ugc(), h->skip);
             HIPCHK(h, hipGetLastError());
         }
-        // one reduction launch for the tables of all passes
-        hipLaunchKernelGGL(k_reduce_tables, dim3((27 * (int)h->C + 63) / 64), dim3(1024), 0, h->stream,
-                           h->tables.as<double>(), grid, (int)h->C, per, h->nb_passes, h->Ugc(), h->skip);
-        HIPCHK(h, hipGetLastError());
         return 0;
     }
     hipLaunchKernelGGL(k_fill, dim3(grid_1d(27 * h->C, 256, 2048)), dim3(256), 0, h->stream, h->Ugc(),
@@ -1150,6 +1158,7 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
         if (m == 0 || m == 2 || (m == 1 && h->lds_acc)) h->acc_mode = m;
         if (const char* r = std::getenv("SFMBA_ACC_RANGE")) h->acc_range = std::max(1, std::min(h->acc_range, std::atoi(r)));
     }
+    h->nb_one_reduce = std::getenv("SFMBA_NB_ONE_REDUCE") && std::atoi(std::getenv("SFMBA_NB_ONE_REDUCE")) != 0;
     h->pcg_fused = h->acc_mode == 1 && C <= kSweepThreads;
     if (const char* e = std::getenv("SFMBA_PCG_FUSED")) h->pcg_fused = h->pcg_fused && std::atoi(e) != 0;   // test hook
     {   // normal-block LDS tables: as many column passes as the 27 columns need (a pass costs ~25 us
@@ -1198,7 +1207,8 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     if (h->nb_passes > 0) {
         const int per = (27 + h->nb_passes - 1) / h->nb_passes;
         const size_t nblk = (ranges.size() + kWavesPerSweepBlock - 1) / kWavesPerSweepBlock;
-        HIPCHK(h, h->tables.ensure(sizeof(double) * std::max<size_t>(1, nblk) * (size_t)C * per * (size_t)h->nb_passes));
+        HIPCHK(h, h->tables.ensure(sizeof(double) * std::max<size_t>(1, nblk) * (size_t)C * per *
+                                   (size_t)(h->nb_one_reduce ? h->nb_passes : 1)));
     }
     HIPCHK(h, h->arena_own.ensure(sizeof(double) * (size_t)sfmba_exchange_doubles(C)));
     h->arena = h->arena_own.as<double>();
