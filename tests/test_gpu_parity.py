@@ -573,7 +573,7 @@ def test_exchange_path_world1_nccl():
 
 # ---- a REAL two-rank run of the C++ solver: both ranks share the one GPU, collectives over gloo ------------
 
-def _two_rank_worker(rank, world, port, q, direct=False):
+def _two_rank_worker(rank, world, port, q, direct=False, dims=(11, 3000, 10000, 0, 0.01)):
     import torch
     import torch.distributed as td
     import sfmba
@@ -583,7 +583,7 @@ def _two_rank_worker(rank, world, port, q, direct=False):
     torch.cuda.set_device(0)
     td.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        pb = sfmba.make_problem(11, 3000, 10000, seed=0)
+        pb = sfmba.make_problem(dims[0], dims[1], dims[2], seed=dims[3], x0_noise=dims[4])
         shards = sdist.partition_points(pb.point_indices, pb.n_points, world)
         loc = sdist.shard_problem(pb, shards[rank])
         be = sfmba.Backend(0)
@@ -609,7 +609,7 @@ def _two_rank_worker(rank, world, port, q, direct=False):
         td.all_gather_object(xs, x)
         if rank == 0:
             q.put(dict(x=sdist.merge_solutions(xs, shards, pb.n_cameras, pb.n_points),
-                       cams_equal=all(np.array_equal(xi[:66], xs[0][:66]) for xi in xs),
+                       cams_equal=all(np.array_equal(xi[:6 * dims[0]], xs[0][:6 * dims[0]]) for xi in xs),
                        status=int(res.status), nfev=int(res.nfev), cost=float(res.cost), rmse=float(res.rmse),
                        calls=ex.n_calls, direct_calls=direct_calls, link_active=link_active,
                        again=float(np.abs(x2 - x).max())))
@@ -618,7 +618,7 @@ def _two_rank_worker(rank, world, port, q, direct=False):
         td.destroy_process_group()
 
 
-def _run_ranks(world, direct):
+def _run_ranks(world, direct, dims=(11, 3000, 10000, 0, 0.01)):
     import socket
     import torch.multiprocessing as mp
     with socket.socket() as s:
@@ -626,7 +626,7 @@ def _run_ranks(world, direct):
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, q, direct)) for r in range(world)]
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, q, direct, dims)) for r in range(world)]
     for p in procs:
         p.start()
     out = q.get(timeout=300)
@@ -654,6 +654,16 @@ def test_direct_allreduce_over_peer_mapped_memory():
         assert (out["status"], out["nfev"]) == (ref.status, ref.nfev)
         assert abs(out["cost"] - ref.cost) <= 1e-10 * ref.cost
         assert np.abs(out["x"] - ref.x).max() <= 1e-6 * np.abs(ref.x).max()
+    # other shapes: an odd camera count (scalar slots no longer 16-byte aligned), a far start with rejected steps
+    # (retries, speculative trials), and more cameras than a single-workgroup collective carries
+    for world, dims in ((3, (7, 500, 4000, 3, 0.01)), (2, (6, 80, 500, 5, 0.2)), (2, (300, 2000, 16000, 9, 0.01))):
+        pb = sfmba.make_problem(dims[0], dims[1], dims[2], seed=dims[3], x0_noise=dims[4])
+        ref = sfmba.least_squares(sfmba.compute_residuals, pb.x0, x_scale="jac", ftol=1e-10, method="trf",
+                                  args=pb.args)
+        out = _run_ranks(world, direct=True, dims=dims)
+        assert out["link_active"] and out["calls"] == 0 and out["cams_equal"]
+        assert (out["status"], out["nfev"]) == (ref.status, ref.nfev)
+        assert abs(out["cost"] - ref.cost) <= 1e-9 * ref.cost
 
 
 def test_two_rank_solve_on_one_gpu_gloo():
