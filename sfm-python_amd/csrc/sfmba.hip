@@ -335,13 +335,15 @@ int wait_stream(sfmba_handle* h) {
 }
 
 // The hand-off of an outer iteration: the device posts scalars + PCG control block into the mailbox and
-// raises its sequence number (post_mailbox); the host polls that word.  A post normally arrives within
-// tens of microseconds; past 100 us the stream is queried between polls as well (every 20 us), which
-// notices a failed launch and makes the runtime push anything it may still be holding back.
+// raises its sequence number (post_mailbox); the host polls that word and nothing else: every
+// hipStreamQuery on a busy stream leaves a marker packet in the queue, and a dozen of them behind the
+// speculative launches cost 5.8 us before the first kernel of the next iteration.  The post of an iteration
+// arrives a few hundred microseconds after the host has finished enqueueing it; only past 5 ms is the stream
+// queried (every millisecond), to notice a failed launch instead of spinning forever.
 int wait_mailbox(sfmba_handle* h, unsigned long long seq) {
     unsigned long long* word = reinterpret_cast<unsigned long long*>(h->mbox + kMboxSeq);
     const double t0 = now_s();
-    double t_check = t0 + 100e-6;
+    double t_check = t0 + 5e-3;
     for (int spin = 0;; ++spin) {
         if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) { report_stall("wait_mailbox", now_s() - t0); return 0; }
         __builtin_ia32_pause();
@@ -354,7 +356,7 @@ int wait_mailbox(sfmba_handle* h, unsigned long long seq) {
             return fail(h, -3, "hand-off mailbox was not written");
         }
         if (e != hipErrorNotReady) return fail(h, -3, "hipStreamQuery failed: %s", hipGetErrorString(e));
-        t_check = t + 20e-6;
+        t_check = t + 1e-3;
     }
 }
 
