@@ -627,10 +627,15 @@ int exchange_tail(sfmba_handle* h) {            // G12, G22, q5..q8
     return exchange(h, h->scal() + 2, 6, 0);
 }
 
-// bring all 32 scalars to the host (h_scal) and wait
+// bring all 32 scalars to the host (h_scal) and wait: one small kernel posts them into the mailbox (no blit
+// copy, no marker packet in the queue, no stream polling)
 int fetch_scalars(sfmba_handle* h) {
-    HIPCHK(h, hipMemcpyAsync(h->h_scal, h->scal(), sizeof(double) * kScalSlots, hipMemcpyDeviceToHost, h->stream));
-    return wait_stream(h);
+    const Mailbox mb{h->mbox_dev, h->scal(), nullptr, ++h->mbox_seq};
+    hipLaunchKernelGGL(k_post, dim3(1), dim3(64), 0, h->stream, mb);
+    HIPCHK(h, hipGetLastError());
+    CHK(wait_mailbox(h, h->mbox_seq));
+    memcpy(h->h_scal, h->mbox, sizeof(double) * kScalSlots);
+    return 0;
 }
 
 // q_k summed over the camera slice and the (rank-reduced) point slice
