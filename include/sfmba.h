@@ -161,8 +161,10 @@ int  sfmba_get_fun_grad(sfmba_handle* h, double* fun_out, double* grad_out);
 
 /* ---- measurement / test entry points -------------------------------------------------------- */
 /* `reps` back-to-back launches of one kernel at x, bracketed by HIP events on the handle's stream.
- * which: 0 residual+Jacobian sweep, 1 residual-only sweep, 2 normal-equation blocks,
- *        3 one implicit Schur mat-vec.  avg_us: average launch duration. */
+ * which: 0 residual+Jacobian sweep, 1 residual-only sweep, 2 normal-equation blocks (point pass + camera pass),
+ *        3 one implicit Schur product (pass A + pass B), 4 pass A alone, 5 pass B alone, 6 the reduced
+ *        right-hand-side pass, 10 a streaming-store fill of the Jacobian buffer (ceiling probe).
+ * avg_us: average duration of one repetition. */
 int  sfmba_time_kernel(sfmba_handle* h, const double* x, int32_t which, int32_t reps, double* avg_us);
 /* Normal-equation blocks at x: U (C,21 upper triangle row-major), V (P,6 upper), gc (C,6), gp (P,3). */
 int  sfmba_normal_blocks(sfmba_handle* h, const double* x, double* U, double* V, double* gc,
@@ -170,6 +172,17 @@ int  sfmba_normal_blocks(sfmba_handle* h, const double* x, double* U, double* V,
 /* y = S v with S = U + diag(dc) - W (V + diag(dp))^-1 W^T at x (v, dc, y: 6C; dp: 3P). */
 int  sfmba_schur_matvec(sfmba_handle* h, const double* x, const double* dc, const double* dp,
                         const double* v, double* y);
+
+/* Host-only helper for the CPU test-suite (no GPU needed): the 2-D trust-region subproblem of
+ * SCIPY/optimize/_lsq/common.py:171-219.  B3 = (B00, B01, B11), g2, Delta -> p2; returns 1 when the Newton step
+ * lies inside the region, 0 for a boundary solution. */
+int  sfmba_tr2d_solve(const double* B3, const double* g2, double Delta, double* p2);
+/* Test / diagnostic hooks (nothing in the library reads the environment).  Placement options take effect at
+ * the next sfmba_set_problem.  Names: "pcg_fused" (0: two-kernel PCG), "tab_lds" / "vec_lds" (0: camera table /
+ * camera vector read from L2 although they would fit the LDS), "cam_chunk" (> 0: chunk length of the
+ * camera-major kernels), "pcg_guess_bias" (added to the speculative PCG iteration count), "trace_pcg",
+ * "trace_stalls", "trace_timing" (stderr diagnostics). */
+int  sfmba_debug_option(sfmba_handle* h, const char* name, int64_t value);
 
 #ifdef __cplusplus
 }

@@ -13,10 +13,14 @@
 //                     -> every stream moves 16 B per lane (global_load/store_dwordx4, 1 KiB per wave
 //                        instruction) with ONE observation per lane
 //   camtab            double [C][17]       R(9) T(3) w(3) b c   -- staged in LDS by the sweeps
-//   per point         V[P][6] (upper), Vinv[P][6], gp[P][3], dp[P][3] ...
+//   per point         V[P][6] (upper), Vinv[P][6], gp[P][3], dp[P][3], z[P][3] ...
 //   per camera        Ugc[C][27] = U upper (21) | gc (6)
+//   camera-major      cm_pt int32 [ld], cm_uv double2 [ld], chunk table: the same observations ordered by
+//                     camera (structure only, built once per problem) for the per-camera sums
 //
-// Every kernel is HBM-bound streaming/gather work (~1.4 flop/byte); no MFMA on this path.
+// Every kernel is HBM-bound streaming/gather work (~1.4 flop/byte); no MFMA on this path.  No kernel uses
+// atomics: per-point sums are reduced inside a wave over the point-major order, per-camera sums inside a
+// workgroup over the camera-major order, both in a fixed order.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -42,12 +46,8 @@ struct KMat { double k[9]; };
 // writes ONE region per batch instead of six streams that lie megabytes apart.
 constexpr int kJPlanes = 6;
 __device__ __forceinline__ size_t jaddr(int64_t ld, int i, int m) {
-#if defined(SFMBA_J_PLANAR)
-    return 2 * ((size_t)m * ld + i);
-#else
     (void)ld;
     return 2 * (((size_t)(i >> 6) * kJPlanes + m) * 64 + (i & 63));
-#endif
 }
 
 // device-resident control block of the PCG (lets the host enqueue iterations without reading back)
@@ -68,16 +68,7 @@ struct PcgCtrl {
     int    max_iters;
     int    done;      // 1 converged, 2 max_iters, 3 breakdown (pAp <= 0 or non-finite)
     int    pad;
-#ifdef SFMBA_STAMPS
-    unsigned long long stamp[16];   // diagnostic build only: s_memrealtime (100 MHz) at phase boundaries
-#endif
 };
-
-#ifdef SFMBA_STAMPS
-#define SFMBA_STAMP(ctrl, k) do { if (threadIdx.x == 0) (ctrl)->stamp[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define SFMBA_STAMP(ctrl, k) do {} while (0)
-#endif
 
 // Cross-lane moves that stay in the VALU (DPP row shifts, v_readlane) instead of going through the LDS pipe
 // as ds_bpermute does; row_shl:N makes lane i read lane i+N of its 16-lane row (0 when that leaves the row).
@@ -196,21 +187,6 @@ __device__ __forceinline__ void finish_in_block(const Piggyback& pb) {
 //   across rows: from the top row down, the first lane of the next row (by then complete) is broadcast with
 //   v_readlane and added by the lanes of this row that carry its key.
 
-#if defined(SFMBA_SEGRED_SHFL)      // the shuffle form, kept for A/B timing
-template <int NV>
-__device__ __forceinline__ void seg_reduce(double (&v)[NV], int key, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int k2 = __shfl_down(key, off);
-        const bool ok = (lane + off < 64) && (k2 == key);
-#pragma unroll
-        for (int n = 0; n < NV; ++n) {
-            const double o = __shfl_down(v[n], off);
-            if (ok) v[n] += o;
-        }
-    }
-}
-#else
 template <int NV, int N>
 __device__ __forceinline__ void seg_row_step(double (&v)[NV], int key, int lane) {
     constexpr int kRowShl = 0x100;                     // DPP control: row_shl:N
@@ -240,7 +216,6 @@ __device__ __forceinline__ void seg_reduce(double (&v)[NV], int key, int lane) {
         }
     }
 }
-#endif
 
 // fp32-STORAGE mode (BASELINE config 5): uv, r, t1 and the compact Jacobian are kept as floats, all
 // arithmetic and every accumulation stays fp64.  The Jacobian tile of 64 observations is then three
@@ -410,13 +385,7 @@ __device__ __forceinline__ void observe(const double* __restrict__ t, double X, 
 // ---------------------------------------------------------------------------------------------
 // 16-byte streaming store of two doubles (one global_store_dwordx4)
 __device__ __forceinline__ void st16(double* __restrict__ p, double a, double b) {
-#if defined(SFMBA_K1_NT)
-    typedef double v2d __attribute__((ext_vector_type(2)));
-    v2d v = {a, b};
-    __builtin_nontemporal_store(v, reinterpret_cast<v2d*>(p));
-#else
     *reinterpret_cast<double2*>(p) = make_double2(a, b);
-#endif
 }
 
 template <bool LDS_TAB, bool JAC, bool STORE_R, bool F32>
@@ -428,15 +397,8 @@ __global__ __launch_bounds__(kSweepThreads) void k_resjac(
     extern __shared__ __align__(16) double smem[];
     __shared__ double red[kWavesPerSweepBlock];
     if (skip != nullptr && *skip != 0.0) return;   // speculative launch cancelled by k_tr_step
-#if defined(SFMBA_K1_CHUNKED)            // experiment: one contiguous chunk of observations per workgroup
-    const int stride = blockDim.x;
-    const int chunk = (((N + (int)gridDim.x - 1) / (int)gridDim.x) + 63) & ~63;
-    int i = blockIdx.x * chunk + threadIdx.x;
-    N = min(N, (int)(blockIdx.x + 1) * chunk);
-#else
     const int stride = gridDim.x * blockDim.x;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-#endif
     // pipeline registers: batch i (uv, X ready), batch i+stride (indices ready)
     int c0 = 0, p0 = 0, c1 = 0, p1 = 0;
     double2 uv0 = make_double2(0.0, 0.0);
@@ -467,23 +429,8 @@ __global__ __launch_bounds__(kSweepThreads) void k_resjac(
             X1 = Xp[0]; Y1 = Xp[1]; Z1 = Xp[2];
         }
         double jc[12], jp[6], rx, ry;
-#if defined(SFMBA_ABLATE_K1_COMPUTE)     // timing-only ablation: loads + stores, no arithmetic
-        rx = X0 + uv0.x; ry = Y0 + uv0.y;
-        for (int k = 0; k < 12; ++k) jc[k] = Z0 + k + c0;
-        for (int k = 0; k < 6; ++k) jp[k] = Z0 - k;
-#else
         observe<JAC>(tab + c0 * kCamTab, X0, Y0, Z0, uv0.x, uv0.y, K, rx, ry, jc, jp);
-#endif
         acc += rx * rx + ry * ry;
-#if defined(SFMBA_ABLATE_K1_STORES)      // timing-only ablation: everything but the Jacobian stores
-        if (STORE_R) store_pair(r, F32, i, rx, ry);
-        if (JAC) {
-            double sacc = 0.0;
-            for (int k = 0; k < 12; ++k) sacc += jc[k];
-            for (int k = 0; k < 6; ++k) sacc += jp[k];
-            if (sacc == 123.456) J[i] = sacc;
-        }
-#else
         if (STORE_R) {
             if (F32) store_pair(r, 1, i, rx, ry); else st16(r + 2 * (size_t)i, rx, ry);
         }
@@ -502,7 +449,6 @@ __global__ __launch_bounds__(kSweepThreads) void k_resjac(
                 for (int m = 0; m < 3; ++m) st16(J + jaddr(ld, i, 3 + m), jp[2 * m], jp[2 * m + 1]);
             }
         }
-#endif
         i = in;
         c0 = c1; p0 = p1; c1 = c2; p1 = p2;
         uv0 = uv1; X0 = X1; Y0 = Y1; Z0 = Z1;
@@ -543,13 +489,7 @@ __global__ void k_unpack_jac(const double* __restrict__ J, int N, int64_t ld, in
         }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Point-major sweep skeleton.  Each WAVE owns an observation range cut at point boundaries
-// (host-built), walks it in steps of <= 64 observations that also end on a point boundary, reduces
-// per-point sums with wave shuffles, hands the per-point result back to the point's lanes, and
-// accumulates per-camera sums with fp64 atomics (LDS table per workgroup, flushed once; or global).
-// A point with more than 64 observations is handled by the wave looping over its run.
-// ---------------------------------------------------------------------------------------------
+// Stored per-observation data of the point-major sweeps.
 struct ObsArrays {
     const int* __restrict__ cam_idx;
     const int* __restrict__ pt_idx;
@@ -584,170 +524,192 @@ __device__ __forceinline__ void load_blocks(const ObsArrays& o, int i, double* j
             jc[6 * row + 3 + k] = -jp[3 * row + k];
         }
 }
-__device__ __forceinline__ void load_jc(const ObsArrays& o, int i, double* jc) {
-    double jp[6];
-    load_blocks(o, i, jc, jp);
+
+// ---------------------------------------------------------------------------------------------
+// Camera-major side.  Per-camera sums (U_c, g_c, the reduced right-hand side, the camera half of the
+// implicit Schur product) are NOT scattered from the point-major sweeps with atomics: set_problem builds,
+// once, the camera-major order of the observations (a stable counting sort of the point-major positions by
+// camera; structure only) and cuts every camera's run into chunks.  One 256-thread workgroup owns one chunk:
+// the camera row is wave-uniform (scalar registers), the point is gathered from the L2-resident parameter
+// vector, and the Jacobian blocks of the observation are RECOMPUTED from them (~250 flop, against 96 B of
+// stored blocks that exist in point-major order only: a second, camera-major copy of J would cost K1 another
+// 96 B of writes per observation).  Every lane keeps its sums in registers over the chunk, the wave adds
+// them with DPP, the four waves through LDS in wave order, chunks of one camera in chunk order
+// (k_cam_combine): plain stores, no atomics, bitwise reproducible from run to run.
+// ---------------------------------------------------------------------------------------------
+struct CamMajor {
+    const int4* __restrict__ chunks;   // (camera, first, end, number of chunks of that camera), ordered by camera
+    const int* __restrict__ pt;        // [ld] point index of the k-th observation in camera-major order
+    const double* __restrict__ uv;     // [ld] its pixel (double2; float2 in fp32-storage mode)
+};
+constexpr int kCamThreads = 256;
+constexpr int kCamWaves = kCamThreads / 64;
+
+// sums of one workgroup: NV values per lane -> out[col] (thread col < NV holds the total afterwards)
+template <int NV>
+__device__ __forceinline__ double cam_block_total(double (&a)[NV], double (*red)[NV]) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) a[q] = wave_sum(a[q]);
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) red[w][q] = a[q];
+    }
+    __syncthreads();
+    double s = 0.0;
+    if ((int)threadIdx.x < NV) {
+#pragma unroll
+        for (int k = 0; k < kCamWaves; ++k) s += red[k][threadIdx.x];      // fixed order
+    }
+    return s;
 }
 
-// K2+K3: V_p = sum Jp^T Jp (6), g_p = sum Jp^T r (3) by segmented reduction;
-//        U_c = sum Jc^T Jc (21), g_c = sum Jc^T r (6) by global fp64 atomics into Ugc[C][27].
-__global__ __launch_bounds__(kSweepThreads) void k_normal_blocks(
-    const int2* __restrict__ ranges, int n_ranges, ObsArrays o, const double* __restrict__ r,
-    double* __restrict__ V, double* __restrict__ gp, double* __restrict__ Ugc,
-    const double* __restrict__ skip) {
+// K3: U_c = sum Jc^T Jc (21, packed upper triangle), g_c = sum Jc^T r (6) of one camera chunk.
+// A camera with a single chunk stores straight into Ugc[c][27]; otherwise the chunk's 27 sums go to
+// partial[chunk][27] and k_cam_combine adds them.
+template <bool F32>
+__global__ __launch_bounds__(kCamThreads) void k_cam_blocks(CamMajor cm, const double* __restrict__ camtab,
+                                                            const double* __restrict__ pts, KMat K,
+                                                            double* __restrict__ Ugc, double* __restrict__ partial,
+                                                            const double* __restrict__ skip) {
+    __shared__ double red[kCamWaves][27];
     if (skip != nullptr && *skip != 0.0) return;   // speculative launch cancelled by k_tr_step
-    const int wg = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (wg >= n_ranges) return;
-    const int lane = threadIdx.x & 63;
-    const int2 rg = ranges[wg];
-    int pos = rg.x;
-    const int end = rg.y;
-
-    auto cam_accumulate = [&](int i, const double* jc, double rx, double ry) {
-        double* u = Ugc + (size_t)o.cam_idx[i] * 27;
+    const int4 ch = cm.chunks[blockIdx.x];
+    double t[kCamTab];
+#pragma unroll
+    for (int k = 0; k < kCamTab; ++k) t[k] = camtab[(size_t)ch.x * kCamTab + k];      // wave-uniform: scalar loads
+    double a[27];
+#pragma unroll
+    for (int q = 0; q < 27; ++q) a[q] = 0.0;
+    int k = ch.y + (int)threadIdx.x;
+    int p = 0;
+    double2 uv = make_double2(0.0, 0.0);
+    if (k < ch.z) { p = cm.pt[k]; uv = load_pair(cm.uv, F32, k); }
+    while (k < ch.z) {
+        const int kn = k + kCamThreads;
+        int pn = 0;
+        double2 uvn = make_double2(0.0, 0.0);
+        if (kn < ch.z) { pn = cm.pt[kn]; uvn = load_pair(cm.uv, F32, kn); }       // next index while this point is gathered
+        const double* __restrict__ Xp = pts + 3 * (size_t)p;
+        double jc[12], jp[6], rx, ry;
+        observe<true>(t, Xp[0], Xp[1], Xp[2], uv.x, uv.y, K, rx, ry, jc, jp);
         int n = 0;
 #pragma unroll
-        for (int a = 0; a < 6; ++a)
+        for (int i = 0; i < 6; ++i)
 #pragma unroll
-            for (int b = a; b < 6; ++b) unsafeAtomicAdd(u + n++, jc[a] * jc[b] + jc[6 + a] * jc[6 + b]);
+            for (int j = i; j < 6; ++j) a[n++] += jc[i] * jc[j] + jc[6 + i] * jc[6 + j];
 #pragma unroll
-        for (int a = 0; a < 6; ++a) unsafeAtomicAdd(u + 21 + a, jc[a] * rx + jc[6 + a] * ry);
-    };
-    auto point_terms = [&](const double* jp, double rx, double ry, double* v) {
-        v[0] = jp[0] * jp[0] + jp[3] * jp[3]; v[1] = jp[0] * jp[1] + jp[3] * jp[4];
-        v[2] = jp[0] * jp[2] + jp[3] * jp[5]; v[3] = jp[1] * jp[1] + jp[4] * jp[4];
-        v[4] = jp[1] * jp[2] + jp[4] * jp[5]; v[5] = jp[2] * jp[2] + jp[5] * jp[5];
-        v[6] = jp[0] * rx + jp[3] * ry; v[7] = jp[1] * rx + jp[4] * ry; v[8] = jp[2] * rx + jp[5] * ry;
-    };
-
-    while (pos < end) {
-        const int i = pos + lane;
-        const bool in = i < end;
-        const int p = in ? o.pt_idx[i] : o.pt_idx[pos];
-        const int sb = o.pt_ptr[p], se = o.pt_ptr[p + 1];
-        const bool complete = in && (se <= pos + 64);
-        const int n_take = __popcll(__ballot(complete));
-        double jc[12], jp[6], v[9];
-        if (n_take == 0) {                         // one point with > 64 observations: [pos, run_end)
-            const int run_end = __shfl(se, 0);
-            const int pp = __shfl(p, 0);
-#pragma unroll
-            for (int q = 0; q < 9; ++q) v[q] = 0.0;
-            for (int j = pos + lane; j < run_end; j += 64) {
-                load_blocks(o, j, jc, jp);
-                const double2 rr_ = load_pair(r, o.f32, j); const double rx = rr_.x, ry = rr_.y;
-                cam_accumulate(j, jc, rx, ry);
-                double w[9];
-                point_terms(jp, rx, ry, w);
-#pragma unroll
-                for (int q = 0; q < 9; ++q) v[q] += w[q];
-            }
-#pragma unroll
-            for (int q = 0; q < 9; ++q) v[q] = wave_sum(v[q]);
-            if (lane == 0) {
-#pragma unroll
-                for (int q = 0; q < 6; ++q) V[(size_t)pp * 6 + q] = v[q];
-#pragma unroll
-                for (int q = 0; q < 3; ++q) gp[(size_t)pp * 3 + q] = v[6 + q];
-            }
-            pos = run_end;
-            continue;
-        }
-        const bool act = lane < n_take;
-        if (act) {
-            load_blocks(o, i, jc, jp);
-            const double2 rr_ = load_pair(r, o.f32, i); const double rx = rr_.x, ry = rr_.y;
-            cam_accumulate(i, jc, rx, ry);
-            point_terms(jp, rx, ry, v);
-        } else {
-#pragma unroll
-            for (int q = 0; q < 9; ++q) v[q] = 0.0;
-        }
-        seg_reduce<9>(v, act ? sb : -1 - lane, lane);
-        if (act && i == sb) {
-#pragma unroll
-            for (int q = 0; q < 6; ++q) V[(size_t)p * 6 + q] = v[q];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) gp[(size_t)p * 3 + q] = v[6 + q];
-        }
-        pos += n_take;
+        for (int i = 0; i < 6; ++i) a[21 + i] += jc[i] * rx + jc[6 + i] * ry;
+        k = kn; p = pn; uv = uvn;
+    }
+    const double s = cam_block_total<27>(a, red);
+    if (threadIdx.x < 27) {
+        if (ch.w == 1) Ugc[(size_t)ch.x * 27 + threadIdx.x] = s;
+        else partial[(size_t)blockIdx.x * 27 + threadIdx.x] = s;
     }
 }
 
-// K2+K3, LDS form: the per-camera sums go to a workgroup-private LDS table [C][ncols] holding columns
-// [col0, col0+ncols) of the 27 (21 U + 6 g_c) with ds_add_f64, written once per workgroup to
-// partial[block][C*ncols] and summed over workgroups in fixed order by k_reduce_tables (no global
-// atomics: 27 same-address fp64 atomics per observation ran 30x slower than the sweep itself).
-// When 27 columns of C cameras exceed the 160 KiB LDS the host runs several column passes.
-__global__ __launch_bounds__(kSweepThreads) void k_normal_blocks_lds(
-    const int2* __restrict__ ranges, int n_ranges, ObsArrays o, const double* __restrict__ r,
-    double* __restrict__ V, double* __restrict__ gp, double* __restrict__ partial, int C, int col0,
-    int ncols, int do_points, const double* __restrict__ skip) {
+// out[c * cs + col * ks] = sum of the chunk rows of camera c, in chunk order, for the cameras that have more
+// than one chunk (single-chunk cameras were stored by their workgroup).  `done`: PCG finished, nothing new.
+__global__ __launch_bounds__(256) void k_cam_combine(const int* __restrict__ chunk_ptr, const double* __restrict__ partial,
+                                                     int C, int ncols, double* __restrict__ out, int cs, int ks,
+                                                     const double* __restrict__ skip, const int* __restrict__ done) {
+    if (skip != nullptr && *skip != 0.0) return;
+    if (done != nullptr && *done != 0) return;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= C * ncols) return;
+    const int c = e / ncols, col = e - c * ncols;
+    const int j0 = chunk_ptr[c], j1 = chunk_ptr[c + 1];
+    if (j1 - j0 <= 1) return;
+    double s = 0.0;
+    for (int j = j0; j < j1; ++j) s += partial[(size_t)j * ncols + col];
+    out[(size_t)c * cs + (size_t)col * ks] = s;
+}
+
+// camera-major copies of the point index and the pixel, gathered on the device from the point-major arrays
+// through the permutation set_problem uploads (4 B per observation cross PCIe instead of 20)
+__global__ void k_build_cam_major(const int* __restrict__ perm, const int* __restrict__ pt_idx,
+                                  const double* __restrict__ uv, int f32, int N, int* __restrict__ cm_pt,
+                                  double* __restrict__ cm_uv) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= N) return;
+    const int i = perm[k];
+    cm_pt[k] = pt_idx[i];
+    if (f32) reinterpret_cast<float2*>(cm_uv)[k] = reinterpret_cast<const float2*>(uv)[i];
+    else reinterpret_cast<double2*>(cm_uv)[k] = reinterpret_cast<const double2*>(uv)[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Point-major sweep skeleton.  Each WAVE owns an observation range cut at point boundaries
+// (host-built) and walks it in precomputed steps: steps[s] = (first observation, count); count <= 64 is a
+// batch that ends on a point boundary, count > 64 a single point with that many observations.
+// wsteps[wave] = (first step, number of steps).  With the step list known, the index loads of step s+1 are
+// issued while step s computes.  Per-point sums are reduced inside the wave (seg_reduce); no run ever spans
+// two waves.
+// ---------------------------------------------------------------------------------------------
+struct StepTable {
+    const int2* __restrict__ wsteps;
+    const int2* __restrict__ steps;
+    int n_waves;
+};
+
+// K2: V_p = sum Jp^T Jp (6, packed upper triangle), g_p = sum Jp^T r (3), recomputed from the camera table
+// and the point like K1 does (20 B per observation of indices and pixels instead of 64 B of stored blocks,
+// and exact fp64 in fp32-storage mode too).  256-thread workgroups: the kernel needs ~150 VGPRs, which a
+// 1024-thread workgroup cannot have; the camera table is staged in LDS only while three workgroups' copies fit
+// a CU (C <= 360), beyond that its rows (2.4 KB ... 136 KB, L2-resident) are gathered from global memory.
+constexpr int kPointBlockThreads = 256;
+template <bool LDS_TAB, bool F32>
+__global__ __launch_bounds__(kPointBlockThreads) void k_point_blocks(
+    StepTable st, const int* __restrict__ cam_idx, const int* __restrict__ pt_idx, const double* __restrict__ uv,
+    const double* __restrict__ camtab, const double* __restrict__ pts, int C, KMat K,
+    double* __restrict__ V, double* __restrict__ gp, const double* __restrict__ skip) {
     extern __shared__ __align__(16) double smem[];
     if (skip != nullptr && *skip != 0.0) return;   // speculative launch cancelled by k_tr_step
-    const int ntab = C * ncols;
-    for (int i = threadIdx.x; i < ntab; i += blockDim.x) smem[i] = 0.0;
-    __syncthreads();
     const int wg = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    int pos = 0, end = 0;
-    if (wg < n_ranges) { const int2 rg = ranges[wg]; pos = rg.x; end = rg.y; }
-    const int col1 = col0 + ncols;
-
-    auto cam_accumulate = [&](int i, const double* jc, double rx, double ry) {
-        double* u = smem + (size_t)o.cam_idx[i] * ncols - col0;
-        int n = 0;
-#pragma unroll
-        for (int a = 0; a < 6; ++a)
-#pragma unroll
-            for (int b = a; b < 6; ++b) {
-#ifndef SFMBA_ABLATE_NB_ATOMICS
-                if (n >= col0 && n < col1) unsafeAtomicAdd(u + n, jc[a] * jc[b] + jc[6 + a] * jc[6 + b]);
-#else
-                if (n >= col0 && n < col1 && jc[a] * jc[b] == 123.456) u[n] = jc[6 + a];
-#endif
-                ++n;
-            }
-#pragma unroll
-        for (int a = 0; a < 6; ++a) {
-            if (21 + a >= col0 && 21 + a < col1) unsafeAtomicAdd(u + 21 + a, jc[a] * rx + jc[6 + a] * ry);
-        }
-    };
-    auto point_terms = [&](const double* jp, double rx, double ry, double* v) {
+    int s = 0, s_end = 0;
+    if (wg < st.n_waves) { const int2 w = st.wsteps[wg]; s = w.x; s_end = w.x + w.y; }
+    int2 cur = make_int2(0, 0);
+    if (s < s_end) cur = st.steps[s];
+    int i = cur.x + lane, c = 0, p = 0;
+    double2 uvi = make_double2(0.0, 0.0);
+    if (cur.y <= 64 && lane < cur.y) { c = cam_idx[i]; p = pt_idx[i]; uvi = load_pair(uv, F32, i); }
+    if (LDS_TAB) {                               // stage the camera table while those loads fly
+        const int n2 = (C * kCamTab) >> 1;
+        const double2* __restrict__ src = reinterpret_cast<const double2*>(camtab);
+        double2* __restrict__ dst = reinterpret_cast<double2*>(smem);
+        for (int k = threadIdx.x; k < n2; k += blockDim.x) dst[k] = src[k];
+        if (((C * kCamTab) & 1) && threadIdx.x == 0) smem[C * kCamTab - 1] = camtab[C * kCamTab - 1];
+        __syncthreads();
+    }
+    const double* __restrict__ tab = LDS_TAB ? smem : camtab;
+    auto terms = [&](int cc, double X, double Y, double Z, double2 px, double* v) {
+        double jc[12], jp[6], rx, ry;
+        observe<true>(tab + cc * kCamTab, X, Y, Z, px.x, px.y, K, rx, ry, jc, jp);
         v[0] = jp[0] * jp[0] + jp[3] * jp[3]; v[1] = jp[0] * jp[1] + jp[3] * jp[4];
         v[2] = jp[0] * jp[2] + jp[3] * jp[5]; v[3] = jp[1] * jp[1] + jp[4] * jp[4];
         v[4] = jp[1] * jp[2] + jp[4] * jp[5]; v[5] = jp[2] * jp[2] + jp[5] * jp[5];
         v[6] = jp[0] * rx + jp[3] * ry; v[7] = jp[1] * rx + jp[4] * ry; v[8] = jp[2] * rx + jp[5] * ry;
     };
-
-    if (!do_points) {                               // later column passes: cameras only, no segments
-        for (int i = pos + lane; i < end; i += 64) {
-            double jc[12];
-            load_jc(o, i, jc);
-            const double2 rr_ = load_pair(r, o.f32, i);
-            cam_accumulate(i, jc, rr_.x, rr_.y);
-        }
-        pos = end;
-    }
-    while (pos < end) {
-        const int i = pos + lane;
-        const bool in = i < end;
-        const int p = in ? o.pt_idx[i] : o.pt_idx[pos];
-        const int sb = o.pt_ptr[p], se = o.pt_ptr[p + 1];
-        const bool complete = in && (se <= pos + 64);
-        const int n_take = __popcll(__ballot(complete));
-        double jc[12], jp[6], v[9];
-        if (n_take == 0) {
-            const int run_end = __shfl(se, 0);
-            const int pp = __shfl(p, 0);
+    while (s < s_end) {
+        int2 nxt = make_int2(0, 0);
+        if (s + 1 < s_end) nxt = st.steps[s + 1];
+        const int in_ = nxt.x + lane;
+        int cn = 0, pn = 0;
+        double2 uvn = make_double2(0.0, 0.0);
+        if (nxt.y <= 64 && lane < nxt.y) { cn = cam_idx[in_]; pn = pt_idx[in_]; uvn = load_pair(uv, F32, in_); }
+        double v[9];
+        if (cur.y > 64) {                          // one point with more than 64 observations
+            const int run_end = cur.x + cur.y;
+            const int pp = pt_idx[cur.x];
+            const double* __restrict__ Xp = pts + 3 * (size_t)pp;
+            const double X = Xp[0], Y = Xp[1], Z = Xp[2];
 #pragma unroll
             for (int q = 0; q < 9; ++q) v[q] = 0.0;
-            for (int j = pos + lane; j < run_end; j += 64) {
-                load_blocks(o, j, jc, jp);
-                const double2 rr_ = load_pair(r, o.f32, j); const double rx = rr_.x, ry = rr_.y;
-                cam_accumulate(j, jc, rx, ry);
+            for (int j = cur.x + lane; j < run_end; j += 64) {
                 double w[9];
-                point_terms(jp, rx, ry, w);
+                terms(cam_idx[j], X, Y, Z, load_pair(uv, F32, j), w);
 #pragma unroll
                 for (int q = 0; q < 9; ++q) v[q] += w[q];
             }
@@ -759,69 +721,27 @@ __global__ __launch_bounds__(kSweepThreads) void k_normal_blocks_lds(
 #pragma unroll
                 for (int q = 0; q < 3; ++q) gp[(size_t)pp * 3 + q] = v[6 + q];
             }
-            pos = run_end;
-            continue;
-        }
-        const bool act = lane < n_take;
-        if (act) {
-            load_blocks(o, i, jc, jp);
-            const double2 rr_ = load_pair(r, o.f32, i); const double rx = rr_.x, ry = rr_.y;
-            cam_accumulate(i, jc, rx, ry);
-            point_terms(jp, rx, ry, v);
         } else {
+            const bool act = lane < cur.y;
+            if (act) {
+                const double* __restrict__ Xp = pts + 3 * (size_t)p;
+                terms(c, Xp[0], Xp[1], Xp[2], uvi, v);
+            } else {
 #pragma unroll
-            for (int q = 0; q < 9; ++q) v[q] = 0.0;
+                for (int q = 0; q < 9; ++q) v[q] = 0.0;
+            }
+            const int key = act ? p : -1 - lane;
+            seg_reduce<9>(v, key, lane);
+            const int prev = __shfl_up(key, 1);
+            if (act && (lane == 0 || prev != key)) {          // first lane of the point's run
+#pragma unroll
+                for (int q = 0; q < 6; ++q) V[(size_t)p * 6 + q] = v[q];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) gp[(size_t)p * 3 + q] = v[6 + q];
+            }
         }
-#ifndef SFMBA_ABLATE_NB_SEGRED
-        seg_reduce<9>(v, act ? sb : -1 - lane, lane);
-#endif
-        if (act && i == sb) {
-#pragma unroll
-            for (int q = 0; q < 6; ++q) V[(size_t)p * 6 + q] = v[q];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) gp[(size_t)p * 3 + q] = v[6 + q];
-        }
-        pos += n_take;
-    }
-    __syncthreads();
-    double* __restrict__ dst = partial + (size_t)blockIdx.x * ntab;
-    for (int i = threadIdx.x; i < ntab; i += blockDim.x) dst[i] = smem[i];
-}
-
-// Ugc[c][col0 + k] = sum over workgroup tables, fixed order.  Block = 64 entries x 16 slices of the
-// workgroup axis (independent loads in flight), combined through LDS in slice order.
-__global__ __launch_bounds__(1024) void k_reduce_tables(const double* __restrict__ partial, int nblocks,
-                                                        int C, int per, int only_pass,
-                                                        double* __restrict__ Ugc,
-                                                        const double* __restrict__ skip) {
-    // only_pass < 0: ONE launch for all column passes; pass q left its per-workgroup tables
-    // [nblocks][C * ncols_q] at partial + q * nblocks * C * per (ncols_q = per, except possibly the last pass).
-    // only_pass = q: the columns of pass q alone, whose tables start at `partial` (all passes reuse one buffer).
-    __shared__ double sm[16][64];
-    if (skip != nullptr && *skip != 0.0) return;   // speculative launch cancelled by k_tr_step
-    const int nout = C * 27;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int e = blockIdx.x * 64 + tx;            // e = c * 27 + col
-    double s = 0.0;
-    bool mine = false;
-    if (e < nout) {
-        const int c = e / 27, col = e - c * 27;
-        const int q = col / per, colq = col - q * per;
-        const int ncols = min(per, 27 - q * per);
-        const size_t ntab = (size_t)C * ncols;
-        const double* __restrict__ src = partial + (only_pass < 0 ? (size_t)q * nblocks * ((size_t)C * per) : (size_t)0) +
-                                         (size_t)c * ncols + colq;
-        if (only_pass < 0 || q == only_pass)
-            for (int b = ty; b < nblocks; b += 16) s += src[(size_t)b * ntab];
-        mine = only_pass < 0 || q == only_pass;
-    }
-    sm[ty][tx] = s;
-    __syncthreads();
-    if (ty == 0 && e < nout && mine) {
-        double t = 0.0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) t += sm[k][tx];
-        Ugc[e] = t;
+        cur = nxt; i = in_; c = cn; p = pn; uvi = uvn;
+        ++s;
     }
 }
 
@@ -1129,13 +1049,13 @@ __global__ void k_cam_prep(const double* __restrict__ Ugc, const double* __restr
 
 // Everything between the Cauchy product and the reduced right-hand side in one launch: the
 // regularisation term from the exchange scalars (every thread evaluates the same few flops, block 0
-// publishes it in scalar slot 13), blocks [0, bc): one camera per thread (Dc, Minv, acc0 = acc1 = 0),
+// publishes it in scalar slot 13), blocks [0, bc): one camera per thread (Dc, Minv),
 // blocks [bc, grid): one point per thread (Vinv, e).
 __global__ __launch_bounds__(64) void k_prep(double* __restrict__ sc, double Delta, double reg_min,
                                              const double* __restrict__ Ugc, const double* __restrict__ V,
                                              const double* __restrict__ gp, const double* __restrict__ si,
                                              int C, int P, int bc, double* __restrict__ Dc,
-                                             double* __restrict__ Minv, double* __restrict__ acc0,
+                                             double* __restrict__ Minv,
                                              double* __restrict__ Vinv, double* __restrict__ e,
                                              const double* __restrict__ jd_part, int jd_n) {
     // G11 = |J D^2 g|^2: either already in slot 1 (k_finish, then all-reduced over ranks) or summed here from
@@ -1156,8 +1076,6 @@ __global__ __launch_bounds__(64) void k_prep(double* __restrict__ sc, double Del
     if ((int)blockIdx.x < bc) {
         const int c = blockIdx.x * blockDim.x + threadIdx.x;
         if (c >= C) return;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) { acc0[(size_t)k * C + c] = 0.0; acc0[(size_t)(6 + k) * C + c] = 0.0; }
         cam_prep_one(Ugc, si, nullptr, C, c, reg, Dc, Minv);
         return;
     }
@@ -1167,20 +1085,13 @@ __global__ __launch_bounds__(64) void k_prep(double* __restrict__ sc, double Del
 }
 
 // ---------------------------------------------------------------------------------------------
-// K4/K5 sweep: one pass over the observations applies the implicit Schur complement,
-//   acc_c += sum_{i in c} Jc_i^T ( Jc_i v_c - Jp_i z_p ),  z_p = Vinv_p sum_{i in p} Jp_i^T Jc_i v_c
-// (MODE 0), or the reduced right-hand side term acc_c -= sum Jc_i^T Jp_i e_p (MODE 1, z = e given).
-// S v = acc + Dc v is completed by k_pcg_update.  ACC selects where the camera-sized operands live:
-//   1  v and acc in LDS (2 * 6C doubles; up to ~1700 cameras)
-//   2  acc of the camera range [c_lo, c_hi) in LDS, v gathered from the camera-major copy in L2; the
-//      host runs one pass per range (each pass repeats the per-point part: ~3400 cameras per pass)
-//   0  everything global (fp64 atomics to HBM): only a last resort
+// K4/K5: the implicit Schur complement  (S - Dc) v = sum_i Jc_i^T ( Jc_i v_c - Jp_i z_p ),
+// z_p = Vinv_p sum_{i in p} Jp_i^T Jc_i v_c, in two passes and without atomics:
+//   A  k_point_sweep  (point-major, reads the stored Jacobian): z_p for every point, reduced inside the wave
+//   B  k_cam_schur    (camera-major, blocks recomputed): the camera sums, one workgroup per camera chunk
+// S v = acc + Dc v is completed by the PCG update.  The reduced right-hand side -sum Jc^T Jp e_p is pass B
+// alone with z = e (MODE 1).
 // ---------------------------------------------------------------------------------------------
-// The walk over a wave's observation range is precomputed on the host (it depends only on the problem
-// structure): steps[s] = (first observation, count); count <= 64 is a batch that ends on a point
-// boundary, count > 64 a single point with that many observations.  wsteps[wave] = (first step, number
-// of steps).  With the step list known, the index loads of step s+1 are issued while step s computes,
-// so a step costs one memory round trip (its Jacobian blocks) instead of three dependent ones.
 // row k of the packed-upper-triangle 6x6 block m times r (block-Jacobi preconditioner)
 __device__ __forceinline__ double minv_row(const double* m, const double* r, int k) {
     double z = 0.0;
@@ -1192,40 +1103,31 @@ __device__ __forceinline__ double minv_row(const double* m, const double* r, int
     return z;
 }
 
-struct StepTable {
-    const int2* __restrict__ wsteps;
-    const int2* __restrict__ steps;
-    int n_waves;
-};
-
-//
-// FUSED (ACC 1, MODE 0, C <= blockDim.x): the launch is a whole PCG iteration.  Its prologue performs the
-// update that k_pcg_update would have done after the PREVIOUS launch's product -- every workgroup
-// redundantly, one thread per camera, from the complete old vector set, leaving the new u directly in
-// the LDS table the sweep reads -- and stores only its own few cameras into the other vector set.
-// Launch L reads the product from accumulator L % 3, flushes its own into (L + 1) % 3 and clears
-// (L + 2) % 3 for the launch after it: nothing a workgroup reads is written during the same launch, so
-// no inter-workgroup synchronisation is needed.  Launch 0 does k_pcg_init's work instead of an update
-// (accumulator 0 holds the reduced right-hand side term, accumulator 1 must be zero: k_prep clears
-// both).  Returns at once when the solve has finished.
+// FUSED (v in LDS, C <= blockDim.x): the launch of pass A is also the PCG update.  Its prologue performs the
+// update that k_pcg_update would have done after the PREVIOUS product -- every workgroup redundantly, one
+// thread per camera, from the complete old vector set, leaving the new u directly in the LDS table the sweep
+// reads -- and stores only its own few cameras into the other vector set.  Nothing a workgroup reads is
+// written during the same launch (vector sets and control blocks alternate; the product `acc` is written by
+// pass B, a launch of its own), so no inter-workgroup synchronisation is needed.  Launch 0 does k_pcg_init's
+// work instead of an update (acc holds the reduced right-hand side term).  Returns at once when the solve
+// has finished.
 struct PcgFused {
     const double* __restrict__ Dc;
     const double* __restrict__ Minv;
-    const double* __restrict__ Ugc;      // launch 0 builds the right-hand side from g_c and accumulator 0
+    const double* __restrict__ Ugc;      // launch 0 builds the right-hand side from g_c and acc
     double* __restrict__ vecs;
     PcgCtrl* __restrict__ ctrl2;
     double tol;
     int max_iters;
 };
 
-template <int ACC, int MODE, bool FUSED = false>
-__global__ __launch_bounds__(kSweepThreads) void k_schur_sweep(
-    StepTable st, ObsArrays o, const double* __restrict__ vin,
-    const double* __restrict__ Vinv, const double* __restrict__ zin, double* __restrict__ acc, int C,
-    const PcgCtrl* __restrict__ ctrl2, int L, int c_lo, int c_hi, PcgFused pf) {
+template <bool LDS_VEC, bool FUSED>
+__global__ __launch_bounds__(kSweepThreads) void k_point_sweep(
+    StepTable st, ObsArrays o, const double* __restrict__ vin, const double* __restrict__ Vinv,
+    double* __restrict__ zout, const double* __restrict__ acc, int C,
+    const PcgCtrl* __restrict__ ctrl2, int L, PcgFused pf) {
     extern __shared__ __align__(16) double smem[];
-    static_assert(!FUSED || (ACC == 1 && MODE == 0), "the fused PCG launch keeps v and acc in LDS");
-    constexpr bool LDS_ACC = ACC == 1;
+    static_assert(!FUSED || LDS_VEC, "the fused PCG launch keeps v in LDS");
     const int n6 = 6 * C;
     // The wave's step list and the indices of its first step form a chain of three dependent loads that
     // depends on nothing else: request it first, so that it overlaps the PCG prologue / the LDS staging.
@@ -1250,10 +1152,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_schur_sweep(
         const bool own = has && cam >= (int)blockIdx.x * slice && cam < ((int)blockIdx.x + 1) * slice;
         const int set = L == 0 ? 0 : (L - 1) & 1;
         const double* __restrict__ vold = pf.vecs + (size_t)set * kPcgVecs * n6;
-        double* __restrict__ vnew = pf.vecs + (size_t)(L == 0 ? 0 : set ^ 1) * kPcgVecs * n6;
-        const double* __restrict__ acc_in = acc + (size_t)(L % 3) * n6;
-        double* __restrict__ acc_clear = acc + (size_t)((L + 2) % 3) * n6;
-        acc += (size_t)((L + 1) % 3) * n6;                        // this launch's product goes here
+        double* __restrict__ vnew = pf.vecs + (size_t)(L == 0 ? 0 : set ^ 1) * kPcgVecs * n6;   // = set L & 1
         double uu[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         double m[21];
         PcgCtrl ci;
@@ -1269,13 +1168,13 @@ __global__ __launch_bounds__(kSweepThreads) void k_schur_sweep(
             for (int n = 0; n < 21; ++n) m[n] = pf.Minv[(size_t)n * C + cam];
         }
         if (L == 0) {
-            // start of a solve (k_pcg_init's work): rhs = -g_c - acc0 (acc0 = -sum W e from the MODE 1
-            // sweep), x = p = s = 0, r = rhs, u = Minv r
+            // start of a solve (k_pcg_init's work): rhs = -g_c - acc (acc = -sum W e from pass B, MODE 1),
+            // x = p = s = 0, r = rhs, u = Minv r
             double rr[6];
             double t[1] = {0.0};
             if (has) {
 #pragma unroll
-                for (int k = 0; k < 6; ++k) rr[k] = -pf.Ugc[(size_t)cam * 27 + 21 + k] - acc_in[(size_t)k * C + cam];
+                for (int k = 0; k < 6; ++k) rr[k] = -pf.Ugc[(size_t)cam * 27 + 21 + k] - acc[(size_t)k * C + cam];
 #pragma unroll
                 for (int k = 0; k < 6; ++k) {
                     uu[k] = minv_row(m, rr, k);
@@ -1297,9 +1196,6 @@ __global__ __launch_bounds__(kSweepThreads) void k_schur_sweep(
                 PcgCtrl c0;
                 c0.rz = rz; c0.rz0 = rz; c0.tol2 = pf.tol * pf.tol; c0.rz_prev = 1.0; c0.alpha_prev = 1.0;
                 c0.iters = 0; c0.max_iters = pf.max_iters; c0.done = done; c0.pad = 1;
-#ifdef SFMBA_STAMPS
-                for (int k = 0; k < 16; ++k) c0.stamp[k] = 0;
-#endif
                 *cout = c0;
             }
             if (done != 0) return;                                // grid-uniform
@@ -1310,7 +1206,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_schur_sweep(
                 for (int k = 0; k < 6; ++k) {
                     const size_t e = (size_t)k * C + cam;
                     ue[k] = vold[kPcgU * n6 + e];
-                    we[k] = acc_in[e] + pf.Dc[e] * ue[k];
+                    we[k] = acc[e] + pf.Dc[e] * ue[k];
                     so[k] = vold[kPcgS * n6 + e];
                     ro[k] = vold[kPcgR * n6 + e];
                 }
@@ -1370,75 +1266,32 @@ __global__ __launch_bounds__(kSweepThreads) void k_schur_sweep(
         }
         if (has) {
 #pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                smem[6 * cam + k] = uu[k];
-                smem[n6 + 6 * cam + k] = 0.0;
-                if (own) acc_clear[(size_t)k * C + cam] = 0.0;
-            }
+            for (int k = 0; k < 6; ++k) smem[6 * cam + k] = uu[k];
         }
         __syncthreads();
     } else if (ctrl2 != nullptr) {
-        // inside the PCG: `vin` is the base of the ping-pong vector sets, `acc` the base of the two
-        // accumulators; the control block of this launch (written by the previous kernel) says which
+        // inside the two-kernel PCG: `vin` is the base of the ping-pong vector sets; the control block of this
+        // launch (written by the previous k_pcg_update) says which set is current
         const PcgCtrl* __restrict__ ctrl = ctrl2 + (L & 1);
         if (ctrl->done != 0) return;                         // grid-uniform
-        const int set = ctrl->iters & 1;
-        vin += (size_t)(set * kPcgVecs + (ACC == 2 ? kPcgUcm : kPcgU)) * n6;
-        acc += (size_t)set * n6;
+        vin += (size_t)((ctrl->iters & 1) * kPcgVecs + (LDS_VEC ? kPcgU : kPcgUcm)) * n6;
     }
-    double* s_v = smem;
-    double* s_acc = (ACC == 2) ? smem : smem + n6;
-    if (LDS_ACC && !FUSED) {
-        for (int e = threadIdx.x; e < n6; e += blockDim.x) {       // e = k*C + c (global, coalesced)
+    if (LDS_VEC && !FUSED) {
+        for (int e = threadIdx.x; e < n6; e += blockDim.x) {       // e = k*C + c (plane-major global, coalesced)
             const int k = e / C, cc = e - k * C;
-            s_v[6 * cc + k] = (MODE == 0) ? vin[e] : 0.0;
-            s_acc[6 * cc + k] = 0.0;
+            smem[6 * cc + k] = vin[e];
         }
-        __syncthreads();
-    } else if (ACC == 2) {
-        for (int e = threadIdx.x; e < 6 * (c_hi - c_lo); e += blockDim.x) s_acc[e] = 0.0;
         __syncthreads();
     }
-    // v: LDS table (ACC 1), camera-major copy in global memory (ACC 2; the standalone test entry hands a
-    // plane-major vector and ctrl2 == nullptr, see the host), plane-major global (ACC 0)
-    const double* __restrict__ vv = LDS_ACC ? s_v : vin;
-    double* __restrict__ av = (ACC == 0) ? acc : (ACC == 1 ? s_acc : s_acc - 6 * (size_t)c_lo);
-    // element k of camera c: LDS tables and the camera-major copy keep one camera's 6 values adjacent,
-    // the plane-major global vectors do not
-    const int cs = (ACC == 0) ? 1 : 6, ks = (ACC == 0) ? C : 1;
-    const int acs = (ACC == 0) ? 1 : 6, aks = (ACC == 0) ? C : 1;
-
-    // per-observation pieces
-    auto jcv = [&](const double* jc, int cc, double& t0, double& t1) {
+    // v: LDS table, or the camera-major copy [C][6] in global memory (L2) when 6 C doubles exceed the LDS
+    const double* __restrict__ vv = LDS_VEC ? smem : vin;
+    auto jcv = [&](const double* jc, int cc, double& t0, double& t1) {    // rows of 48 bytes, 16-byte aligned
+        const double2* a2 = reinterpret_cast<const double2*>(vv + 6 * cc);
+        const double2 a01 = a2[0], a23 = a2[1], a45 = a2[2];
+        const double a[6] = {a01.x, a01.y, a23.x, a23.y, a45.x, a45.y};
         t0 = 0.0; t1 = 0.0;
-        if (MODE == 0) {
-            if (ACC == 1) {                        // LDS row of 48 bytes, 16-byte aligned: three 128-bit reads
-                const double2* a2 = reinterpret_cast<const double2*>(s_v + 6 * cc);
-                const double2 a01 = a2[0], a23 = a2[1], a45 = a2[2];
-                const double a[6] = {a01.x, a01.y, a23.x, a23.y, a45.x, a45.y};
 #pragma unroll
-                for (int k = 0; k < 6; ++k) { t0 += jc[k] * a[k]; t1 += jc[6 + k] * a[k]; }
-            } else {
-                const double* a = vv + cs * cc;
-#pragma unroll
-                for (int k = 0; k < 6; ++k) { const double ak = a[ks * k]; t0 += jc[k] * ak; t1 += jc[6 + k] * ak; }
-            }
-        }
-    };
-    auto scatter = [&](const double* jc, const double* jp, int cc, double t0, double t1, double z0,
-                       double z1, double z2) {
-        const double u0 = t0 - (jp[0] * z0 + jp[1] * z1 + jp[2] * z2);
-        const double u1 = t1 - (jp[3] * z0 + jp[4] * z1 + jp[5] * z2);
-        if (ACC == 2 && (cc < c_lo || cc >= c_hi)) return;                  // another pass owns this camera
-#ifndef SFMBA_ABLATE_SCATTER
-#pragma unroll
-        for (int k = 0; k < 6; ++k) unsafeAtomicAdd(av + acs * cc + aks * k, jc[k] * u0 + jc[6 + k] * u1);
-#else
-        double sacc = 0.0;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) sacc += jc[k] * u0 + jc[6 + k] * u1;
-        if (sacc == 123.456) av[acs * cc] = sacc;                           // keep the values live
-#endif
+        for (int k = 0; k < 6; ++k) { t0 += jc[k] * a[k]; t1 += jc[6 + k] * a[k]; }
     };
 
     while (s < s_end) {
@@ -1450,94 +1303,114 @@ __global__ __launch_bounds__(kSweepThreads) void k_schur_sweep(
         if (nxt.y <= 64 && lane < nxt.y) { cn = o.cam_idx[in_]; pn = o.pt_idx[in_]; }
 
         double jc[12], jp[6];
+        double y[3] = {0.0, 0.0, 0.0};
         if (cur.y > 64) {                          // one point with more than 64 observations
             const int run_end = cur.x + cur.y;
             const int pp = o.pt_idx[cur.x];
-            double z0, z1, z2;
-            if (MODE == 0) {
-                double y[3] = {0.0, 0.0, 0.0};
-                for (int j = cur.x + lane; j < run_end; j += 64) {
-                    load_blocks(o, j, jc, jp);
-                    double t0, t1;
-                    jcv(jc, o.cam_idx[j], t0, t1);
-                    y[0] += jp[0] * t0 + jp[3] * t1; y[1] += jp[1] * t0 + jp[4] * t1;
-                    y[2] += jp[2] * t0 + jp[5] * t1;
-                }
-                y[0] = wave_sum(y[0]); y[1] = wave_sum(y[1]); y[2] = wave_sum(y[2]);
-                const double* vi = Vinv + 6 * (size_t)pp;
-                z0 = vi[0] * y[0] + vi[1] * y[1] + vi[2] * y[2];
-                z1 = vi[1] * y[0] + vi[3] * y[1] + vi[4] * y[2];
-                z2 = vi[2] * y[0] + vi[4] * y[1] + vi[5] * y[2];
-            } else {
-                z0 = zin[3 * (size_t)pp]; z1 = zin[3 * (size_t)pp + 1]; z2 = zin[3 * (size_t)pp + 2];
-            }
             for (int j = cur.x + lane; j < run_end; j += 64) {
                 load_blocks(o, j, jc, jp);
-                const int cc = o.cam_idx[j];
                 double t0, t1;
-                jcv(jc, cc, t0, t1);
-                scatter(jc, jp, cc, t0, t1, z0, z1, z2);
+                jcv(jc, o.cam_idx[j], t0, t1);
+                y[0] += jp[0] * t0 + jp[3] * t1; y[1] += jp[1] * t0 + jp[4] * t1;
+                y[2] += jp[2] * t0 + jp[5] * t1;
+            }
+            y[0] = wave_sum(y[0]); y[1] = wave_sum(y[1]); y[2] = wave_sum(y[2]);
+            if (lane == 0) {
+                const double* vi = Vinv + 6 * (size_t)pp;
+                zout[3 * (size_t)pp + 0] = vi[0] * y[0] + vi[1] * y[1] + vi[2] * y[2];
+                zout[3 * (size_t)pp + 1] = vi[1] * y[0] + vi[3] * y[1] + vi[4] * y[2];
+                zout[3 * (size_t)pp + 2] = vi[2] * y[0] + vi[4] * y[1] + vi[5] * y[2];
             }
         } else {
             const bool act = lane < cur.y;
-            double t0 = 0.0, t1 = 0.0, z0 = 0.0, z1 = 0.0, z2 = 0.0;
             double vi[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
             if (act) {
                 load_blocks(o, i, jc, jp);
-                if (MODE == 0) {                   // every lane of a run reads its point's block: no
-#pragma unroll                                     // dependent gather after the reduction
-                    for (int k = 0; k < 6; ++k) vi[k] = Vinv[6 * (size_t)p + k];
-                } else {
-                    z0 = zin[3 * (size_t)p]; z1 = zin[3 * (size_t)p + 1]; z2 = zin[3 * (size_t)p + 2];
-                }
+#pragma unroll                                     // every lane of a run reads its point's block: no dependent
+                for (int k = 0; k < 6; ++k) vi[k] = Vinv[6 * (size_t)p + k];       // gather after the reduction
+                double t0, t1;
                 jcv(jc, c, t0, t1);
+                y[0] = jp[0] * t0 + jp[3] * t1; y[1] = jp[1] * t0 + jp[4] * t1;
+                y[2] = jp[2] * t0 + jp[5] * t1;
             }
-            if (MODE == 0) {
-                double y[3] = {0.0, 0.0, 0.0};
-                if (act) {
-                    y[0] = jp[0] * t0 + jp[3] * t1; y[1] = jp[1] * t0 + jp[4] * t1;
-                    y[2] = jp[2] * t0 + jp[5] * t1;
-                }
-                const int key = act ? p : -1 - lane;                  // run key = point index
-#ifndef SFMBA_ABLATE_SWEEP_SEGRED
-                seg_reduce<3>(y, key, lane);
-#endif
-                z0 = vi[0] * y[0] + vi[1] * y[1] + vi[2] * y[2];      // meaningful on run heads
-                z1 = vi[1] * y[0] + vi[3] * y[1] + vi[4] * y[2];
-                z2 = vi[2] * y[0] + vi[4] * y[1] + vi[5] * y[2];
-#ifndef SFMBA_ABLATE_SWEEP_SEGRED
-                // first lane of the lane's run: the highest run start at or below it
-                const int prev = __shfl_up(key, 1);
-                const unsigned long long starts = __ballot(lane == 0 || prev != key);
-                const int head = 63 - __clzll((long long)(starts & (~0ull >> (63 - lane))));
-                z0 = __shfl(z0, head); z1 = __shfl(z1, head); z2 = __shfl(z2, head);
-#endif
+            const int key = act ? p : -1 - lane;                  // run key = point index
+            seg_reduce<3>(y, key, lane);
+            const int prev = __shfl_up(key, 1);
+            if (act && (lane == 0 || prev != key)) {              // first lane of the point's run
+                zout[3 * (size_t)p + 0] = vi[0] * y[0] + vi[1] * y[1] + vi[2] * y[2];
+                zout[3 * (size_t)p + 1] = vi[1] * y[0] + vi[3] * y[1] + vi[4] * y[2];
+                zout[3 * (size_t)p + 2] = vi[2] * y[0] + vi[4] * y[1] + vi[5] * y[2];
             }
-            if (act) scatter(jc, jp, c, t0, t1, z0, z1, z2);
         }
         cur = nxt; i = in_; c = cn; p = pn;
         ++s;
     }
-    if (ACC == 2) {
-        __syncthreads();
-        const int nr = c_hi - c_lo;
-        for (int e = threadIdx.x; e < 6 * nr; e += blockDim.x) {    // e = k*nr + (c - c_lo): coalesced per plane
-            const int k = e / nr, cc = e - k * nr;
-            const double a = s_acc[6 * cc + k];
-            if (a != 0.0) unsafeAtomicAdd(acc + (size_t)k * C + c_lo + cc, a);
-        }
+}
+
+// Pass B: acc_c = sum_{i in c} Jc_i^T ( Jc_i v_c - Jp_i z_p )   (MODE 0; v_c wave-uniform, z gathered), or
+//         acc_c = - sum Jc_i^T Jp_i e_p                          (MODE 1; z = e), over one camera chunk, with the
+// blocks recomputed from the camera row and the gathered point.  In fp32-storage mode the recomputed entries
+// are rounded to float first: pass A applied the STORED (rounded) blocks, and the product has to be that of one
+// symmetric matrix.  Output: plane-major acc[k][C] for a single-chunk camera, partial[chunk][6] otherwise.
+//   ctrl_done: PCG control block whose `done` voids this launch (null: unconditional)
+//   set:       vector set holding u; < 0: take it from ctrl_done->iters (two-kernel PCG); vin then is the base of
+//              the sets.  ctrl_done == null: vin is the plane-major vector itself.
+template <int MODE, bool F32>
+__global__ __launch_bounds__(kCamThreads) void k_cam_schur(CamMajor cm, const double* __restrict__ camtab,
+                                                           const double* __restrict__ pts, KMat K,
+                                                           const double* __restrict__ vin,
+                                                           const double* __restrict__ zin, int C,
+                                                           double* __restrict__ acc, double* __restrict__ partial,
+                                                           const PcgCtrl* __restrict__ ctrl_done, int set) {
+    __shared__ double red[kCamWaves][6];
+    if (ctrl_done != nullptr) {
+        if (ctrl_done->done != 0) return;                       // grid-uniform
+        if (MODE == 0) vin += (size_t)((set < 0 ? (ctrl_done->iters & 1) : set) * kPcgVecs + kPcgU) * 6 * C;
     }
-    if (LDS_ACC) {
-        __syncthreads();
-#ifndef SFMBA_ABLATE_FLUSH          // timing-only ablation builds, never shipped
-        for (int e = threadIdx.x; e < n6; e += blockDim.x) {
-            const int k = e / C, cc = e - k * C;
-            const double a = s_acc[6 * cc + k];
-            if (a != 0.0) unsafeAtomicAdd(acc + e, a);
+    const int4 ch = cm.chunks[blockIdx.x];
+    double t[kCamTab];
+#pragma unroll
+    for (int k = 0; k < kCamTab; ++k) t[k] = camtab[(size_t)ch.x * kCamTab + k];      // wave-uniform: scalar loads
+    double vc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (MODE == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) vc[k] = vin[(size_t)k * C + ch.x];
+    }
+    double a[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    int k = ch.y + (int)threadIdx.x;
+    int p = 0;
+    if (k < ch.z) p = cm.pt[k];
+    while (k < ch.z) {
+        const int kn = k + kCamThreads;
+        int pn = 0;
+        if (kn < ch.z) pn = cm.pt[kn];
+        const double* __restrict__ Xp = pts + 3 * (size_t)p;
+        const double* __restrict__ zp = zin + 3 * (size_t)p;
+        const double z0 = zp[0], z1 = zp[1], z2 = zp[2];
+        double jc[12], jp[6], rx, ry;
+        observe<true>(t, Xp[0], Xp[1], Xp[2], 0.0, 0.0, K, rx, ry, jc, jp);
+        if (F32) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { jc[q] = (double)(float)jc[q]; jc[6 + q] = (double)(float)jc[6 + q]; }
+#pragma unroll
+            for (int q = 0; q < 6; ++q) jp[q] = (double)(float)jp[q];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { jc[3 + q] = -jp[q]; jc[9 + q] = -jp[3 + q]; }
         }
-#else
-        if (threadIdx.x == 0 && s_acc[0] == 123.456) acc[0] = s_acc[1];     // keep the table live
-#endif
+        double u0 = -(jp[0] * z0 + jp[1] * z1 + jp[2] * z2);
+        double u1 = -(jp[3] * z0 + jp[4] * z1 + jp[5] * z2);
+        if (MODE == 0) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) { u0 += jc[q] * vc[q]; u1 += jc[6 + q] * vc[q]; }
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) a[q] += jc[q] * u0 + jc[6 + q] * u1;
+        k = kn; p = pn;
+    }
+    const double s = cam_block_total<6>(a, red);
+    if (threadIdx.x < 6) {
+        if (ch.w == 1) acc[(size_t)threadIdx.x * C + ch.x] = s;
+        else partial[(size_t)blockIdx.x * 6 + threadIdx.x] = s;
     }
 }
 
@@ -1554,10 +1427,10 @@ __global__ __launch_bounds__(kSweepThreads) void k_schur_sweep(
 // blocks alternate as well (read ctrl2[L&1], written ctrl2[(L+1)&1] by block 0 only), so no workgroup
 // can observe a value written during its own launch.
 
-// Start: rhs = -g_c - acc0 (acc0 = -sum W e from the MODE 1 sweep), x = 0, r = rhs, u = Minv r,
-// p = s = 0 in set 0; all three accumulators zeroed; ctrl2[0] initialised.  Single workgroup.
+// Start: rhs = -g_c - acc (acc = -sum W e from pass B, MODE 1), x = 0, r = rhs, u = Minv r,
+// p = s = 0 in set 0; ctrl2[0] initialised.  Single workgroup.
 __global__ __launch_bounds__(1024) void k_pcg_init(const double* __restrict__ Ugc,
-                                                   double* __restrict__ acc,
+                                                   const double* __restrict__ acc,
                                                    const double* __restrict__ Minv, int C,
                                                    double* __restrict__ vecs, double tol,
                                                    int max_iters, PcgCtrl* __restrict__ ctrl2) {
@@ -1575,7 +1448,6 @@ __global__ __launch_bounds__(1024) void k_pcg_init(const double* __restrict__ Ug
         for (int k = 0; k < 6; ++k) {
             const size_t e = (size_t)k * C + c;
             rr[k] = -Ugc[(size_t)c * 27 + 21 + k] - acc[e];
-            acc[e] = 0.0; acc[n6 + e] = 0.0; acc[2 * n6 + e] = 0.0;
             xk[e] = 0.0; pk[e] = 0.0; sk[e] = 0.0;
             rk[e] = rr[k];
         }
@@ -1596,17 +1468,14 @@ __global__ __launch_bounds__(1024) void k_pcg_init(const double* __restrict__ Ug
         c0.iters = 0; c0.max_iters = max_iters;
         c0.done = (s[0] > 0.0) ? 0 : (s[0] == 0.0 ? 1 : 3);
         c0.pad = 0;
-#ifdef SFMBA_STAMPS
-        for (int k = 0; k < 16; ++k) c0.stamp[k] = 0;
-#endif
         ctrl2[0] = c0;
     }
 }
 
-// One PCG step after the sweep of launch L produced acc[set] = (S - Dc) u.  A finished solve turns every
+// One PCG step after passes A and B of launch L produced acc = (S - Dc) u.  A finished solve turns every
 // later sweep/update into a no-op (done is copied forward), so the host may enqueue iterations without
 // reading back.
-__global__ __launch_bounds__(1024) void k_pcg_update(double* __restrict__ acc,
+__global__ __launch_bounds__(1024) void k_pcg_update(const double* __restrict__ acc_in,
                                                      const double* __restrict__ Dc,
                                                      const double* __restrict__ Minv, int C,
                                                      double* __restrict__ vecs,
@@ -1624,8 +1493,6 @@ __global__ __launch_bounds__(1024) void k_pcg_update(double* __restrict__ acc,
     const int set = ci.iters & 1;
     const double* __restrict__ vin = vecs + (size_t)set * kPcgVecs * n6;
     double* __restrict__ vout = vecs + (size_t)(set ^ 1) * kPcgVecs * n6;
-    const double* __restrict__ acc_in = acc + (size_t)set * n6;
-    double* __restrict__ acc_out = acc + (size_t)(set ^ 1) * n6;
     const double* __restrict__ u_in = vin + kPcgU * n6;
     // cameras whose results this workgroup stores
     const int slice = ((C + (int)gridDim.x - 1) / (int)gridDim.x + 63) & ~63;
@@ -1680,7 +1547,6 @@ __global__ __launch_bounds__(1024) void k_pcg_update(double* __restrict__ acc,
                 vout[kPcgP * n6 + e] = pp[k]; vout[kPcgS * n6 + e] = ss[k];
                 vout[kPcgU * n6 + e] = uu[k];
                 vout[kPcgUcm * n6 + 6 * (size_t)c + k] = uu[k];
-                acc_out[e] = 0.0;                        // the sweep after next accumulates here
             }
         }
     }
@@ -1715,7 +1581,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_backsub(
     if (ctrl2 != nullptr)                      // dc_planes = base of the PCG vector sets: take x of the final set
         dc_planes += (size_t)((ctrl2[L & 1].iters & 1) * kPcgVecs + kPcgX) * 6 * C;
     // dc_planes: PCG solution, plane-major [6][C]; dc: camera-major [C][6] copy (already written by
-    // k_transpose6 when the LDS table is not used)
+    // k_transpose when the LDS table is not used)
     if (LDS_VEC) {
         for (int i = threadIdx.x; i < 6 * C; i += blockDim.x) {
             const int k = i / C, c = i - k * C;
@@ -1847,14 +1713,15 @@ __global__ __launch_bounds__(kSweepThreads) void k_backsub(
     }
 }
 
-// camera-major [C][6] <- plane-major [6][C]
-__global__ void k_transpose6(const double* __restrict__ planes, int C, double* __restrict__ out,
-                             const PcgCtrl* __restrict__ ctrl2, int L) {
+// out [cols][rows] <- in [rows][cols]; camera-major [C][6] <- plane-major [6][C] with rows = 6, cols = C.
+// ctrl2 != null: `in` is the base of the PCG vector sets, take x of the final set.
+__global__ void k_transpose(const double* __restrict__ in, int rows, int cols, double* __restrict__ out,
+                            const PcgCtrl* __restrict__ ctrl2, int L) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 6 * C) return;
-    if (ctrl2 != nullptr) planes += (size_t)((ctrl2[L & 1].iters & 1) * kPcgVecs + kPcgX) * 6 * C;
-    const int k = i / C, c = i - k * C;
-    out[6 * c + k] = planes[i];
+    if (i >= rows * cols) return;
+    if (ctrl2 != nullptr) in += (size_t)((ctrl2[L & 1].iters & 1) * kPcgVecs + kPcgX) * rows * cols;
+    const int r = i / cols, c = i - r * cols;
+    out[(size_t)c * rows + r] = in[i];
 }
 
 // streaming-store ceiling probe: 16 B per lane, grid-stride
@@ -1956,13 +1823,6 @@ __global__ __launch_bounds__(256) void k_p2p_allreduce(double* __restrict__ vec,
 __global__ __launch_bounds__(1024) void k_fill16(double* __restrict__ a, int64_t n2, double v) {
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n2; e += (int64_t)gridDim.x * blockDim.x)
         *reinterpret_cast<double2*>(a + 2 * e) = make_double2(v, v + 1.0);
-}
-
-__global__ void k_fill(double* __restrict__ a, int64_t n, double v, const double* __restrict__ skip) {
-    if (skip != nullptr && *skip != 0.0) return;   // speculative launch cancelled by k_tr_step
-    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n;
-         e += (int64_t)gridDim.x * blockDim.x)
-        a[e] = v;
 }
 
 }  // namespace sfmba

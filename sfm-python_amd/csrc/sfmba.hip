@@ -133,21 +133,29 @@ struct sfmba_handle {
     int n_ranges = 0;
     bool f32 = false;                        // fp32 storage of uv, r, t1 and the Jacobian (arithmetic stays fp64)
     bool f32_next = false;                   // takes effect at the next sfmba_set_problem
-    bool lds_tab = true, lds_acc = true, lds_vec = true;
-    int acc_mode = 1, acc_range = 0;         // operand placement of the Schur sweep (launch_schur_sweep)
-    int nb_passes = 1;                       // column passes of the LDS normal-block tables; 0 = global atomics
+    bool lds_tab = true, lds_vec = true;     // camera table (K1, K2) / camera vector (sweeps) staged in LDS
+    // test / diagnostic hooks, set through sfmba_debug_option only (nothing reads the environment)
+    struct Debug {
+        int pcg_fused = -1;                  // 0: two-kernel PCG although the fused launch would fit
+        int tab_lds = -1, vec_lds = -1;      // 0: camera table / camera vector read from L2 although LDS would fit
+        int cam_chunk = 0;                   // > 0: chunk length of the camera-major kernels
+        int pcg_guess_bias = 0;              // added to the number of speculatively enqueued PCG iterations
+        int trace_pcg = 0, trace_stalls = 0, trace_timing = 0;   // stderr diagnostics
+    } dbg;
 
     DevBuf cam_idx, pt_idx, pt_ptr, uv, ranges, wsteps, steps;
     int n_steps = 0;
-    DevBuf xa, xb, tabA, tabB, r[2], J[2], t1;   // J and r double-buffered: a trial step is
-                                                       // evaluated into the spare set and swapped in on accept
-    int jcur = 0;
-    DevBuf V, Vinv, gp, e;
+    // camera-major order of the same observations (structure only): per-camera sums without atomics
+    DevBuf cm_perm, cm_pt, cm_uv, cam_chunks, cam_chunk_ptr, cam_partial;
+    int n_chunks = 0;
+    bool cam_multi = false;                  // some camera has more than one chunk: k_cam_combine runs
+    DevBuf xa, xb, tabA, tabB, r, J, t1;     // ONE Jacobian / residual buffer set
+    DevBuf V, Vinv, gp, e, z;                // z: per-point vector of the Schur product (pass A -> pass B)
     DevBuf g, si, sg, p;                     // n-vectors; p = [dc | dp]
     DevBuf Dc, Minv, vecs, vtmp, vcm;               // camera-sized, plane-major [k][C]; vecs = 2 sets x (x r p s u)
-    DevBuf part, ctrl, tables;
+    DevBuf part, ctrl;
     DevBuf arena_own;
-    double* arena = nullptr;                 // [acc0 6C | acc1 6C | acc2 6C | Ugc 27C | 32 scalars]
+    double* arena = nullptr;                 // [acc 6C | spare 12C | Ugc 27C | 32 scalars]
     int64_t arena_doubles = 0;
     sfmba_allreduce_fn ar_fn = nullptr;
     void* ar_ctx = nullptr;
@@ -177,9 +185,7 @@ struct sfmba_handle {
     size_t h_x_doubles = 0;
     const double* skip = nullptr;         // device flag gating speculative trial launches (sfmba_solve); else null
     double pcg_tol = 0.0; int pcg_cap = 0; // options of the running PCG (fused launch 0 writes the control block)
-    bool nb_one_reduce = false;           // SFMBA_NB_ONE_REDUCE=1: keep the tables of all normal-block passes and reduce them
-                                          // in one launch (1.4 us less, but 27 MB more between two K1 launches: K1 +1.6 us)
-    bool pcg_fused = false;               // PCG update fused into the sweep launch (acc_mode 1, C <= 1024)
+    bool pcg_fused = false;               // PCG update fused into the launch of pass A (v in LDS, C <= 1024)
     int pcg_hint = 0;                     // largest PCG iteration count a solve on this handle has needed
     bool solved = false;
     std::vector<const void*> lds_ready;      // kernels already opted in to 160 KiB dynamic LDS
@@ -190,7 +196,7 @@ struct sfmba_handle {
     double* tab = nullptr;
     double* tab_new = nullptr;
 
-    double* acc() const { return arena; }    // three accumulators (PCG rotation); [0] also serves the rhs sweep
+    double* acc() const { return arena; }    // product of the implicit Schur complement / reduced rhs term (6C)
     double* Ugc() const { return arena + 18 * C; }
     double* scal() const { return arena + 45 * C; }
     int pcg_L = 0;                           // launches (sweep+update pairs) since pcg_start
@@ -299,7 +305,7 @@ int set_lds(sfmba_handle* h, Kern k, size_t bytes) {
 
 ObsArrays obs_arrays(const sfmba_handle* h) {
     return ObsArrays{h->cam_idx.as<int>(), h->pt_idx.as<int>(), h->pt_ptr.as<int>(),
-                     h->J[h->jcur].as<double>(), h->ld, h->f32 ? 1 : 0};
+                     h->J.as<double>(), h->ld, h->f32 ? 1 : 0};
 }
 
 StepTable step_table(const sfmba_handle* h) {
@@ -316,21 +322,20 @@ int grid_1d(int64_t n, int block, int cap) {
 // Host/device hand-off: poll the stream instead of sleeping in hipStreamSynchronize.  The solver
 // hands control back to the host two to three times per outer iteration for ~30 us of GPU work each;
 // a blocking wait that parks the thread costs up to a millisecond per wake-up on an idle host.
-void report_stall(const char* where, double seconds) {          // SFMBA_DEBUG_STALLS=1: waits longer than 2 ms
-    static const bool on = std::getenv("SFMBA_DEBUG_STALLS") != nullptr;
-    if (on && seconds > 2e-3) fprintf(stderr, "sfmba: waited %.2f ms in %s\n", 1e3 * seconds, where);
+void report_stall(const sfmba_handle* h, const char* where, double seconds) {   // trace_stalls: waits longer than 2 ms
+    if (h->dbg.trace_stalls && seconds > 2e-3) fprintf(stderr, "sfmba: waited %.2f ms in %s\n", 1e3 * seconds, where);
 }
 
 int wait_stream(sfmba_handle* h) {
     const double t0 = now_s();
     for (;;) {
         const hipError_t e = hipStreamQuery(h->stream);
-        if (e == hipSuccess) { report_stall("wait_stream", now_s() - t0); return 0; }
+        if (e == hipSuccess) { report_stall(h, "wait_stream", now_s() - t0); return 0; }
         if (e != hipErrorNotReady) return fail(h, -3, "hipStreamQuery failed: %s", hipGetErrorString(e));
         if (now_s() - t0 > 0.05) break;          // long wait: stop burning the core
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    report_stall("wait_stream (blocking)", now_s() - t0);
+    report_stall(h, "wait_stream (blocking)", now_s() - t0);
     return 0;
 }
 
@@ -345,14 +350,14 @@ int wait_mailbox(sfmba_handle* h, unsigned long long seq) {
     const double t0 = now_s();
     double t_check = t0 + 5e-3;
     for (int spin = 0;; ++spin) {
-        if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) { report_stall("wait_mailbox", now_s() - t0); return 0; }
+        if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) { report_stall(h, "wait_mailbox", now_s() - t0); return 0; }
         __builtin_ia32_pause();
         if ((spin & 15) != 15) continue;
         const double t = now_s();
         if (t < t_check) continue;
         const hipError_t e = hipStreamQuery(h->stream);
         if (e == hipSuccess) {                               // everything enqueued has run: the post is visible
-            if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) { report_stall("wait_mailbox (stream idle)", now_s() - t0); return 0; }
+            if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) { report_stall(h, "wait_mailbox (stream idle)", now_s() - t0); return 0; }
             return fail(h, -3, "hand-off mailbox was not written");
         }
         if (e != hipErrorNotReady) return fail(h, -3, "hipStreamQuery failed: %s", hipGetErrorString(e));
@@ -368,12 +373,12 @@ int launch_cam_table(sfmba_handle* h, const double* x, double* tab) {
     return 0;
 }
 
-// residual (+Jacobian) sweep at x (camera table must be current) into buffer set `js`; leaves the
+// residual (+Jacobian) sweep at x (camera table must be current); leaves the
 // sum r^2 partials in `part` and returns the number of partials.  With ev0/ev1 the dispatch itself
 // is bracketed (hipExtLaunchKernelGGL: start/stop taken from the kernel's own dispatch, as rocprofv3
 // does), so the measured duration is the kernel's and not host launch latency.
 template <bool LDS, bool JAC, bool STORE_R, bool F32>
-int launch_resjac_v(sfmba_handle* h, const double* x, const double* tab, int js, int grid, size_t lds,
+int launch_resjac_v(sfmba_handle* h, const double* x, const double* tab, int grid, size_t lds,
                     hipEvent_t ev0, hipEvent_t ev1) {
     const double* pts = x + 6 * h->C;
     auto kern = k_resjac<LDS, JAC, STORE_R, F32>;
@@ -381,12 +386,12 @@ int launch_resjac_v(sfmba_handle* h, const double* x, const double* tab, int js,
     if (ev0) {
         hipExtLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), (uint32_t)lds, h->stream, ev0, ev1, 0u, tab, pts,
                               (const int*)h->cam_idx.as<int>(), (const int*)h->pt_idx.as<int>(),
-                              (const double*)h->uv.as<double>(), h->r[js].as<double>(), h->J[js].as<double>(),
+                              (const double*)h->uv.as<double>(), h->r.as<double>(), h->J.as<double>(),
                               (int)h->N, h->ld, (int)h->C, h->K, h->part.as<double>(), h->skip);
     } else {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), lds, h->stream, tab, pts,
                            h->cam_idx.as<int>(), h->pt_idx.as<int>(), h->uv.as<double>(),
-                           h->r[js].as<double>(), h->J[js].as<double>(), (int)h->N,
+                           h->r.as<double>(), h->J.as<double>(), (int)h->N,
                            h->ld, (int)h->C, h->K, h->part.as<double>(), h->skip);
     }
     HIPCHK(h, hipGetLastError());
@@ -394,16 +399,16 @@ int launch_resjac_v(sfmba_handle* h, const double* x, const double* tab, int js,
 }
 
 template <bool JAC, bool STORE_R>
-int launch_resjac(sfmba_handle* h, const double* x, const double* tab, int js, int* nparts,
+int launch_resjac(sfmba_handle* h, const double* x, const double* tab, int* nparts,
                   hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
     const int grid = grid_1d(h->N, kSweepThreads, h->n_cu);
     *nparts = grid;
     const size_t lds = (size_t)h->C * kCamTab * sizeof(double);
     if (h->lds_tab)
-        return h->f32 ? launch_resjac_v<true, JAC, STORE_R, true>(h, x, tab, js, grid, lds, ev0, ev1)
-                      : launch_resjac_v<true, JAC, STORE_R, false>(h, x, tab, js, grid, lds, ev0, ev1);
-    return h->f32 ? launch_resjac_v<false, JAC, STORE_R, true>(h, x, tab, js, grid, 0, ev0, ev1)
-                  : launch_resjac_v<false, JAC, STORE_R, false>(h, x, tab, js, grid, 0, ev0, ev1);
+        return h->f32 ? launch_resjac_v<true, JAC, STORE_R, true>(h, x, tab, grid, lds, ev0, ev1)
+                      : launch_resjac_v<true, JAC, STORE_R, false>(h, x, tab, grid, lds, ev0, ev1);
+    return h->f32 ? launch_resjac_v<false, JAC, STORE_R, true>(h, x, tab, grid, 0, ev0, ev1)
+                  : launch_resjac_v<false, JAC, STORE_R, false>(h, x, tab, grid, 0, ev0, ev1);
 }
 
 // sum of `nparts` partial rows of width nq into the exchange scalars starting at slot `slot`
@@ -442,92 +447,109 @@ int launch_finish_slices(sfmba_handle* h, int q_lo, int q_hi) {
     return 0;
 }
 
-int launch_normal_blocks(sfmba_handle* h) {
-    const int grid = (h->n_ranges + kWavesPerSweepBlock - 1) / kWavesPerSweepBlock;
-    if (h->nb_passes > 0) {
-        // LDS tables: columns of [U | g_c] split into nb_passes groups that fit 160 KiB
-        const int per = (27 + h->nb_passes - 1) / h->nb_passes;
-        for (int ps = 0; ps < h->nb_passes; ++ps) {
-            const int col0 = ps * per, ncols = std::min(per, 27 - col0);
-            const size_t lds = sizeof(double) * (size_t)h->C * ncols;
-            CHK(set_lds(h, k_normal_blocks_lds, lds));
-            hipLaunchKernelGGL(k_normal_blocks_lds, dim3(grid), dim3(kSweepThreads), lds, h->stream,
-                               h->ranges.as<int2>(), h->n_ranges, obs_arrays(h), h->r[h->jcur].as<double>(),
-                               h->V.as<double>(), h->gp.as<double>(),
-                               h->tables.as<double>() + (h->nb_one_reduce ? (size_t)ps * grid * ((size_t)h->C * per) : (size_t)0),
-                               (int)h->C, col0, ncols, ps == 0 ? 1 : 0, h->skip);
-            HIPCHK(h, hipGetLastError());
-            if (!h->nb_one_reduce) {          // all passes reuse one table buffer: reduce each before the next
-                hipLaunchKernelGGL(k_reduce_tables, dim3((27 * (int)h->C + 63) / 64), dim3(1024), 0, h->stream,
-                                   h->tables.as<double>(), grid, (int)h->C, per, ps, h->Ugc(), h->skip);
-                HIPCHK(h, hipGetLastError());
-            }
-        }
-        if (h->nb_one_reduce) {               // one reduction launch for the tables of all passes
-            hipLaunchKernelGGL(k_reduce_tables, dim3((27 * (int)h->C + 63) / 64), dim3(1024), 0, h->stream,
-                               h->tables.as<double>(), grid, (int)h->C, per, -1, h->Ugc(), h->skip);
-            HIPCHK(h, hipGetLastError());
-        }
-        return 0;
+CamMajor cam_major(const sfmba_handle* h) {
+    return CamMajor{h->cam_chunks.as<int4>(), h->cm_pt.as<int>(), h->cm_uv.as<double>()};
+}
+
+// chunk rows of cameras with several chunks -> out[c * cs + col * ks]
+int launch_cam_combine(sfmba_handle* h, int ncols, double* out, int cs, int ks, const double* skip, const int* done) {
+    if (!h->cam_multi) return 0;
+    hipLaunchKernelGGL(k_cam_combine, dim3((int)((h->C * ncols + 255) / 256)), dim3(256), 0, h->stream,
+                       h->cam_chunk_ptr.as<int>(), h->cam_partial.as<double>(), (int)h->C, ncols, out, cs, ks, skip, done);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+// K2 + K3 at (x, tab): V_p, g_p over the point-major order, [U_c | g_c] over the camera-major order; both
+// recompute the blocks from the camera table and the point (no stored Jacobian is read)
+template <bool F32>
+int launch_normal_blocks_v(sfmba_handle* h, const double* x, const double* tab) {
+    const double* pts = x + 6 * h->C;
+    constexpr int wpb = kPointBlockThreads / 64;
+    const int grid = (h->n_ranges + wpb - 1) / wpb;
+    const size_t lds = (size_t)h->C * kCamTab * sizeof(double);
+    if (lds <= 48 * 1024 && h->dbg.tab_lds != 0) {
+        hipLaunchKernelGGL((k_point_blocks<true, F32>), dim3(grid), dim3(kPointBlockThreads), lds, h->stream, step_table(h),
+                           h->cam_idx.as<int>(), h->pt_idx.as<int>(), h->uv.as<double>(), tab, pts, (int)h->C, h->K,
+                           h->V.as<double>(), h->gp.as<double>(), h->skip);
+    } else {
+        hipLaunchKernelGGL((k_point_blocks<false, F32>), dim3(grid), dim3(kPointBlockThreads), 0, h->stream, step_table(h),
+                           h->cam_idx.as<int>(), h->pt_idx.as<int>(), h->uv.as<double>(), tab, pts, (int)h->C, h->K,
+                           h->V.as<double>(), h->gp.as<double>(), h->skip);
     }
-    hipLaunchKernelGGL(k_fill, dim3(grid_1d(27 * h->C, 256, 2048)), dim3(256), 0, h->stream, h->Ugc(),
-                       (int64_t)(27 * h->C), 0.0, h->skip);
     HIPCHK(h, hipGetLastError());
-    hipLaunchKernelGGL(k_normal_blocks, dim3(grid), dim3(kSweepThreads), 0, h->stream,
-                       h->ranges.as<int2>(), h->n_ranges, obs_arrays(h), h->r[h->jcur].as<double>(),
-                       h->V.as<double>(), h->gp.as<double>(), h->Ugc(), h->skip);
+    hipLaunchKernelGGL((k_cam_blocks<F32>), dim3(h->n_chunks), dim3(kCamThreads), 0, h->stream, cam_major(h), tab, pts,
+                       h->K, h->Ugc(), h->cam_partial.as<double>(), h->skip);
     HIPCHK(h, hipGetLastError());
-    return 0;
+    return launch_cam_combine(h, 27, h->Ugc(), 27, 1, h->skip, nullptr);
+}
+int launch_normal_blocks(sfmba_handle* h, const double* x, const double* tab) {
+    return h->f32 ? launch_normal_blocks_v<true>(h, x, tab) : launch_normal_blocks_v<false>(h, x, tab);
 }
 
-// MODE 0 inside the PCG: vin = base of the vector sets, ctrl2/L select set and accumulator on the
-// device; MODE 0 standalone (test entry): vin = the vector itself (plane-major), ctrl2 = nullptr;
-// MODE 1: zin = e.  Operand placement (h->acc_mode): 1 = v and acc in LDS; 2 = acc in LDS per camera
-// range, one pass per range, v from the camera-major copy; 0 = all global.
-template <int ACC, int MODE>
-int launch_schur_sweep_v(sfmba_handle* h, const double* vin, const double* zin, const PcgCtrl* ctrl2, int L,
-                         size_t lds, int c_lo, int c_hi) {
+// Pass A of the implicit Schur product (z_p for every point).  Inside the two-kernel PCG: vin = base of the
+// vector sets, ctrl2 / L select the set on the device; standalone (test entry): vin = the vector itself,
+// plane-major when it is staged in LDS, camera-major otherwise; ctrl2 = nullptr.
+int launch_point_sweep(sfmba_handle* h, const double* vin, const PcgCtrl* ctrl2, int L) {
     const int grid = (h->n_ranges + kWavesPerSweepBlock - 1) / kWavesPerSweepBlock;
-    auto kern = k_schur_sweep<ACC, MODE, false>;
-    CHK(set_lds(h, kern, lds));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), lds, h->stream, step_table(h), obs_arrays(h), vin,
-                       h->Vinv.as<double>(), zin, h->acc(), (int)h->C, ctrl2, L, c_lo, c_hi, PcgFused{});
+    if (h->lds_vec) {
+        const size_t lds = sizeof(double) * 6 * (size_t)h->C;
+        auto kern = k_point_sweep<true, false>;
+        CHK(set_lds(h, kern, lds));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), lds, h->stream, step_table(h), obs_arrays(h), vin,
+                           h->Vinv.as<double>(), h->z.as<double>(), (const double*)h->acc(), (int)h->C, ctrl2, L, PcgFused{});
+    } else {
+        hipLaunchKernelGGL((k_point_sweep<false, false>), dim3(grid), dim3(kSweepThreads), 0, h->stream, step_table(h),
+                           obs_arrays(h), vin, h->Vinv.as<double>(), h->z.as<double>(), (const double*)h->acc(),
+                           (int)h->C, ctrl2, L, PcgFused{});
+    }
     HIPCHK(h, hipGetLastError());
     return 0;
 }
 
-// one whole PCG iteration per launch (update of the previous product in the prologue, then the sweep)
+// pass A fused with the PCG update of the previous product (one launch)
 int launch_pcg_fused(sfmba_handle* h, int L) {
     const int grid = (h->n_ranges + kWavesPerSweepBlock - 1) / kWavesPerSweepBlock;
-    const size_t lds = sizeof(double) * 12 * (size_t)h->C;
-    auto kern = k_schur_sweep<1, 0, true>;
+    const size_t lds = sizeof(double) * 6 * (size_t)h->C;
+    auto kern = k_point_sweep<true, true>;
     CHK(set_lds(h, kern, lds));
     PcgFused pf{h->Dc.as<double>(), h->Minv.as<double>(), h->Ugc(), h->vecs.as<double>(), h->ctrl.as<PcgCtrl>(),
                 h->pcg_tol, h->pcg_cap};
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), lds, h->stream, step_table(h), obs_arrays(h),
-                       (const double*)h->vecs.as<double>(), h->Vinv.as<double>(), (const double*)nullptr, h->acc(),
-                       (int)h->C, (const PcgCtrl*)h->ctrl.as<PcgCtrl>(), L, 0, (int)h->C, pf);
+                       (const double*)h->vecs.as<double>(), h->Vinv.as<double>(), h->z.as<double>(),
+                       (const double*)h->acc(), (int)h->C, (const PcgCtrl*)h->ctrl.as<PcgCtrl>(), L, pf);
     HIPCHK(h, hipGetLastError());
     return 0;
 }
 
+// Pass B (camera-major): MODE 0  acc = sum Jc^T (Jc v - Jp z) with z from pass A; MODE 1  acc = -sum Jc^T Jp e.
+// ctrl_done / set: see k_cam_schur.
 template <int MODE>
-int launch_schur_sweep(sfmba_handle* h, const double* vin, const double* zin, const PcgCtrl* ctrl2, int L) {
-    const int C = (int)h->C;
-    if (h->acc_mode == 1) return launch_schur_sweep_v<1, MODE>(h, vin, zin, ctrl2, L, sizeof(double) * 12 * C, 0, C);
-    if (h->acc_mode == 0) return launch_schur_sweep_v<0, MODE>(h, vin, zin, ctrl2, L, 0, 0, C);
-    const double* v = vin;
-    if (MODE == 0 && ctrl2 == nullptr) {          // standalone: make the camera-major copy the kernel gathers from
-        hipLaunchKernelGGL(k_transpose6, dim3((6 * C + 255) / 256), dim3(256), 0, h->stream, vin, C,
-                           h->vcm.as<double>(), (const PcgCtrl*)nullptr, 0);
+int launch_cam_schur(sfmba_handle* h, const double* vin, const double* zin, const PcgCtrl* ctrl_done, int set) {
+    const double* pts = h->x + 6 * h->C;
+    if (h->f32)
+        hipLaunchKernelGGL((k_cam_schur<MODE, true>), dim3(h->n_chunks), dim3(kCamThreads), 0, h->stream, cam_major(h),
+                           (const double*)h->tab, pts, h->K, vin, zin, (int)h->C, h->acc(), h->cam_partial.as<double>(),
+                           ctrl_done, set);
+    else
+        hipLaunchKernelGGL((k_cam_schur<MODE, false>), dim3(h->n_chunks), dim3(kCamThreads), 0, h->stream, cam_major(h),
+                           (const double*)h->tab, pts, h->K, vin, zin, (int)h->C, h->acc(), h->cam_partial.as<double>(),
+                           ctrl_done, set);
+    HIPCHK(h, hipGetLastError());
+    return launch_cam_combine(h, 6, h->acc(), 1, (int)h->C, nullptr, ctrl_done ? &ctrl_done->done : nullptr);
+}
+
+// acc = (S - Dc) v for a plane-major vector v outside the PCG (test and timing entries): pass A, pass B
+int schur_product_standalone(sfmba_handle* h, const double* v_planes) {
+    const double* va = v_planes;
+    if (!h->lds_vec) {                    // pass A gathers v from a camera-major copy in L2
+        hipLaunchKernelGGL(k_transpose, dim3((unsigned)((6 * h->C + 255) / 256)), dim3(256), 0, h->stream, v_planes,
+                           6, (int)h->C, h->vcm.as<double>(), (const PcgCtrl*)nullptr, 0);
         HIPCHK(h, hipGetLastError());
-        v = h->vcm.as<double>();
+        va = h->vcm.as<double>();
     }
-    for (int c_lo = 0; c_lo < C; c_lo += h->acc_range) {
-        const int c_hi = std::min(C, c_lo + h->acc_range);
-        CHK((launch_schur_sweep_v<2, MODE>(h, v, zin, ctrl2, L, sizeof(double) * 6 * (size_t)(c_hi - c_lo), c_lo, c_hi)));
-    }
-    return 0;
+    CHK(launch_point_sweep(h, va, nullptr, 0));
+    return launch_cam_schur<0>(h, v_planes, h->z.as<double>(), nullptr, 0);
 }
 
 // partials -> half B.  When k_update_scale's final sums are still pending they ride along (one extra workgroup).
@@ -568,8 +590,8 @@ int launch_backsub(sfmba_handle* h, int* nparts) {
                            h->gp.as<double>(), h->t1.as<double>(), dp, h->partB(), (int)h->C,
                            ctrl2, h->pcg_L, h->g.as<double>(), h->si.as<double>(), h->sg.as<double>());
     } else {
-        hipLaunchKernelGGL(k_transpose6, dim3((6 * h->C + 255) / 256), dim3(256), 0, h->stream,
-                           h->vecs.as<double>(), (int)h->C, dc, ctrl2, h->pcg_L);
+        hipLaunchKernelGGL(k_transpose, dim3((6 * h->C + 255) / 256), dim3(256), 0, h->stream,
+                           (const double*)h->vecs.as<double>(), 6, (int)h->C, dc, ctrl2, h->pcg_L);
         hipLaunchKernelGGL(k_backsub<false>, dim3(grid), dim3(kSweepThreads), 0, h->stream,
                            h->ranges.as<int2>(), h->n_ranges, obs_arrays(h), h->vecs.as<double>(), dc,
                            h->Vinv.as<double>(), h->gp.as<double>(), h->t1.as<double>(), dp,
@@ -676,7 +698,7 @@ int download_residuals(sfmba_handle* h, double* r_out) {
     CHK(ensure_h_x(h));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     const size_t bytes = (h->f32 ? sizeof(float) : sizeof(double)) * 2 * (size_t)h->N;
-    HIPCHK(h, hipMemcpyAsync(h->h_x, h->r[h->jcur].p, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_x, h->r.p, bytes, hipMemcpyDeviceToHost, h->stream));
     CHK(wait_stream(h));
     if (!h->f32 && !h->permuted) { memcpy(r_out, h->h_x, bytes); return 0; }
     const float* sf = reinterpret_cast<const float*>(h->h_x);
@@ -698,7 +720,7 @@ int pcg_max_iters(const sfmba_handle* h, const sfmba_options& opt) {
     return opt.pcg_max_iter > 0 ? opt.pcg_max_iter : (int)std::max<int64_t>(20, 2 * 6 * h->C);
 }
 
-// x = 0, r = rhs, u = Minv r (acc0 holds the reduced right-hand side term of the MODE 1 sweep)
+// x = 0, r = rhs, u = Minv r (acc holds the reduced right-hand side term of pass B, MODE 1)
 int pcg_start(sfmba_handle* h, const sfmba_options& opt) {
     h->pcg_L = 0;
     if (h->pcg_fused) {                   // launch 0 of the fused form initialises the solve itself
@@ -706,30 +728,34 @@ int pcg_start(sfmba_handle* h, const sfmba_options& opt) {
         h->pcg_cap = pcg_max_iters(h, opt);
         return 0;
     }
-    hipLaunchKernelGGL(k_pcg_init, dim3(1), dim3(1024), 0, h->stream, h->Ugc(), h->acc(), h->Minv.as<double>(),
-                       (int)h->C, h->vecs.as<double>(), opt.pcg_tol, pcg_max_iters(h, opt), h->ctrl.as<PcgCtrl>());
+    hipLaunchKernelGGL(k_pcg_init, dim3(1), dim3(1024), 0, h->stream, h->Ugc(), (const double*)h->acc(),
+                       h->Minv.as<double>(), (int)h->C, h->vecs.as<double>(), opt.pcg_tol, pcg_max_iters(h, opt),
+                       h->ctrl.as<PcgCtrl>());
     HIPCHK(h, hipGetLastError());
-    h->pcg_L = 0;
     return 0;
 }
 
-// enqueue `count` PCG iterations (sweep + all-reduce + update); iterations after convergence are
-// device-side no-ops, so over-enqueueing is harmless and deterministic
+// enqueue `count` PCG iterations (pass A [+ update], pass B, all-reduce [, update]); iterations after
+// convergence are device-side no-ops, so over-enqueueing is harmless and deterministic
 int pcg_enqueue(sfmba_handle* h, int count) {
     PcgCtrl* ctrl2 = h->ctrl.as<PcgCtrl>();
     for (int k = 0; k < count; ++k) {
         const int L = h->pcg_L;
         if (h->pcg_fused) {
             CHK(launch_pcg_fused(h, L));
-            // a launch that found the solve finished (or finished it) produced no product: its control block
-            // (written to slot (L+1)&1) says so
-            CHK(exchange(h, h->acc() + (size_t)((L + 1) % 3) * 6 * h->C, 6 * h->C, 0, &ctrl2[(L + 1) & 1].done));
+            // a launch that found the solve finished (or finished it) produced no z: its control block (written
+            // to slot (L+1)&1) says so, and pass B and the collective behind it are void as well
+            const PcgCtrl* cd = ctrl2 + ((L + 1) & 1);
+            CHK(launch_cam_schur<0>(h, h->vecs.as<double>(), h->z.as<double>(), cd, L & 1));
+            CHK(exchange(h, h->acc(), 6 * h->C, 0, &cd->done));
             h->pcg_L = L + 1;
             continue;
         }
-        CHK(launch_schur_sweep<0>(h, h->vecs.as<double>(), nullptr, ctrl2, L));
-        CHK(exchange(h, h->acc() + (size_t)(L & 1) * 6 * h->C, 6 * h->C, 0, &ctrl2[L & 1].done));   // set == L & 1 until done
-        hipLaunchKernelGGL(k_pcg_update, dim3(kPcgUpdateBlocks), dim3(1024), 0, h->stream, h->acc(),
+        const PcgCtrl* cd = ctrl2 + (L & 1);                     // current until k_pcg_update writes the other one
+        CHK(launch_point_sweep(h, h->vecs.as<double>(), ctrl2, L));
+        CHK(launch_cam_schur<0>(h, h->vecs.as<double>(), h->z.as<double>(), cd, -1));
+        CHK(exchange(h, h->acc(), 6 * h->C, 0, &cd->done));
+        hipLaunchKernelGGL(k_pcg_update, dim3(kPcgUpdateBlocks), dim3(1024), 0, h->stream, (const double*)h->acc(),
                            h->Dc.as<double>(), h->Minv.as<double>(), (int)h->C, h->vecs.as<double>(), ctrl2, L);
         HIPCHK(h, hipGetLastError());
         h->pcg_L = L + 1;
@@ -847,6 +873,23 @@ int sfmba_set_stream(sfmba_handle* h, void* hip_stream) {
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     h->stream = static_cast<hipStream_t>(hip_stream);
     h->own_stream = false;
+    return 0;
+}
+
+int sfmba_debug_option(sfmba_handle* h, const char* name, int64_t value) {
+    CHK(enter(h));
+    if (!name) return fail(h, -1, "option name is NULL");
+    const std::string n(name);
+    const int v = (int)value;
+    if (n == "pcg_fused") h->dbg.pcg_fused = v;
+    else if (n == "tab_lds") h->dbg.tab_lds = v;
+    else if (n == "vec_lds") h->dbg.vec_lds = v;
+    else if (n == "cam_chunk") h->dbg.cam_chunk = v;
+    else if (n == "pcg_guess_bias") h->dbg.pcg_guess_bias = v;
+    else if (n == "trace_pcg") h->dbg.trace_pcg = v;
+    else if (n == "trace_stalls") h->dbg.trace_stalls = v;
+    else if (n == "trace_timing") h->dbg.trace_timing = v;
+    else return fail(h, -1, "unknown debug option '%s'", name);
     return 0;
 }
 
@@ -1042,7 +1085,7 @@ int sfmba_set_problem_i64(sfmba_handle* h, int64_t C, int64_t P, int64_t N, cons
 static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, const int64_t* cam, const int64_t* pt,
                             const double* uv, const int64_t* uv_i64, const double* K) {
     CHK(enter(h));
-    const bool timing = std::getenv("SFMBA_DEBUG_TIMING") != nullptr;
+    const bool timing = h->dbg.trace_timing != 0;
     const double tp0 = now_s();
     double tp1 = tp0, tp2 = tp0, tp3 = tp0;
     h->have_problem = false;
@@ -1087,15 +1130,16 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
         std::stable_sort(h->order.begin(), h->order.end(), [&](int64_t a, int64_t b) { return pt[a] < pt[b]; });
     }
     // device-bound arrays are built directly in pinned memory:
-    // [uv 2 ld doubles | cam ld | pt ld | ptr P+1 ints | fp32 storage: uv once more as floats]
+    // [uv 2 ld doubles | cam ld | pt ld | camera-major permutation ld | ptr P+1 ints | fp32 storage: uv once more as floats]
     const size_t ldz = (size_t)h->ld;
     HIPCHK(h, hipStreamSynchronize(h->stream));                  // a previous upload may still read the staging
-    const size_t stage_ints = 2 * ldz + (((size_t)P + 1 + 3) & ~(size_t)3);      // keeps what follows 16-byte aligned
+    const size_t stage_ints = 3 * ldz + (((size_t)P + 1 + 3) & ~(size_t)3);      // keeps what follows 16-byte aligned
     CHK(ensure_stage(h, sizeof(double) * 2 * ldz + sizeof(int) * stage_ints + sizeof(float) * 2 * ldz));
     double* uvs = static_cast<double*>(h->h_stage);
     int* ci = reinterpret_cast<int*>(uvs + 2 * ldz);
     int* pi = ci + ldz;
-    int* ptr = pi + ldz;
+    int* perm = pi + ldz;
+    int* ptr = perm + ldz;
     for (size_t k = (size_t)N; k < ldz; ++k) { ci[k] = 0; pi[k] = 0; uvs[2 * k] = 0.0; uvs[2 * k + 1] = 0.0; }
     const int64_t* ord = sorted ? nullptr : h->order.data();
     parallel_chunks(N, kHostParts, [&](int64_t b, int64_t e, int) {
@@ -1154,26 +1198,52 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
         wsteps[w] = make_int2(first, (int)steps.size() - first);
     }
     h->n_steps = (int)steps.size();
+    // Camera-major order: stable counting sort of the point-major positions by camera (per-part histograms, so
+    // that the parts scatter independently and the order inside a camera stays the point-major one), and the
+    // chunk table of the camera-major kernels: every camera gets at least one chunk (an empty one writes its
+    // zeros), runs longer than chunk_len are cut; one 256-thread workgroup per chunk.
+    std::vector<int4> chunks;
+    std::vector<int> chunk_ptr((size_t)C + 1);
+    {
+        std::vector<int> hist((size_t)kHostParts * (size_t)C, 0);
+        parallel_chunks(N, kHostParts, [&](int64_t b, int64_t e, int t) {
+            int* hcount = hist.data() + (size_t)t * (size_t)C;
+            for (int64_t k = b; k < e; ++k) ++hcount[ci[k]];
+        });
+        std::vector<int> cam_ptr((size_t)C + 1);
+        int run = 0;
+        for (int64_t c = 0; c < C; ++c) {
+            cam_ptr[c] = run;
+            for (int t = 0; t < kHostParts; ++t) { int& v = hist[(size_t)t * (size_t)C + c]; const int n = v; v = run; run += n; }
+        }
+        cam_ptr[C] = run;
+        parallel_chunks(N, kHostParts, [&](int64_t b, int64_t e, int t) {
+            int* off = hist.data() + (size_t)t * (size_t)C;
+            for (int64_t k = b; k < e; ++k) perm[off[ci[k]]++] = (int)k;
+        });
+        for (size_t k = (size_t)N; k < ldz; ++k) perm[k] = 0;
+        int64_t chunk_len = std::max<int64_t>(1024, (N + 2 * h->n_cu - 1) / (2 * h->n_cu));
+        if (h->dbg.cam_chunk > 0) chunk_len = h->dbg.cam_chunk;
+        h->cam_multi = false;
+        for (int64_t c = 0; c < C; ++c) {
+            chunk_ptr[c] = (int)chunks.size();
+            const int b = cam_ptr[c], e = cam_ptr[c + 1];
+            const int nch = std::max<int>(1, (int)((e - b + chunk_len - 1) / chunk_len));
+            if (nch > 1) h->cam_multi = true;
+            for (int j = 0; j < nch; ++j)
+                chunks.push_back(make_int4((int)c, (int)std::min<int64_t>(e, b + j * chunk_len),
+                                           (int)std::min<int64_t>(e, b + (j + 1) * chunk_len), nch));
+        }
+        chunk_ptr[C] = (int)chunks.size();
+        h->n_chunks = (int)chunks.size();
+    }
     tp2 = now_s();
     h->lds_tab = (size_t)C * kCamTab * sizeof(double) <= kLdsDynMax;
-    h->lds_acc = (size_t)C * 12 * sizeof(double) <= kLdsDynMax;
     h->lds_vec = (size_t)C * 6 * sizeof(double) <= kLdsDynMax;
-    h->acc_range = (int)(kLdsDynMax / (6 * sizeof(double)));
-    h->acc_mode = h->lds_acc ? 1 : 2;
-    if (const char* e = std::getenv("SFMBA_ACC_MODE")) {        // test hook: force a placement
-        const int m = std::atoi(e);
-        if (m == 0 || m == 2 || (m == 1 && h->lds_acc)) h->acc_mode = m;
-        if (const char* r = std::getenv("SFMBA_ACC_RANGE")) h->acc_range = std::max(1, std::min(h->acc_range, std::atoi(r)));
-    }
-    h->nb_one_reduce = std::getenv("SFMBA_NB_ONE_REDUCE") && std::atoi(std::getenv("SFMBA_NB_ONE_REDUCE")) != 0;
-    h->pcg_fused = h->acc_mode == 1 && C <= kSweepThreads;
-    if (const char* e = std::getenv("SFMBA_PCG_FUSED")) h->pcg_fused = h->pcg_fused && std::atoi(e) != 0;   // test hook
-    {   // normal-block LDS tables: as many column passes as the 27 columns need (a pass costs ~25 us
-        // per million observations, the global-atomics fallback ~1300 us); atomics only past ~20k cameras
-        const size_t budget = kLdsDynMax;
-        const int max_cols = (int)std::min<size_t>(27, budget / (sizeof(double) * (size_t)C));
-        h->nb_passes = max_cols >= 1 ? (27 + max_cols - 1) / max_cols : 0;
-    }
+    if (h->dbg.tab_lds == 0) h->lds_tab = false;               // test hooks (sfmba_debug_option): force the L2 placements
+    if (h->dbg.vec_lds == 0) h->lds_vec = false;
+    h->pcg_fused = h->lds_vec && C <= kSweepThreads;
+    if (h->dbg.pcg_fused == 0) h->pcg_fused = false;
 
     const size_t ld = (size_t)h->ld;
     HIPCHK(h, h->cam_idx.ensure(sizeof(int) * ld));
@@ -1188,11 +1258,15 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     HIPCHK(h, h->xb.ensure(sizeof(double) * h->n));
     HIPCHK(h, h->tabA.ensure(sizeof(double) * kCamTab * C));
     HIPCHK(h, h->tabB.ensure(sizeof(double) * kCamTab * C));
-    for (int js = 0; js < 2; ++js) {
-        HIPCHK(h, h->r[js].ensure(esz * 2 * ld));
-        HIPCHK(h, h->J[js].ensure(esz * 12 * ld));
-    }
-    h->jcur = 0;
+    HIPCHK(h, h->r.ensure(esz * 2 * ld));
+    HIPCHK(h, h->J.ensure(esz * 12 * ld));
+    HIPCHK(h, h->cm_perm.ensure(sizeof(int) * ld));
+    HIPCHK(h, h->cm_pt.ensure(sizeof(int) * ld));
+    HIPCHK(h, h->cm_uv.ensure(esz * 2 * ld));
+    HIPCHK(h, h->cam_chunks.ensure(sizeof(int4) * chunks.size()));
+    HIPCHK(h, h->cam_chunk_ptr.ensure(sizeof(int) * chunk_ptr.size()));
+    HIPCHK(h, h->cam_partial.ensure(sizeof(double) * 27 * chunks.size()));
+    HIPCHK(h, h->z.ensure(sizeof(double) * 3 * P));
     HIPCHK(h, h->t1.ensure(esz * 2 * ld));
     HIPCHK(h, h->V.ensure(sizeof(double) * 6 * P));
     HIPCHK(h, h->Vinv.ensure(sizeof(double) * 6 * P));
@@ -1211,12 +1285,6 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     h->red_grid = h->red_bc + grid_1d(3 * P, 256, 992);   // <= 1024 partial rows, summed by k_jdot's rider workgroup
     HIPCHK(h, h->part.ensure(sizeof(double) * (size_t)(2 * kPartRows * kNQ)));
     HIPCHK(h, h->ctrl.ensure(2 * sizeof(PcgCtrl)));
-    if (h->nb_passes > 0) {
-        const int per = (27 + h->nb_passes - 1) / h->nb_passes;
-        const size_t nblk = (ranges.size() + kWavesPerSweepBlock - 1) / kWavesPerSweepBlock;
-        HIPCHK(h, h->tables.ensure(sizeof(double) * std::max<size_t>(1, nblk) * (size_t)C * per *
-                                   (size_t)(h->nb_one_reduce ? h->nb_passes : 1)));
-    }
     HIPCHK(h, h->arena_own.ensure(sizeof(double) * (size_t)sfmba_exchange_doubles(C)));
     h->arena = h->arena_own.as<double>();
     h->ar_fn = nullptr; h->ar_ctx = nullptr;
@@ -1243,8 +1311,15 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     HIPCHK(h, hipMemsetAsync(h->V.p, 0, sizeof(double) * 6 * P, h->stream));
     HIPCHK(h, hipMemsetAsync(h->gp.p, 0, sizeof(double) * 3 * P, h->stream));
     HIPCHK(h, hipMemsetAsync(h->p.p, 0, sizeof(double) * h->n, h->stream));      // ... and their step is 0
-    HIPCHK(h, hipMemsetAsync(h->r[0].p, 0, esz * 2 * ld, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->r[1].p, 0, esz * 2 * ld, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->r.p, 0, esz * 2 * ld, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->z.p, 0, sizeof(double) * 3 * P, h->stream));      // points without observations keep z = 0
+    HIPCHK(h, hipMemcpyAsync(h->cm_perm.p, perm, sizeof(int) * ld, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->cam_chunks.p, chunks.data(), sizeof(int4) * chunks.size(), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->cam_chunk_ptr.p, chunk_ptr.data(), sizeof(int) * chunk_ptr.size(), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_build_cam_major, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, h->stream, h->cm_perm.as<int>(),
+                       h->pt_idx.as<int>(), h->uv.as<double>(), h->f32 ? 1 : 0, (int)N, h->cm_pt.as<int>(),
+                       h->cm_uv.as<double>());
+    HIPCHK(h, hipGetLastError());
     tp3 = now_s();
     HIPCHK(h, hipStreamSynchronize(h->stream));     // the staging buffer is reused by the next call
     if (timing)
@@ -1261,7 +1336,7 @@ int sfmba_residuals(sfmba_handle* h, const double* x, double* r_out) {
     CHK(upload_x(h, x));
     CHK(launch_cam_table(h, h->x, h->tab));
     int np = 0;
-    CHK((launch_resjac<false, true>(h, h->x, h->tab, h->jcur, &np)));
+    CHK((launch_resjac<false, true>(h, h->x, h->tab, &np)));
     return download_residuals(h, r_out);
 }
 
@@ -1272,11 +1347,11 @@ int sfmba_residual_jacobian(sfmba_handle* h, const double* x, double* r_out, dou
     CHK(upload_x(h, x));
     CHK(launch_cam_table(h, h->x, h->tab));
     int np = 0;
-    CHK((launch_resjac<true, true>(h, h->x, h->tab, h->jcur, &np)));
+    CHK((launch_resjac<true, true>(h, h->x, h->tab, &np)));
     DevBuf jc_rm, jp_rm;
     HIPCHK(h, jc_rm.ensure(sizeof(double) * 12 * h->N));
     HIPCHK(h, jp_rm.ensure(sizeof(double) * 6 * h->N));
-    hipLaunchKernelGGL(k_unpack_jac, dim3((h->N + 255) / 256), dim3(256), 0, h->stream, h->J[h->jcur].as<double>(),
+    hipLaunchKernelGGL(k_unpack_jac, dim3((h->N + 255) / 256), dim3(256), 0, h->stream, h->J.as<double>(),
                        (int)h->N, h->ld, h->f32 ? 1 : 0, jc_rm.as<double>(), jp_rm.as<double>());
     HIPCHK(h, hipGetLastError());
     std::vector<double> tc(12 * h->N), tp(6 * h->N);
@@ -1298,8 +1373,8 @@ int sfmba_normal_blocks(sfmba_handle* h, const double* x, double* U, double* V, 
     CHK(upload_x(h, x));
     CHK(launch_cam_table(h, h->x, h->tab));
     int np = 0;
-    CHK((launch_resjac<true, true>(h, h->x, h->tab, h->jcur, &np)));
-    CHK(launch_normal_blocks(h));
+    CHK((launch_resjac<true, true>(h, h->x, h->tab, &np)));
+    CHK(launch_normal_blocks(h, h->x, h->tab));
     CHK(exchange(h, h->Ugc(), 27 * h->C, 0));
     std::vector<double> ugc(27 * h->C);
     HIPCHK(h, hipMemcpyAsync(ugc.data(), h->Ugc(), sizeof(double) * 27 * h->C, hipMemcpyDeviceToHost, h->stream));
@@ -1320,8 +1395,8 @@ int sfmba_schur_matvec(sfmba_handle* h, const double* x, const double* dc, const
     CHK(upload_x(h, x));
     CHK(launch_cam_table(h, h->x, h->tab));
     int np = 0;
-    CHK((launch_resjac<true, true>(h, h->x, h->tab, h->jcur, &np)));
-    CHK(launch_normal_blocks(h));
+    CHK((launch_resjac<true, true>(h, h->x, h->tab, &np)));
+    CHK(launch_normal_blocks(h, h->x, h->tab));
     CHK(exchange(h, h->Ugc(), 27 * h->C, 0));
     // stage dp in e (as explicit diagonal), v in pk -- camera vectors are plane-major on the device
     const int64_t C = h->C;
@@ -1334,8 +1409,7 @@ int sfmba_schur_matvec(sfmba_handle* h, const double* x, const double* dc, const
                        h->gp.as<double>(), (const double*)nullptr, h->e.as<double>(), (int)h->P, 0.0,
                        h->Vinv.as<double>(), (double*)nullptr);
     HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipMemsetAsync(h->acc(), 0, sizeof(double) * 6 * C, h->stream));
-    CHK(launch_schur_sweep<0>(h, h->vtmp.as<double>(), nullptr, nullptr, 0));
+    CHK(schur_product_standalone(h, h->vtmp.as<double>()));
     CHK(exchange(h, h->acc(), 6 * C, 0));
     std::vector<double> a(6 * C);
     HIPCHK(h, hipMemcpyAsync(a.data(), h->acc(), sizeof(double) * 6 * C, hipMemcpyDeviceToHost, h->stream));
@@ -1353,53 +1427,49 @@ int sfmba_time_kernel(sfmba_handle* h, const double* x, int32_t which, int32_t r
     CHK(upload_x(h, x));
     CHK(launch_cam_table(h, h->x, h->tab));
     int np = 0;
-    CHK((launch_resjac<true, true>(h, h->x, h->tab, h->jcur, &np)));
+    CHK((launch_resjac<true, true>(h, h->x, h->tab, &np)));
     if (which >= 2) {
-        CHK(launch_normal_blocks(h));
+        CHK(launch_normal_blocks(h, h->x, h->tab));
         CHK(launch_update_scale(h, 1));
         hipLaunchKernelGGL(k_point_prep, dim3((h->P + 255) / 256), dim3(256), 0, h->stream, h->V.as<double>(),
                            h->gp.as<double>(), h->si.as<double>() + 6 * h->C, (const double*)nullptr, (int)h->P,
                            1e-6, h->Vinv.as<double>(), h->e.as<double>());
-        HIPCHK(h, hipMemsetAsync(h->acc(), 0, sizeof(double) * 6 * h->C, h->stream));
-        HIPCHK(h, hipMemcpyAsync(h->vtmp.p, h->g.p, sizeof(double) * 6 * h->C, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipGetLastError());
+        // v = the camera slice of the gradient, as plane-major planes (and camera-major when v is not staged in LDS)
+        hipLaunchKernelGGL(k_transpose, dim3((unsigned)((6 * h->C + 255) / 256)), dim3(256), 0, h->stream,
+                           (const double*)h->g.as<double>(), (int)h->C, 6, h->vtmp.as<double>(), (const PcgCtrl*)nullptr, 0);
+        HIPCHK(h, hipMemcpyAsync(h->vcm.p, h->g.p, sizeof(double) * 6 * h->C, hipMemcpyDeviceToDevice, h->stream));
+        CHK(schur_product_standalone(h, h->vtmp.as<double>()));          // leaves a valid z for case 5
     }
-    hipEvent_t e0, e1;
-    HIPCHK(h, hipEventCreate(&e0));
-    HIPCHK(h, hipEventCreate(&e1));
+    struct EventPair {                    // destroyed on every exit path
+        hipEvent_t a = nullptr, b = nullptr;
+        ~EventPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    } ev;
+    HIPCHK(h, hipEventCreate(&ev.a));
+    HIPCHK(h, hipEventCreate(&ev.b));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipEventRecord(e0, h->stream));
+    HIPCHK(h, hipEventRecord(ev.a, h->stream));
     for (int k = 0; k < reps; ++k) {
         switch (which) {
-            case 0: CHK((launch_resjac<true, true>(h, h->x, h->tab, h->jcur, &np))); break;
-            case 1: CHK((launch_resjac<false, false>(h, h->x, h->tab, h->jcur, &np))); break;
-            case 2: CHK(launch_normal_blocks(h)); break;
-            case 3: CHK(launch_schur_sweep<0>(h, h->vtmp.as<double>(), nullptr, nullptr, 0)); break;
-            case 10:   // streaming-store ceiling: fill the 12 Jc planes, 16 B per lane, one stream
-                hipLaunchKernelGGL(k_fill16, dim3(h->n_cu * 2), dim3(1024), 0, h->stream, h->J[h->jcur].as<double>(),
+            case 0: CHK((launch_resjac<true, true>(h, h->x, h->tab, &np))); break;
+            case 1: CHK((launch_resjac<false, false>(h, h->x, h->tab, &np))); break;
+            case 2: CHK(launch_normal_blocks(h, h->x, h->tab)); break;
+            case 3: CHK(schur_product_standalone(h, h->vtmp.as<double>())); break;
+            case 4: CHK(launch_point_sweep(h, h->lds_vec ? h->vtmp.as<double>() : h->vcm.as<double>(), nullptr, 0)); break;
+            case 5: CHK(launch_cam_schur<0>(h, h->vtmp.as<double>(), h->z.as<double>(), nullptr, 0)); break;
+            case 6: CHK(launch_cam_schur<1>(h, nullptr, h->e.as<double>(), nullptr, 0)); break;
+            case 10:   // streaming-store ceiling: fill the Jacobian planes, 16 B per lane, one stream
+                hipLaunchKernelGGL(k_fill16, dim3(h->n_cu * 2), dim3(1024), 0, h->stream, h->J.as<double>(),
                                    (int64_t)((h->f32 ? 3 : 6) * h->ld), 1.0);
-                break;
-            case 11:   // same bytes, 2048 workgroups
-                hipLaunchKernelGGL(k_fill16, dim3(2048), dim3(1024), 0, h->stream, h->J[h->jcur].as<double>(),
-                                   (int64_t)(6 * h->ld), 1.0);
-                break;
-            case 13:   // cold streaming-store ceiling: 144 MB per rep, alternating buffer sets (288 MB cycle > 256 MiB Infinity Cache)
-                hipLaunchKernelGGL(k_fill16, dim3(2048), dim3(1024), 0, h->stream, h->J[k & 1].as<double>(),
-                                   (int64_t)(6 * h->ld), 1.0);
-                break;
-            case 12:   // alternate between the two Jacobian buffer sets (defeats Infinity-Cache write hits)
-                CHK((launch_resjac<true, true>(h, h->x, h->tab, k & 1, &np)));
                 break;
             default: return fail(h, -1, "unknown kernel id %d", which);
         }
     }
-    HIPCHK(h, hipEventRecord(e1, h->stream));
-    HIPCHK(h, hipEventSynchronize(e1));
+    HIPCHK(h, hipEventRecord(ev.b, h->stream));
+    HIPCHK(h, hipEventSynchronize(ev.b));
     float ms = 0.f;
-    HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    HIPCHK(h, hipEventElapsedTime(&ms, ev.a, ev.b));
     *avg_us = 1e3 * (double)ms / reps;
-    HIPCHK(h, hipMemsetAsync(h->acc(), 0, sizeof(double) * 6 * h->C, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return 0;
 }
@@ -1422,18 +1492,19 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
 
     h->x = h->xa.as<double>(); h->x_new = h->xb.as<double>();
     h->tab = h->tabA.as<double>(); h->tab_new = h->tabB.as<double>();
-    h->jcur = 0;
     CHK(upload_x(h, x_inout));
     const double t_dev0 = now_s();
-    report_stall("upload_x", t_dev0 - t_begin);
+    report_stall(h, "upload_x", t_dev0 - t_begin);
 
     // Host/device hand-offs per outer iteration: ONE read-back after the whole linear phase
     // (Cauchy product, Schur PCG, back-substitution, Gram/dot reductions are enqueued without the
     // host seeing intermediate values: the regularisation term is computed by k_prep on the device
     // and the PCG stops itself through its device-side control block) and ONE per trial step.
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
+    struct EventList : std::vector<std::pair<hipEvent_t, hipEvent_t>> {     // destroyed on every exit path
+        ~EventList() { for (auto& pr : *this) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); } }
+    } evs;
     int np_cost = 0;                                                  // partial rows of the last K1 launch
-    auto eval_jac = [&](const double* x, double* tab, int js, bool table_ready, bool finish = true) -> int {   // K0 + K1, sum r^2 -> scalar 0
+    auto eval_jac = [&](const double* x, double* tab, bool table_ready, bool finish = true) -> int {   // K0 + K1, sum r^2 -> scalar 0
         if (!table_ready) CHK(launch_cam_table(h, x, tab));
         int& np = np_cost;
         if (opt.profile) {
@@ -1442,17 +1513,20 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
             // invalidation when they are recorded, which otherwise lands inside the measured interval (+1.3 us)
             // and delays the launches around the kernel
             HIPCHK(h, hipEventCreateWithFlags(&a, hipEventDisableSystemFence));
-            HIPCHK(h, hipEventCreateWithFlags(&b, hipEventDisableSystemFence));
-            CHK((launch_resjac<true, true>(h, x, tab, js, &np, a, b)));
+            if (hipEventCreateWithFlags(&b, hipEventDisableSystemFence) != hipSuccess) {
+                (void)hipEventDestroy(a);
+                return fail(h, -3, "hipEventCreateWithFlags failed");
+            }
             evs.emplace_back(a, b);
+            CHK((launch_resjac<true, true>(h, x, tab, &np, a, b)));
         } else {
-            CHK((launch_resjac<true, true>(h, x, tab, js, &np)));
+            CHK((launch_resjac<true, true>(h, x, tab, &np)));
         }
         if (finish) CHK(launch_finish(h, h->part.as<double>(), np, 1, 0));
         return 0;
     };
     auto linearise = [&](int first) -> int {      // normal blocks, scale, gradient, q0..q4 at h->x
-        CHK(launch_normal_blocks(h));
+        CHK(launch_normal_blocks(h, h->x, h->tab));
         CHK(exchange(h, h->Ugc(), 27 * C, 0));
         CHK(launch_update_scale(h, first));
         CHK(exchange_linearise(h));
@@ -1460,7 +1534,7 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
     };
 
     // f0, J0 (least_squares.py:838, 903-912)
-    CHK(eval_jac(h->x, h->tab, h->jcur, false));
+    CHK(eval_jac(h->x, h->tab, false));
     CHK(exchange(h, sc, 1, 0));                      // sum r^2
     CHK(linearise(1));
     CHK(fetch_scalars(h));
@@ -1481,14 +1555,14 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
     // this iteration have just read, so K1's stores land on lines that are still resident in the
     // Infinity Cache instead of cold ones.  A rejected step leaves J / r describing the rejected point;
     // nothing uses them before the next trial overwrites them, except the rare exits handled below.
-    const bool pcg_debug = std::getenv("SFMBA_DEBUG_PCG") != nullptr;
-    const int pcg_bias = std::getenv("SFMBA_PCG_GUESS_BIAS") ? std::atoi(std::getenv("SFMBA_PCG_GUESS_BIAS")) : 0;   // test hook
+    const bool pcg_debug = h->dbg.trace_pcg != 0;
+    const int pcg_bias = h->dbg.pcg_guess_bias;                 // test hook (sfmba_debug_option)
     if (opt.verbose >= 2) print_header();
 
     for (;;) {                                                  // trf.py:450
         if (!nb_valid) {                                        // a rejected trial overwrote the blocks and no
-            CHK(eval_jac(h->x, h->tab, h->jcur, true));         // step was accepted afterwards
-            CHK(launch_normal_blocks(h));                       // (nfev limit)
+            CHK(eval_jac(h->x, h->tab, true));         // step was accepted afterwards
+            CHK(launch_normal_blocks(h, h->x, h->tab));                       // (nfev limit)
             CHK(exchange(h, h->Ugc(), 27 * C, 0));
             nb_valid = true;
         }
@@ -1522,11 +1596,11 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
             const int bc = (int)((C + 63) / 64), bp = (int)((P + 63) / 64);
             hipLaunchKernelGGL(k_prep, dim3(bc + bp), dim3(64), 0, h->stream, sc, Delta, opt.reg_min, h->Ugc(),
                                h->V.as<double>(), h->gp.as<double>(), h->si.as<double>(), (int)C, (int)P, bc,
-                               h->Dc.as<double>(), h->Minv.as<double>(), h->acc(), h->Vinv.as<double>(),
+                               h->Dc.as<double>(), h->Minv.as<double>(), h->Vinv.as<double>(),
                                h->e.as<double>(), one_rank ? (const double*)h->partB() : (const double*)nullptr, np);
             HIPCHK(h, hipGetLastError());
         }
-        CHK(launch_schur_sweep<1>(h, nullptr, h->e.as<double>(), nullptr, 0));   // reduced rhs -> acc0
+        CHK(launch_cam_schur<1>(h, nullptr, h->e.as<double>(), nullptr, 0));      // reduced rhs term -> acc
         CHK(exchange(h, h->acc(), 6 * C, 0));
         CHK(pcg_start(h, opt));                                 // replaces lsmr, trf.py:477-480
         PcgCtrl hc{};
@@ -1572,7 +1646,7 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
             if (ranks && h->p2p.ready) {
                 // direct path: ONE single-workgroup launch sums K1's cost partials, reduces the cost over the
                 // ranks and posts the hand-off (or only posts, when k_tr_step cancelled the trial)
-                CHK(eval_jac(h->x_new, h->tab_new, h->jcur, true, /*finish=*/false));
+                CHK(eval_jac(h->x_new, h->tab_new, true, /*finish=*/false));
                 Piggyback pb{h->part.as<double>(), sc, FinishJob{}, 1, 1, 0};
                 pb.job.row0[0] = 0; pb.job.nrows[0] = np_cost;
                 for (int k = 0; k < kNQ; ++k) { pb.job.slot[0][k] = k; pb.job.slot[1][k] = -1; }
@@ -1581,7 +1655,7 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
                 return 0;
             }
             if (!ranks) h->post = mb;
-            const int rc = eval_jac(h->x_new, h->tab_new, h->jcur, true);
+            const int rc = eval_jac(h->x_new, h->tab_new, true);
             h->post = Mailbox{};
             CHK(rc);
             CHK(exchange(h, sc, 1, 0));
@@ -1596,7 +1670,7 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
             // (speculating on acceptance, the common case).  They overwrite V / g_p / [U|g_c], which a
             // rejected step does not need: a retry only re-solves the 2-D model (host scalars) and
             // re-applies k_step_table to x, D^2 g and p, all untouched.
-            CHK(launch_normal_blocks(h));
+            CHK(launch_normal_blocks(h, h->x_new, h->tab_new));
             CHK(exchange(h, h->Ugc(), 27 * C, 0));
             nb_valid = false;
             CHK(wait_mailbox(h, h->mbox_seq));
@@ -1604,21 +1678,24 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
             if (with_ctrl) memcpy(&hc, h->mbox + kMboxCtrl, sizeof hc);
             return 0;
         };
-        const bool speculative = pcg_guess > 0;
-        hipLaunchKernelGGL(k_tr_step, dim3(1), dim3(one_rank ? 1024 : 64), 0, h->stream, sc, Delta,
-                           speculative ? (const PcgCtrl*)(h->ctrl.as<PcgCtrl>() + (h->pcg_L & 1)) : (const PcgCtrl*)nullptr,
-                           one_rank ? backsub_rider(h, np_tail) : Piggyback{});
-        HIPCHK(h, hipGetLastError());
-        h->skip = sc + 30;                                      // k_tr_step's verdict gates every launch below
-        int rc_trial = enqueue_trial(sc + 25, 0.0, 0.0);
-        if (rc_trial == 0) rc_trial = handoff(speculative);     // THE hand-off of this iteration
-        h->skip = nullptr;
-        CHK(rc_trial);
-        bool first_trial_ready = true;
-        if (speculative && hc.done == 0) {
+        const bool speculated = pcg_guess > 0;
+        bool missed = false;
+        for (bool speculative = speculated;;) {
+            hipLaunchKernelGGL(k_tr_step, dim3(1), dim3(one_rank ? 1024 : 64), 0, h->stream, sc, Delta,
+                               speculative ? (const PcgCtrl*)(h->ctrl.as<PcgCtrl>() + (h->pcg_L & 1)) : (const PcgCtrl*)nullptr,
+                               one_rank ? backsub_rider(h, np_tail) : Piggyback{});
+            HIPCHK(h, hipGetLastError());
+            h->skip = sc + 30;                                  // k_tr_step's verdict gates every launch below
+            int rc_trial = enqueue_trial(sc + 25, 0.0, 0.0);
+            if (rc_trial == 0) rc_trial = handoff(speculative); // THE hand-off of this iteration
+            h->skip = nullptr;
+            CHK(rc_trial);
+            if (!(speculative && hc.done == 0)) break;
             // The PCG needed more iterations than were enqueued.  k_tr_step saw that on the device and
             // cancelled the trial launches, so J, r and the normal blocks still describe x: finish the
-            // PCG (host-polled), redo the tail and take the host-driven path below.
+            // PCG (host-polled), redo the tail and decide the step on the device again -- the arithmetic of
+            // an iteration does not depend on whether its guess sufficed.
+            missed = true;
             nb_valid = true;
             if (opt.profile && !evs.empty()) {                  // the cancelled launch is not a K1 timing sample
                 (void)hipEventDestroy(evs.back().first);
@@ -1626,10 +1703,10 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
                 evs.pop_back();
             }
             CHK(pcg_finish_polling(h, opt, &hc));
-            CHK(tail(false));
-            CHK(fetch_scalars(h));
-            first_trial_ready = false;
+            CHK(tail(true));
+            speculative = false;
         }
+        bool first_trial_ready = true;
         // hc.done == 3: the CG recurrences lost positive definiteness (rounding, typically on a converged
         // system whose right-hand side is noise).  The iterate of the last good step is kept -- it is
         // zero when the very first step failed, in which case the 2-D model below degenerates to the
@@ -1644,7 +1721,7 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
         pcg_total += hc.iters;
         if (pcg_debug)
             fprintf(stderr, "sfmba: iteration %lld: PCG enqueued %d, needed %d%s\n", (long long)iteration,
-                    speculative ? pcg_guess + (h->pcg_fused ? 2 : 1) : 0, hc.iters, speculative && !first_trial_ready ? " (miss)" : "");
+                    speculated ? pcg_guess + (h->pcg_fused ? 2 : 1) : 0, hc.iters, missed ? " (miss)" : "");
         // Next guess: the largest recent count, forgotten by one iteration per outer iteration.  A surplus
         // iteration costs two empty launches (~10 us); a miss costs a hand-off per polled batch.
         h->pcg_hint = std::max(hc.iters, h->pcg_hint - 1);
@@ -1712,7 +1789,7 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
     if (status == -1) status = 0;
     if (!nb_valid) {                                            // last trial was not accepted: result.fun is f(x)
         int np = 0;
-        CHK((launch_resjac<false, true>(h, h->x, h->tab, h->jcur, &np)));
+        CHK((launch_resjac<false, true>(h, h->x, h->tab, &np)));
     }
 
     CHK(ensure_h_x(h));
@@ -1732,8 +1809,6 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
         for (auto& pr : evs) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) tot += ms;
-            (void)hipEventDestroy(pr.first);
-            (void)hipEventDestroy(pr.second);
         }
         out->resjac_avg_us = 1e3 * tot / (double)evs.size();
         out->resjac_launches = (int64_t)evs.size();

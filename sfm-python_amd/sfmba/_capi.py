@@ -19,7 +19,7 @@ SYMBOLS = (
     "sfmba_residual_jacobian", "sfmba_solve", "sfmba_get_fun_grad", "sfmba_time_kernel",
     "sfmba_normal_blocks", "sfmba_schur_matvec", "sfmba_comm_get_unique_id", "sfmba_comm_init",
     "sfmba_comm_destroy", "sfmba_set_precision", "sfmba_p2p_export", "sfmba_p2p_attach", "sfmba_p2p_detach",
-    "sfmba_p2p_calls",
+    "sfmba_p2p_calls", "sfmba_tr2d_solve", "sfmba_debug_option",
 )
 
 
@@ -84,13 +84,14 @@ def load():
     lib.sfmba_p2p_export.argtypes = [P, C.c_int32, P]
     lib.sfmba_p2p_attach.argtypes = [P, P, C.c_int32, C.c_int32]
     lib.sfmba_p2p_detach.argtypes = [P]
+    lib.sfmba_debug_option.argtypes = [P, C.c_char_p, C.c_int64]
     lib.sfmba_p2p_calls.argtypes = [P]
     lib.sfmba_p2p_calls.restype = C.c_int64
     for name in ("sfmba_set_stream", "sfmba_set_problem", "sfmba_set_problem_i64", "sfmba_set_exchange", "sfmba_residuals",
                  "sfmba_residual_jacobian", "sfmba_solve", "sfmba_get_fun_grad", "sfmba_time_kernel",
                  "sfmba_normal_blocks", "sfmba_schur_matvec", "sfmba_tr2d_solve", "sfmba_comm_get_unique_id",
                  "sfmba_comm_init", "sfmba_comm_destroy", "sfmba_set_precision", "sfmba_p2p_export",
-                 "sfmba_p2p_attach", "sfmba_p2p_detach"):
+                 "sfmba_p2p_attach", "sfmba_p2p_detach", "sfmba_debug_option"):
         getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib

@@ -62,6 +62,10 @@ class Backend:
         next set_problem."""
         self._check(self._lib.sfmba_set_precision(self._h, int(storage_bits)))
 
+    def debug_option(self, name: str, value: int):
+        """Test / diagnostic hook (include/sfmba.h: sfmba_debug_option)."""
+        self._check(self._lib.sfmba_debug_option(self._h, name.encode(), int(value)))
+
     def set_stream(self, hip_stream: int):
         self._check(self._lib.sfmba_set_stream(self._h, C.c_void_p(int(hip_stream))))
 
