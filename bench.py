@@ -12,10 +12,12 @@ capped so that exactly K iterations fall in the timed region.  Problem arrays ar
 before the clock starts; only x0 (6C+3P doubles) crosses PCIe per solve.
 
 N = 1: the 1000-camera / 100k-point / 1M-observation synthetic (BASELINE.json: the problem the >=100x
-target is quoted on).  N > 1: weak scaling -- every rank owns a shard of that size (its own 100k points
-and 1M observations), all shards share the 1000 cameras, and the camera-side normal-equation blocks,
-reduced right-hand side and PCG products are all-reduced over RCCL; `value` counts shard-iterations
-summed over ranks per second (= iterations/s at N = 1).
+target is quoted on).  N > 1, default `--scaling strong` (BASELINE.json configs[3], north_star ">= 6x at 8 GPUs"):
+the SAME 1M-observation problem, observations cut at point boundaries into N shards (sfmba.dist.partition_points
+/ shard_problem), cameras replicated, camera-side normal-equation blocks, reduced right-hand side and PCG
+products all-reduced; `value` = outer iterations of the whole problem per second, comparable with the N = 1
+number.  `--scaling weak`: every rank owns its own cfg-sized shard that shares the cameras; `value` then counts
+shard-iterations summed over ranks (a different unit, labelled as such).
 """
 from __future__ import annotations
 
@@ -85,6 +87,32 @@ def cpu_baseline(workload_dims, seconds_budget=25.0):
                 detail=out)
 
 
+def per_call_times(workload, storage_bits):
+    """What a user of the drop-in sees: wall time of ONE sfmba.least_squares(...) call with the reference's
+    kwargs (sfm.py:266-268) -- argument conversion, set_problem (structure tables + upload), solve, download of
+    x / fun / grad -- for the bench workload and for the SceauxCastle-scale problem the reference itself
+    produces.  `cold`: first call on a fresh handle (allocations, code-object load); `warm`: median of the
+    following calls with the same arrays (every call still rebuilds and re-uploads the problem, as the
+    reference does once per fused edge, sfm.py:59-71)."""
+    import sfmba
+    out = {}
+    for name in dict.fromkeys([workload, "cfg2"]):
+        pb = sfmba.make_config(name)
+        be = sfmba.Backend(0)
+        times = []
+        for k in range(6):
+            t = time.perf_counter()
+            res = sfmba.least_squares(sfmba.compute_residuals, pb.x0, jac_sparsity=None, verbose=0, x_scale="jac",
+                                      ftol=1e-10, method="trf", args=pb.args, storage_bits=storage_bits, backend=be)
+            times.append(1e3 * (time.perf_counter() - t))
+        warm = sorted(times[1:])[len(times[1:]) // 2]
+        out[name] = {"cold": round(times[0], 3), "warm": round(warm, 3), "iterations": int(res.iterations),
+                     "solve_only": round(1e3 * float(res.seconds), 3),
+                     "iterations_per_s_per_call": round(res.iterations / (1e-3 * warm), 1)}
+        be.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -104,6 +132,10 @@ def main():
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--exchange", default="native", choices=["native", "torch"],
                     help="native: RCCL called from C++ on the solver stream; torch: torch.distributed callback")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1 only.  strong (default): one problem of the workload's size sharded over the ranks; "
+                         "weak: one workload-sized shard per rank")
+    ap.add_argument("--no-per-call", action="store_true", help="skip the end-to-end least_squares() call timings")
     ap.add_argument("--no-direct", action="store_true",
                     help="do not map the peers' staging buffers: every collective goes through --exchange "
                          "(default: the direct xGMI all-reduce kernel serves them, --exchange is the fallback)")
@@ -135,10 +167,20 @@ def main():
             td.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             td.init_process_group(backend="gloo")
-        pb = sdist.make_sharded_problem(C, P, N, rank, world, seed=0) if world > 1 else sfmba.make_problem(C, P, N, seed=0)
+        if world > 1 and a.scaling == "weak":
+            pb = sdist.make_sharded_problem(C, P, N, rank, world, seed=0)
+        elif world > 1:                    # strong: every rank builds the same problem and keeps its shard of it
+            full = sfmba.make_problem(C, P, N, seed=0)
+            shard = sdist.partition_points(full.point_indices, full.n_points, world)[rank]
+            pb = sdist.shard_problem(full, shard)
+            del full
+        else:
+            pb = sfmba.make_problem(C, P, N, seed=0)
     else:
         td = None
         pb = sfmba.make_problem(C, P, N, seed=0)
+    scaling = a.scaling if world > 1 else "strong"          # at N = 1 the two coincide
+    Cl, Pl, Nl = pb.n_cameras, pb.n_points, pb.n_obs          # this rank's share
 
     with torch.cuda.stream(stream):
         be.set_stream(stream.cuda_stream)
@@ -148,13 +190,13 @@ def main():
         if td is not None:
             if a.exchange == "native":
                 try:
-                    ex = sdist.NativeComm(be, n_obs_local=N)
+                    ex = sdist.NativeComm(be, n_obs_local=Nl)
                 except Exception as exc:                      # noqa: BLE001 -- e.g. librccl not loadable
                     print(f"[bench] native RCCL transport unavailable ({exc}); using the torch.distributed "
                           f"callback transport", file=sys.stderr, flush=True)
                     a.exchange = "torch"
             if a.exchange == "torch":
-                ex = sdist.Exchange(be, n_obs_local=N, device="cuda")
+                ex = sdist.Exchange(be, n_obs_local=Nl, device="cuda")
             link = None
             if world > 1 and not a.no_direct:
                 try:
@@ -208,10 +250,12 @@ def main():
                 run_iterations(5)
         run_iterations(max(1, a.warmup))
         barrier()
+        n_launch0, n_coll0 = be.counters()
         t0 = time.perf_counter()
         results = run_iterations(a.steps)
         barrier()
         elapsed = time.perf_counter() - t0
+        n_launch1, n_coll1 = be.counters()
 
     if td is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -222,30 +266,37 @@ def main():
         steps = sum(r[0] for r in results)
         k1_us = sum(r[3] * r[4] for r in results) / max(1, sum(r[4] for r in results))
         kb = k1_bytes_f32 if a.storage_bits == 32 else k1_bytes
-        achieved = kb(C, P, N) / (k1_us * 1e-6) / 1e9 if k1_us > 0 else None
+        achieved = kb(Cl, Pl, Nl) / (k1_us * 1e-6) / 1e9 if k1_us > 0 else None
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "k1_traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and world == 1:
             tj = json.load(open(tpath))
             if str(tj.get("workload", "")).split()[0] == a.workload and a.storage_bits == 64:
                 traffic = tj.get("hbm_bytes_per_launch")
         full = [r for r in results if r[6] != 0] or results
+        strong = scaling == "strong"
+        n_total, p_total = (N, P) if strong else (N * world, P * world)
         line = {
             "metric": "BA iterations/sec",
-            "value": steps * world / elapsed,
-            "unit": "iterations/s (per 1M-observation shard, summed over GPUs)" if a.workload == "cfg4"
-                    else "iterations/s (per shard, summed over GPUs)",
+            # strong: iterations of the ONE problem per second; weak: shard-iterations summed over the ranks
+            "value": steps / elapsed if strong else steps * world / elapsed,
+            "unit": "iterations/s" if strong else "shard-iterations/s (one workload-sized shard per GPU, summed over GPUs)",
             "n_gpus": world, "steps": steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * elapsed / steps,
             "settle_s": a.settle,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f64" if a.storage_bits == 64 else "f64 arithmetic, f32 storage", "data": "synthetic",
             "transport": None if td is None else (f"direct xGMI all-reduce kernel ({be.p2p_calls()} collectives; "
                                                   f"fallback {a.exchange})" if be.p2p_calls() > 0 else a.exchange),
-            "config": {"workload": f"{a.workload}: {C} cameras / {P} points / {N} observations per GPU shard, "
-                                   f"shared cameras, seed 0 (SURVEY.md 8d generator)",
+            "launches_per_iteration": round((n_launch1 - n_launch0) / steps, 1),
+            "collectives_per_iteration": round((n_coll1 - n_coll0) / steps, 1),
+            "config": {"workload": (f"{a.workload}: {C} cameras / {P} points / {N} observations, seed 0 (SURVEY.md 8d "
+                                    f"generator)" + ("" if world == 1 else
+                                                     f", observations sharded at point boundaries over {world} GPUs"
+                                                     if strong else f" PER GPU shard, shared cameras")),
                        "solver": "TRF (scipy trf_no_bounds restated) + analytic Jacobian + Schur PCG, ftol=1e-10",
-                       "n_obs_total": N * world, "n_points_total": P * world, "n_cameras": C,
+                       "n_obs_total": n_total, "n_points_total": p_total, "n_cameras": C,
+                       "n_obs_rank0": Nl, "n_points_rank0": Pl,
                        "solves_in_timed_region": len(results),
                        "iterations_per_solve": [r[0] for r in results],
                        "pcg_iterations_per_solve": [r[5] for r in results],
@@ -259,13 +310,15 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                          "traffic": traffic, "avg_launch_us": k1_us,
-                         "algorithmic_bytes_per_launch": kb(C, P, N),
-                         "note": "bytes = 136 N + 24 P + 48 C: the 2x3 block d r/d T = -d r/d X is not stored; "
-                                 "SURVEY 8d's 184 N figure writes it a second time",
-                         "achieved_if_counted_as_survey_184B": (k1_bytes_survey(C, P, N) / (k1_us * 1e-6) / 1e9)
+                         "algorithmic_bytes_per_launch": kb(Cl, Pl, Nl),
+                         "note": "bytes = 136 N + 24 P + 48 C of the rank's shard: the 2x3 block d r/d T = -d r/d X is "
+                                 "not stored; SURVEY 8d's 184 N figure writes it a second time",
+                         "achieved_if_counted_as_survey_184B": (k1_bytes_survey(Cl, Pl, Nl) / (k1_us * 1e-6) / 1e9)
                                                                 if k1_us > 0 else None,
                          "launches_timed": sum(r[4] for r in results)},
         }
+        if world == 1 and not a.no_per_call:
+            line["per_call_ms"] = per_call_times(a.workload, a.storage_bits)
         if not a.no_cpu_baseline and world == 1:     # the CPU baseline is timed on rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline((C, P, N))
             line["speedup_vs_cpu_baseline"] = (steps / elapsed) / line["cpu_baseline"]["value"]

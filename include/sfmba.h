@@ -82,11 +82,18 @@ typedef struct sfmba_result {
  * ranks on the handle's stream; op 0 = sum, 1 = max.  Return 0 on success. */
 typedef int (*sfmba_allreduce_fn)(void* ctx, void* dev_ptr, int64_t count, int32_t op);
 
+/* Sink for the lines of the verbose = 2 iteration table (scipy prints it through Python's sys.stdout,
+ * SCIPY/optimize/_lsq/common.py:545-563; the host shim registers a callback that does the same, so that
+ * redirect_stdout / notebook capture see the table in order with the summary).  `line` has no trailing newline and
+ * is valid during the call only.  fn = NULL: the C library's stdout. */
+typedef void (*sfmba_print_fn)(void* ctx, const char* line);
+
 /* ---- lifetime ---------------------------------------------------------------------------- */
 int  sfmba_create(sfmba_handle** out, int device_id);
 void sfmba_destroy(sfmba_handle* h);
 const char* sfmba_last_error(const sfmba_handle* h);     /* valid until the next call on h */
 void sfmba_default_options(sfmba_options* opt);
+int  sfmba_set_print(sfmba_handle* h, sfmba_print_fn fn, void* ctx);
 /* Run every kernel of `h` on this hipStream_t (default: a stream the handle owns). */
 int  sfmba_set_stream(sfmba_handle* h, void* hip_stream);
 
@@ -100,7 +107,9 @@ int  sfmba_set_precision(sfmba_handle* h, int32_t storage_bits);
  * reference's int64 pixels, bundle_adjustment.py:41 promotes them the same way); K: 3x3 row-major.
  * Indices are range-checked here (the reference's fancy indexing would raise IndexError,
  * bundle_adjustment.py:40).  Any observation order is accepted; point-major (what
- * Graph.pt3ds_pt2ds produces, graph.py:186-191) is the fast path. */
+ * Graph.pt3ds_pt2ds produces, graph.py:186-191) is the fast path.
+ * A new problem returns the handle to single-process operation: a registered exchange callback, RCCL
+ * communicator or direct link is dropped and has to be set up again after this call. */
 int  sfmba_set_problem(sfmba_handle* h, int64_t n_cameras, int64_t n_points, int64_t n_obs,
                        const int64_t* camera_indices, const int64_t* point_indices,
                        const double* points_2d, const double* K);
@@ -143,6 +152,9 @@ int  sfmba_p2p_export(sfmba_handle* h, int32_t world, void* handle64_out);
 int  sfmba_p2p_attach(sfmba_handle* h, const void* handles_world_x_64, int32_t rank, int32_t world);
 int  sfmba_p2p_detach(sfmba_handle* h);
 int64_t sfmba_p2p_calls(const sfmba_handle* h);      /* collectives served by the direct path so far */
+/* Running totals since sfmba_create: kernel launches enqueued by the library and collectives performed (any
+ * transport).  Differences around a solve give launches / collectives per outer iteration (bench.py). */
+int  sfmba_get_counters(const sfmba_handle* h, int64_t* kernel_launches, int64_t* collectives);
 
 /* ---- compute_residuals (bundle_adjustment.py:35-42) ----------------------------------------- */
 /* x: (6C+3P) float64 -> r_out: (2N) float64, interleaved x,y in the caller's observation order. */

@@ -241,7 +241,15 @@ __device__ __forceinline__ void store_pair(double* __restrict__ base, int f32, i
 // bundle_adjustment.py:25, which the reference rebuilds per OBSERVATION), and the coefficients of the
 // right Jacobian Jr = I - b [w]x + c [w]x^2 used by d r / d w.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void cam_table_row(const double* __restrict__ prm, double* __restrict__ t) {
+// The table buffer holds three views of the same data: rows [C][17] (K1, K2, the camera-major passes), the
+// compact [C][12] = R | T that the recomputing Schur pass stages in LDS, and w, b, c plane-major [5][C] for its
+// one-thread-per-camera prologue.
+constexpr int kCamRT = 12, kCamWbc = 5;
+__host__ __device__ constexpr size_t cam_rt_offset(int C) { return ((size_t)C * kCamTab + 1) & ~(size_t)1; }   // 16-byte aligned
+__host__ __device__ constexpr size_t cam_wbc_offset(int C) { return cam_rt_offset(C) + (size_t)C * kCamRT; }
+__host__ __device__ constexpr size_t cam_table_doubles(int C) { return cam_wbc_offset(C) + (size_t)C * kCamWbc; }
+__device__ __forceinline__ void cam_table_row(const double* __restrict__ prm, double* __restrict__ tab, int C, int c) {
+    double* __restrict__ t = tab + (size_t)c * kCamTab;
     const double wx = prm[0], wy = prm[1], wz = prm[2];
     const double th2 = wx * wx + wy * wy + wz * wz;
     const double th = sqrt(th2);
@@ -267,6 +275,12 @@ __device__ __forceinline__ void cam_table_row(const double* __restrict__ prm, do
     t[9] = prm[3]; t[10] = prm[4]; t[11] = prm[5];
     t[12] = wx; t[13] = wy; t[14] = wz;
     t[15] = b; t[16] = cc;
+    double* __restrict__ rt = tab + cam_rt_offset(C) + (size_t)c * kCamRT;
+#pragma unroll
+    for (int k = 0; k < kCamRT; ++k) rt[k] = t[k];
+    double* __restrict__ wbc = tab + cam_wbc_offset(C);
+#pragma unroll
+    for (int k = 0; k < kCamWbc; ++k) wbc[(size_t)k * C + c] = t[12 + k];
 }
 
 __global__ void k_cam_table(const double* __restrict__ xc, int C, double* __restrict__ tab) {
@@ -275,7 +289,7 @@ __global__ void k_cam_table(const double* __restrict__ xc, int C, double* __rest
     double prm[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) prm[k] = xc[6 * (size_t)c + k];
-    cam_table_row(prm, tab + (size_t)c * kCamTab);
+    cam_table_row(prm, tab, C, c);
 }
 
 // The first trust-region step of an outer iteration, decided on the device so that the host does not
@@ -323,7 +337,7 @@ __global__ __launch_bounds__(256) void k_step_table(const double* __restrict__ x
             prm[k] = x[e] + c1 * sg[e] + c2 * p[e];
             x_new[e] = prm[k];
         }
-        cam_table_row(prm, tab + (size_t)c * kCamTab);
+        cam_table_row(prm, tab, C, c);
         return;
     }
     const int64_t n6 = 6 * (int64_t)C;
@@ -544,6 +558,7 @@ struct CamMajor {
 };
 constexpr int kCamThreads = 256;
 constexpr int kCamWaves = kCamThreads / 64;
+constexpr int kCamUnroll = 4;
 
 // sums of one workgroup: NV values per lane -> out[col] (thread col < NV holds the total afterwards)
 template <int NV>
@@ -581,26 +596,37 @@ __global__ __launch_bounds__(kCamThreads) void k_cam_blocks(CamMajor cm, const d
     double a[27];
 #pragma unroll
     for (int q = 0; q < 27; ++q) a[q] = 0.0;
-    int k = ch.y + (int)threadIdx.x;
-    int p = 0;
-    double2 uv = make_double2(0.0, 0.0);
-    if (k < ch.z) { p = cm.pt[k]; uv = load_pair(cm.uv, F32, k); }
-    while (k < ch.z) {
-        const int kn = k + kCamThreads;
-        int pn = 0;
-        double2 uvn = make_double2(0.0, 0.0);
-        if (kn < ch.z) { pn = cm.pt[kn]; uvn = load_pair(cm.uv, F32, kn); }       // next index while this point is gathered
-        const double* __restrict__ Xp = pts + 3 * (size_t)p;
-        double jc[12], jp[6], rx, ry;
-        observe<true>(t, Xp[0], Xp[1], Xp[2], uv.x, uv.y, K, rx, ry, jc, jp);
-        int n = 0;
+    // kCamUnroll observations per lane and trip, all index loads first, then all gathers: a camera of ~1000
+    // observations is one trip, whose latency is one index round trip plus one gather round trip
+    for (int k0 = ch.y + (int)threadIdx.x; k0 < ch.z; k0 += kCamThreads * kCamUnroll) {
+        int p[kCamUnroll];
+        double2 uv[kCamUnroll];
+        double X[kCamUnroll][3];
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
+        for (int u = 0; u < kCamUnroll; ++u) {
+            const int k = k0 + u * kCamThreads;
+            p[u] = -1;
+            uv[u] = make_double2(0.0, 0.0);
+            if (k < ch.z) { p[u] = cm.pt[k]; uv[u] = load_pair(cm.uv, F32, k); }
+        }
 #pragma unroll
-            for (int j = i; j < 6; ++j) a[n++] += jc[i] * jc[j] + jc[6 + i] * jc[6 + j];
+        for (int u = 0; u < kCamUnroll; ++u) {
+            const double* __restrict__ Xp = pts + 3 * (size_t)(p[u] < 0 ? 0 : p[u]);
+            X[u][0] = Xp[0]; X[u][1] = Xp[1]; X[u][2] = Xp[2];
+        }
 #pragma unroll
-        for (int i = 0; i < 6; ++i) a[21 + i] += jc[i] * rx + jc[6 + i] * ry;
-        k = kn; p = pn; uv = uvn;
+        for (int u = 0; u < kCamUnroll; ++u) {
+            if (p[u] < 0) continue;
+            double jc[12], jp[6], rx, ry;
+            observe<true>(t, X[u][0], X[u][1], X[u][2], uv[u].x, uv[u].y, K, rx, ry, jc, jp);
+            int n = 0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = i; j < 6; ++j) a[n++] += jc[i] * jc[j] + jc[6 + i] * jc[6 + j];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) a[21 + i] += jc[i] * rx + jc[6 + i] * ry;
+        }
     }
     const double s = cam_block_total<27>(a, red);
     if (threadIdx.x < 27) {
@@ -823,14 +849,15 @@ __global__ __launch_bounds__(256) void k_update_scale(const double* __restrict__
 // control block into coherent host memory and raises a sequence number behind them; the host polls
 // that word instead of waiting on an event behind two blit copies.  mbox = [0..31] scalars,
 // [32..] control block, [63] sequence number.
-constexpr int kMboxCtrl = 32, kMboxSeq = 63;
+constexpr int kMboxCtrl = 32, kMboxErr = 62, kMboxSeq = 63;
 struct Mailbox {
     double* __restrict__ host;            // device-visible address of the pinned block; null: no post
     const double* __restrict__ sc;
     const PcgCtrl* __restrict__ ctrl;
     unsigned long long seq;
-};
-static_assert(kMboxCtrl + (int)((sizeof(PcgCtrl) + 7) / 8) <= kMboxSeq, "mailbox layout");
+    const unsigned* __restrict__ err;     // error word of the direct all-reduce (null: none): travels with every post,
+};                                        // so that a collective that timed out aborts the solve at the next hand-off
+static_assert(kMboxCtrl + (int)((sizeof(PcgCtrl) + 7) / 8) <= kMboxErr, "mailbox layout");
 
 __device__ __forceinline__ void post_mailbox(const Mailbox& mb) {     // one full wave
     const int lane = threadIdx.x & 63;
@@ -838,6 +865,7 @@ __device__ __forceinline__ void post_mailbox(const Mailbox& mb) {     // one ful
     constexpr int nc = (int)((sizeof(PcgCtrl) + 7) / 8);
     if (mb.ctrl != nullptr && lane >= kMboxCtrl && lane < kMboxCtrl + nc)
         mb.host[lane] = reinterpret_cast<const double*>(mb.ctrl)[lane - kMboxCtrl];
+    if (lane == kMboxErr) mb.host[lane] = (mb.err != nullptr && *mb.err != 0u) ? 1.0 : 0.0;
     __threadfence_system();
     if (lane == 0)
         __hip_atomic_store(reinterpret_cast<unsigned long long*>(mb.host + kMboxSeq), mb.seq, __ATOMIC_RELEASE,
@@ -1121,6 +1149,138 @@ struct PcgFused {
     int max_iters;
 };
 
+// The PCG update in the prologue of a fused pass-A launch (see PcgFused): returns false when the launch has
+// nothing more to do (the solve had finished or finishes here; grid-uniform).  Otherwise uu = the new u of
+// camera threadIdx.x (zeros for threads without a camera), which the caller puts into its LDS table.
+__device__ __forceinline__ bool pcg_fused_update(const PcgFused& pf, const double* __restrict__ acc, int C, int L,
+                                                 double (&uu)[6]) {
+    __shared__ double red_a[16];
+    __shared__ double red_b[16];
+    const int n6 = 6 * C;
+    // Until the solve finishes, launch L >= 1 sees iters == L - 1, so every address below follows from
+    // L alone and all vector loads of the prologue are in flight together.
+    PcgCtrl* __restrict__ cout = pf.ctrl2 + ((L + 1) & 1);
+    const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
+    const int cam = threadIdx.x;
+    const bool has = cam < C;
+    const int slice = (C + (int)gridDim.x - 1) / (int)gridDim.x;
+    const bool own = has && cam >= (int)blockIdx.x * slice && cam < ((int)blockIdx.x + 1) * slice;
+    const int set = L == 0 ? 0 : (L - 1) & 1;
+    const double* __restrict__ vold = pf.vecs + (size_t)set * kPcgVecs * n6;
+    double* __restrict__ vnew = pf.vecs + (size_t)(L == 0 ? 0 : set ^ 1) * kPcgVecs * n6;   // = set L & 1
+#pragma unroll
+    for (int k = 0; k < 6; ++k) uu[k] = 0.0;
+    double m[21];
+    PcgCtrl ci;
+    if (L != 0) {
+        ci = pf.ctrl2[L & 1];
+        if (ci.done != 0) {                                   // grid-uniform; before any other load is issued
+            if (writer) *cout = ci;
+            return false;
+        }
+    }
+    if (has) {
+#pragma unroll
+        for (int n = 0; n < 21; ++n) m[n] = pf.Minv[(size_t)n * C + cam];
+    }
+    if (L == 0) {
+        // start of a solve (k_pcg_init's work): rhs = -g_c - acc (acc = -sum W e from pass B, MODE 1),
+        // x = p = s = 0, r = rhs, u = Minv r
+        double rr[6];
+        double t = 0.0;
+        if (has) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) rr[k] = -pf.Ugc[(size_t)cam * 27 + 21 + k] - acc[(size_t)k * C + cam];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                uu[k] = minv_row(m, rr, k);
+                t += uu[k] * rr[k];
+            }
+            if (own) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const size_t e = (size_t)k * C + cam;
+                    vnew[kPcgX * n6 + e] = 0.0; vnew[kPcgP * n6 + e] = 0.0; vnew[kPcgS * n6 + e] = 0.0;
+                    vnew[kPcgR * n6 + e] = rr[k];
+                    vnew[kPcgU * n6 + e] = uu[k];
+                }
+            }
+        }
+        const double rz = block_sum_all(t, red_b);
+        const int done = (rz > 0.0) ? 0 : (rz == 0.0 ? 1 : 3);
+        if (writer) {
+            PcgCtrl c0;
+            c0.rz = rz; c0.rz0 = rz; c0.tol2 = pf.tol * pf.tol; c0.rz_prev = 1.0; c0.alpha_prev = 1.0;
+            c0.iters = 0; c0.max_iters = pf.max_iters; c0.done = done; c0.pad = 1;
+            *cout = c0;
+        }
+        return done == 0;                                         // grid-uniform
+    }
+    double ue[6], we[6], so[6], ro[6];
+    if (has) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const size_t e = (size_t)k * C + cam;
+            ue[k] = vold[kPcgU * n6 + e];
+            we[k] = acc[e] + pf.Dc[e] * ue[k];
+            so[k] = vold[kPcgS * n6 + e];
+            ro[k] = vold[kPcgR * n6 + e];
+        }
+    }
+    double d = 0.0;
+    if (has) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) d += we[k] * ue[k];
+    }
+    const double delta = block_sum_all(d, red_a);
+    const double gamma = ci.rz;
+    const double beta = ci.iters == 0 ? 0.0 : gamma / ci.rz_prev;
+    const double den = delta - (ci.iters == 0 ? 0.0 : beta * gamma / ci.alpha_prev);
+    const double alpha = gamma / den;
+    if (!(den > 0.0) || !isfinite(alpha)) {                    // S not SPD / NaN: uniform in the grid
+        if (writer) { PcgCtrl co = ci; co.done = 3; *cout = co; }
+        return false;
+    }
+    double t = 0.0;
+    if (has) {
+        double rr[6], ss[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            ss[k] = we[k] + beta * so[k];
+            rr[k] = ro[k] - alpha * ss[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            uu[k] = minv_row(m, rr, k);
+            t += uu[k] * rr[k];
+        }
+        if (own) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const size_t e = (size_t)k * C + cam;
+                // p and x of the few cameras this workgroup stores are read late: keeping them in
+                // registers from the top would spill
+                const double pk = ue[k] + beta * vold[kPcgP * n6 + e];
+                vnew[kPcgP * n6 + e] = pk;
+                vnew[kPcgX * n6 + e] = vold[kPcgX * n6 + e] + alpha * pk;
+                vnew[kPcgR * n6 + e] = rr[k];
+                vnew[kPcgS * n6 + e] = ss[k];
+                vnew[kPcgU * n6 + e] = uu[k];
+            }
+        }
+    }
+    const double rz = block_sum_all(t, red_b);
+    int done = 0;
+    if (!(rz > ci.tol2 * ci.rz0)) done = 1;                   // also catches NaN
+    else if (ci.iters + 1 >= ci.max_iters) done = 2;
+    if (writer) {
+        PcgCtrl co = ci;
+        co.rz_prev = ci.rz; co.alpha_prev = alpha; co.rz = rz; co.iters = ci.iters + 1; co.done = done;
+        *cout = co;
+    }
+    return done == 0;                                             // grid-uniform
+}
+
 template <bool LDS_VEC, bool FUSED>
 __global__ __launch_bounds__(kSweepThreads) void k_point_sweep(
     StepTable st, ObsArrays o, const double* __restrict__ vin, const double* __restrict__ Vinv,
@@ -1140,133 +1300,11 @@ __global__ __launch_bounds__(kSweepThreads) void k_point_sweep(
     int i = cur.x + lane, c = 0, p = 0;
     if (cur.y <= 64 && lane < cur.y) { c = o.cam_idx[i]; p = o.pt_idx[i]; }
     if (FUSED) {
-        __shared__ double red_a[16];
-        __shared__ double red_b[16];
-        // Until the solve finishes, launch L >= 1 sees iters == L - 1, so every address below follows from
-        // L alone and all vector loads of the prologue are in flight together.
-        PcgCtrl* __restrict__ cout = pf.ctrl2 + ((L + 1) & 1);
-        const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
-        const int cam = threadIdx.x;
-        const bool has = cam < C;
-        const int slice = (C + (int)gridDim.x - 1) / (int)gridDim.x;
-        const bool own = has && cam >= (int)blockIdx.x * slice && cam < ((int)blockIdx.x + 1) * slice;
-        const int set = L == 0 ? 0 : (L - 1) & 1;
-        const double* __restrict__ vold = pf.vecs + (size_t)set * kPcgVecs * n6;
-        double* __restrict__ vnew = pf.vecs + (size_t)(L == 0 ? 0 : set ^ 1) * kPcgVecs * n6;   // = set L & 1
-        double uu[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        double m[21];
-        PcgCtrl ci;
-        if (L != 0) {
-            ci = pf.ctrl2[L & 1];
-            if (ci.done != 0) {                                   // grid-uniform; before any other load is issued
-                if (writer) *cout = ci;
-                return;
-            }
-        }
-        if (has) {
+        double uu[6];
+        if (!pcg_fused_update(pf, acc, C, L, uu)) return;
+        if ((int)threadIdx.x < C) {
 #pragma unroll
-            for (int n = 0; n < 21; ++n) m[n] = pf.Minv[(size_t)n * C + cam];
-        }
-        if (L == 0) {
-            // start of a solve (k_pcg_init's work): rhs = -g_c - acc (acc = -sum W e from pass B, MODE 1),
-            // x = p = s = 0, r = rhs, u = Minv r
-            double rr[6];
-            double t[1] = {0.0};
-            if (has) {
-#pragma unroll
-                for (int k = 0; k < 6; ++k) rr[k] = -pf.Ugc[(size_t)cam * 27 + 21 + k] - acc[(size_t)k * C + cam];
-#pragma unroll
-                for (int k = 0; k < 6; ++k) {
-                    uu[k] = minv_row(m, rr, k);
-                    t[0] += uu[k] * rr[k];
-                }
-                if (own) {
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) {
-                        const size_t e = (size_t)k * C + cam;
-                        vnew[kPcgX * n6 + e] = 0.0; vnew[kPcgP * n6 + e] = 0.0; vnew[kPcgS * n6 + e] = 0.0;
-                        vnew[kPcgR * n6 + e] = rr[k];
-                        vnew[kPcgU * n6 + e] = uu[k];
-                    }
-                }
-            }
-            const double rz = block_sum_all(t[0], red_b);
-            const int done = (rz > 0.0) ? 0 : (rz == 0.0 ? 1 : 3);
-            if (writer) {
-                PcgCtrl c0;
-                c0.rz = rz; c0.rz0 = rz; c0.tol2 = pf.tol * pf.tol; c0.rz_prev = 1.0; c0.alpha_prev = 1.0;
-                c0.iters = 0; c0.max_iters = pf.max_iters; c0.done = done; c0.pad = 1;
-                *cout = c0;
-            }
-            if (done != 0) return;                                // grid-uniform
-        } else {
-            double ue[6], we[6], so[6], ro[6];
-            if (has) {
-#pragma unroll
-                for (int k = 0; k < 6; ++k) {
-                    const size_t e = (size_t)k * C + cam;
-                    ue[k] = vold[kPcgU * n6 + e];
-                    we[k] = acc[e] + pf.Dc[e] * ue[k];
-                    so[k] = vold[kPcgS * n6 + e];
-                    ro[k] = vold[kPcgR * n6 + e];
-                }
-            }
-            double d[1] = {0.0};
-            if (has) {
-#pragma unroll
-                for (int k = 0; k < 6; ++k) d[0] += we[k] * ue[k];
-            }
-            const double delta = block_sum_all(d[0], red_a);
-            const double gamma = ci.rz;
-            const double beta = ci.iters == 0 ? 0.0 : gamma / ci.rz_prev;
-            const double den = delta - (ci.iters == 0 ? 0.0 : beta * gamma / ci.alpha_prev);
-            const double alpha = gamma / den;
-            if (!(den > 0.0) || !isfinite(alpha)) {                // S not SPD / NaN: uniform in the grid
-                if (writer) { PcgCtrl co = ci; co.done = 3; *cout = co; }
-                return;
-            }
-            double t[1] = {0.0};
-            if (has) {
-                double rr[6], ss[6];
-#pragma unroll
-                for (int k = 0; k < 6; ++k) {
-                    ss[k] = we[k] + beta * so[k];
-                    rr[k] = ro[k] - alpha * ss[k];
-                }
-#pragma unroll
-                for (int k = 0; k < 6; ++k) {
-                    uu[k] = minv_row(m, rr, k);
-                    t[0] += uu[k] * rr[k];
-                }
-                if (own) {
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) {
-                        const size_t e = (size_t)k * C + cam;
-                        // p and x of the few cameras this workgroup stores are read late: keeping them in
-                        // registers from the top would spill
-                        const double pk = ue[k] + beta * vold[kPcgP * n6 + e];
-                        vnew[kPcgP * n6 + e] = pk;
-                        vnew[kPcgX * n6 + e] = vold[kPcgX * n6 + e] + alpha * pk;
-                        vnew[kPcgR * n6 + e] = rr[k];
-                        vnew[kPcgS * n6 + e] = ss[k];
-                        vnew[kPcgU * n6 + e] = uu[k];
-                    }
-                }
-            }
-            const double rz = block_sum_all(t[0], red_b);
-            int done = 0;
-            if (!(rz > ci.tol2 * ci.rz0)) done = 1;               // also catches NaN
-            else if (ci.iters + 1 >= ci.max_iters) done = 2;
-            if (writer) {
-                PcgCtrl co = ci;
-                co.rz_prev = ci.rz; co.alpha_prev = alpha; co.rz = rz; co.iters = ci.iters + 1; co.done = done;
-                *cout = co;
-            }
-            if (done != 0) return;                                // grid-uniform
-        }
-        if (has) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) smem[6 * cam + k] = uu[k];
+            for (int k = 0; k < 6; ++k) smem[6 * threadIdx.x + k] = uu[k];
         }
         __syncthreads();
     } else if (ctrl2 != nullptr) {
@@ -1347,15 +1385,171 @@ __global__ __launch_bounds__(kSweepThreads) void k_point_sweep(
     }
 }
 
+// Pass A, recomputing form (C <= kRcMaxCams): no stored Jacobian is read.  With j_k = row k of d r/d X = A R,
+// v = X - T and the camera vector u = (u_w, u_T):
+//     row k of d r/d w . u_w = -(j_k x v) . a',   a' = u_w - b (w x u_w) + c (w x (w x u_w))
+//     (Jc u)_k = -j_k . g,   g = v x a' + u_T,          y_p = sum_i Jp_i^T (Jc_i u),   z_p = Vinv_p y_p
+// (the identity (m x w).u = m.(w x u) moves the rotation Jacobian from the observation to the camera), so the
+// LDS table holds 18 doubles per camera, R | T | a' | u_T, 144 KB at 1000 cameras: R | T copied from the compact
+// view of the camera table, a' and u_T built per launch from u by one thread per camera.  Per observation: 8 B of
+// indices from HBM, 144 B from LDS, ~90 flop -- against 104 B from HBM for the form that reads J.
+constexpr int kRcRow = 18;
+constexpr int kRcMaxCams = 1100;          // 18 doubles x C within the 160 KiB LDS (FUSED additionally needs C <= 1024)
+
+template <bool FUSED>
+__global__ __launch_bounds__(kSweepThreads) void k_point_sweep_rc(
+    StepTable st, const int* __restrict__ cam_idx, const int* __restrict__ pt_idx,
+    const double* __restrict__ camtab, const double* __restrict__ pts, KMat K, const double* __restrict__ vin,
+    const double* __restrict__ Vinv, double* __restrict__ zout, const double* __restrict__ acc, int C,
+    const PcgCtrl* __restrict__ ctrl2, int L, PcgFused pf) {
+    extern __shared__ __align__(16) double smem[];
+    const int n6 = 6 * C;
+    const int wg = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    int s = 0, s_end = 0;
+    if (wg < st.n_waves) { const int2 w = st.wsteps[wg]; s = w.x; s_end = w.x + w.y; }
+    // Software pipeline of the walk: step descriptors three steps ahead, indices two ahead, the point and its
+    // inverse block one ahead -- every load of a step is in flight while the previous step computes.
+    int2 cur = make_int2(0, 0), nxt = make_int2(0, 0), nn = make_int2(0, 0);
+    if (s < s_end) cur = st.steps[s];
+    if (s + 1 < s_end) nxt = st.steps[s + 1];
+    if (s + 2 < s_end) nn = st.steps[s + 2];
+    int c = 0, p = 0, cn = 0, pn = 0;
+    if (cur.y <= 64 && lane < cur.y) { c = cam_idx[cur.x + lane]; p = pt_idx[cur.x + lane]; }
+    if (nxt.y <= 64 && lane < nxt.y) { cn = cam_idx[nxt.x + lane]; pn = pt_idx[nxt.x + lane]; }
+    const double* __restrict__ rt = camtab + cam_rt_offset(C);                    // compact [C][12] = R | T
+    const double* __restrict__ wbc = camtab + cam_wbc_offset(C);                  // w, b, c plane-major [5][C]
+    auto put_au = [&](int cam, const double* u) {          // a' and u_T of camera `cam` from its u (6)
+        const double wx = wbc[cam], wy = wbc[(size_t)C + cam], wz = wbc[2 * (size_t)C + cam];
+        const double b = wbc[3 * (size_t)C + cam], cc = wbc[4 * (size_t)C + cam];
+        const double c0 = wy * u[2] - wz * u[1], c1 = wz * u[0] - wx * u[2], c2 = wx * u[1] - wy * u[0];   // w x u_w
+        const double d0 = wy * c2 - wz * c1, d1 = wz * c0 - wx * c2, d2 = wx * c1 - wy * c0;               // w x (w x u_w)
+        double* __restrict__ row = smem + (size_t)kRcRow * cam;
+        row[12] = u[0] - b * c0 + cc * d0; row[13] = u[1] - b * c1 + cc * d1; row[14] = u[2] - b * c2 + cc * d2;
+        row[15] = u[3]; row[16] = u[4]; row[17] = u[5];
+    };
+    if (FUSED) {
+        double uu[6];
+        if (!pcg_fused_update(pf, acc, C, L, uu)) return;
+        if ((int)threadIdx.x < C) put_au(threadIdx.x, uu);
+    } else {
+        if (ctrl2 != nullptr) {                               // two-kernel PCG: vin = base of the vector sets
+            const PcgCtrl* __restrict__ ctrl = ctrl2 + (L & 1);
+            if (ctrl->done != 0) return;                      // grid-uniform
+            vin += (size_t)((ctrl->iters & 1) * kPcgVecs + kPcgU) * n6;
+        }
+        for (int cam = threadIdx.x; cam < C; cam += blockDim.x) {     // vin: plane-major [6][C]
+            double u[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) u[k] = vin[(size_t)k * C + cam];
+            put_au(cam, u);
+        }
+    }
+    for (int e = threadIdx.x; e < C * (kCamRT / 2); e += blockDim.x) {     // R | T: 6 x 16 bytes per camera, coalesced
+        const int cam = e / (kCamRT / 2), k = e - cam * (kCamRT / 2);
+        reinterpret_cast<double2*>(smem + (size_t)kRcRow * cam)[k] = reinterpret_cast<const double2*>(rt)[e];
+    }
+    __syncthreads();
+
+    // y contribution of one observation: camera row `cc` (LDS), point X
+    auto contrib = [&](int cc, double X, double Y, double Z, double* y) {
+        const double2* __restrict__ row = reinterpret_cast<const double2*>(smem + (size_t)kRcRow * cc);
+        const double2 r01 = row[0], r23 = row[1], r45 = row[2], r67 = row[3], r8t = row[4], t12 = row[5];
+        const double2 a01 = row[6], a2u = row[7], u12 = row[8];
+        const double R0 = r01.x, R1 = r01.y, R2 = r23.x, R3 = r23.y, R4 = r45.x, R5 = r45.y, R6 = r67.x, R7 = r67.y,
+                     R8 = r8t.x;
+        const double vx = X - r8t.y, vy = Y - t12.x, vz = Z - t12.y;
+        const double qx = R0 * vx + R1 * vy + R2 * vz;
+        const double qy = R3 * vx + R4 * vy + R5 * vz;
+        const double qz = R6 * vx + R7 * vy + R8 * vz;
+        const double px = K.k[0] * qx + K.k[1] * qy + K.k[2] * qz;
+        const double py = K.k[3] * qx + K.k[4] * qy + K.k[5] * qz;
+        const double pz = K.k[6] * qx + K.k[7] * qy + K.k[8] * qz;
+        const double iz = 1.0 / pz;
+        // g = v x a' + u_T
+        const double ax = a01.x, ay = a01.y, az = a2u.x;
+        const double g0 = vy * az - vz * ay + a2u.y, g1 = vz * ax - vx * az + u12.x, g2 = vx * ay - vy * ax + u12.y;
+        y[0] = 0.0; y[1] = 0.0; y[2] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const double pk = (k == 0 ? px : py) * iz;
+            const double b0 = (K.k[3 * k + 0] - pk * K.k[6]) * iz;
+            const double b1 = (K.k[3 * k + 1] - pk * K.k[7]) * iz;
+            const double b2 = (K.k[3 * k + 2] - pk * K.k[8]) * iz;
+            const double j0 = b0 * R0 + b1 * R3 + b2 * R6;            // row k of A R
+            const double j1 = b0 * R1 + b1 * R4 + b2 * R7;
+            const double j2 = b0 * R2 + b1 * R5 + b2 * R8;
+            const double tk = -(j0 * g0 + j1 * g1 + j2 * g2);        // (Jc u)_k
+            y[0] += j0 * tk; y[1] += j1 * tk; y[2] += j2 * tk;
+        }
+    };
+
+    auto load_point = [&](bool on, int pp, double* X, double* vi) {
+        if (on) {
+            const double* __restrict__ Xp = pts + 3 * (size_t)pp;
+            X[0] = Xp[0]; X[1] = Xp[1]; X[2] = Xp[2];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) vi[k] = Vinv[6 * (size_t)pp + k];
+        }
+    };
+    double X[3] = {0.0, 0.0, 0.0}, vi[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    load_point(cur.y <= 64 && lane < cur.y, p, X, vi);
+    while (s < s_end) {
+        int2 n3 = make_int2(0, 0);
+        if (s + 3 < s_end) n3 = st.steps[s + 3];
+        int c2 = 0, p2 = 0;
+        if (nn.y <= 64 && lane < nn.y) { c2 = cam_idx[nn.x + lane]; p2 = pt_idx[nn.x + lane]; }
+        double Xn[3] = {0.0, 0.0, 0.0}, vin_[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        load_point(nxt.y <= 64 && lane < nxt.y, pn, Xn, vin_);
+        double y[3] = {0.0, 0.0, 0.0};
+        if (cur.y > 64) {                          // one point with more than 64 observations
+            const int run_end = cur.x + cur.y;
+            const int pp = pt_idx[cur.x];
+            const double* __restrict__ Xp = pts + 3 * (size_t)pp;
+            const double Xl = Xp[0], Yl = Xp[1], Zl = Xp[2];
+            for (int j = cur.x + lane; j < run_end; j += 64) {
+                double w[3];
+                contrib(cam_idx[j], Xl, Yl, Zl, w);
+                y[0] += w[0]; y[1] += w[1]; y[2] += w[2];
+            }
+            y[0] = wave_sum(y[0]); y[1] = wave_sum(y[1]); y[2] = wave_sum(y[2]);
+            if (lane == 0) {
+                const double* vl = Vinv + 6 * (size_t)pp;
+                zout[3 * (size_t)pp + 0] = vl[0] * y[0] + vl[1] * y[1] + vl[2] * y[2];
+                zout[3 * (size_t)pp + 1] = vl[1] * y[0] + vl[3] * y[1] + vl[4] * y[2];
+                zout[3 * (size_t)pp + 2] = vl[2] * y[0] + vl[4] * y[1] + vl[5] * y[2];
+            }
+        } else {
+            const bool act = lane < cur.y;
+            if (act) contrib(c, X[0], X[1], X[2], y);
+            const int key = act ? p : -1 - lane;
+            seg_reduce<3>(y, key, lane);
+            const int prev = __shfl_up(key, 1);
+            if (act && (lane == 0 || prev != key)) {
+                zout[3 * (size_t)p + 0] = vi[0] * y[0] + vi[1] * y[1] + vi[2] * y[2];
+                zout[3 * (size_t)p + 1] = vi[1] * y[0] + vi[3] * y[1] + vi[4] * y[2];
+                zout[3 * (size_t)p + 2] = vi[2] * y[0] + vi[4] * y[1] + vi[5] * y[2];
+            }
+        }
+        cur = nxt; nxt = nn; nn = n3;
+        c = cn; p = pn; cn = c2; pn = p2;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) X[k] = Xn[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) vi[k] = vin_[k];
+        ++s;
+    }
+}
+
 // Pass B: acc_c = sum_{i in c} Jc_i^T ( Jc_i v_c - Jp_i z_p )   (MODE 0; v_c wave-uniform, z gathered), or
 //         acc_c = - sum Jc_i^T Jp_i e_p                          (MODE 1; z = e), over one camera chunk, with the
-// blocks recomputed from the camera row and the gathered point.  In fp32-storage mode the recomputed entries
-// are rounded to float first: pass A applied the STORED (rounded) blocks, and the product has to be that of one
-// symmetric matrix.  Output: plane-major acc[k][C] for a single-chunk camera, partial[chunk][6] otherwise.
+// blocks recomputed from the camera row and the gathered point.  ROUND (fp32-storage mode, when pass A is the
+// form that reads the stored blocks): the recomputed entries are rounded to float first -- pass A applied the
+// STORED (rounded) blocks, and the product has to be that of one symmetric matrix.  Output: plane-major acc[k][C] for a single-chunk camera, partial[chunk][6] otherwise.
 //   ctrl_done: PCG control block whose `done` voids this launch (null: unconditional)
 //   set:       vector set holding u; < 0: take it from ctrl_done->iters (two-kernel PCG); vin then is the base of
 //              the sets.  ctrl_done == null: vin is the plane-major vector itself.
-template <int MODE, bool F32>
+template <int MODE, bool ROUND>
 __global__ __launch_bounds__(kCamThreads) void k_cam_schur(CamMajor cm, const double* __restrict__ camtab,
                                                            const double* __restrict__ pts, KMat K,
                                                            const double* __restrict__ vin,
@@ -1377,35 +1571,42 @@ __global__ __launch_bounds__(kCamThreads) void k_cam_schur(CamMajor cm, const do
         for (int k = 0; k < 6; ++k) vc[k] = vin[(size_t)k * C + ch.x];
     }
     double a[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    int k = ch.y + (int)threadIdx.x;
-    int p = 0;
-    if (k < ch.z) p = cm.pt[k];
-    while (k < ch.z) {
-        const int kn = k + kCamThreads;
-        int pn = 0;
-        if (kn < ch.z) pn = cm.pt[kn];
-        const double* __restrict__ Xp = pts + 3 * (size_t)p;
-        const double* __restrict__ zp = zin + 3 * (size_t)p;
-        const double z0 = zp[0], z1 = zp[1], z2 = zp[2];
-        double jc[12], jp[6], rx, ry;
-        observe<true>(t, Xp[0], Xp[1], Xp[2], 0.0, 0.0, K, rx, ry, jc, jp);
-        if (F32) {
+    for (int k0 = ch.y + (int)threadIdx.x; k0 < ch.z; k0 += kCamThreads * kCamUnroll) {      // see k_cam_blocks
+        int p[kCamUnroll];
+        double X[kCamUnroll][3], z[kCamUnroll][3];
 #pragma unroll
-            for (int q = 0; q < 3; ++q) { jc[q] = (double)(float)jc[q]; jc[6 + q] = (double)(float)jc[6 + q]; }
-#pragma unroll
-            for (int q = 0; q < 6; ++q) jp[q] = (double)(float)jp[q];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) { jc[3 + q] = -jp[q]; jc[9 + q] = -jp[3 + q]; }
-        }
-        double u0 = -(jp[0] * z0 + jp[1] * z1 + jp[2] * z2);
-        double u1 = -(jp[3] * z0 + jp[4] * z1 + jp[5] * z2);
-        if (MODE == 0) {
-#pragma unroll
-            for (int q = 0; q < 6; ++q) { u0 += jc[q] * vc[q]; u1 += jc[6 + q] * vc[q]; }
+        for (int u = 0; u < kCamUnroll; ++u) {
+            const int k = k0 + u * kCamThreads;
+            p[u] = k < ch.z ? cm.pt[k] : -1;
         }
 #pragma unroll
-        for (int q = 0; q < 6; ++q) a[q] += jc[q] * u0 + jc[6 + q] * u1;
-        k = kn; p = pn;
+        for (int u = 0; u < kCamUnroll; ++u) {
+            const size_t pp = 3 * (size_t)(p[u] < 0 ? 0 : p[u]);
+            X[u][0] = pts[pp]; X[u][1] = pts[pp + 1]; X[u][2] = pts[pp + 2];
+            z[u][0] = zin[pp]; z[u][1] = zin[pp + 1]; z[u][2] = zin[pp + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < kCamUnroll; ++u) {
+            if (p[u] < 0) continue;
+            double jc[12], jp[6], rx, ry;
+            observe<true>(t, X[u][0], X[u][1], X[u][2], 0.0, 0.0, K, rx, ry, jc, jp);
+            if (ROUND) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) { jc[q] = (double)(float)jc[q]; jc[6 + q] = (double)(float)jc[6 + q]; }
+#pragma unroll
+                for (int q = 0; q < 6; ++q) jp[q] = (double)(float)jp[q];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) { jc[3 + q] = -jp[q]; jc[9 + q] = -jp[3 + q]; }
+            }
+            double u0 = -(jp[0] * z[u][0] + jp[1] * z[u][1] + jp[2] * z[u][2]);
+            double u1 = -(jp[3] * z[u][0] + jp[4] * z[u][1] + jp[5] * z[u][2]);
+            if (MODE == 0) {
+#pragma unroll
+                for (int q = 0; q < 6; ++q) { u0 += jc[q] * vc[q]; u1 += jc[6 + q] * vc[q]; }
+            }
+#pragma unroll
+            for (int q = 0; q < 6; ++q) a[q] += jc[q] * u0 + jc[6 + q] * u1;
+        }
     }
     const double s = cam_block_total<6>(a, red);
     if (threadIdx.x < 6) {
@@ -1769,6 +1970,10 @@ __global__ __launch_bounds__(256) void k_p2p_allreduce(double* __restrict__ vec,
         return;
     }
     if (a.cancel != nullptr && *a.cancel != 0) return;        // grid-uniform, identical on all ranks
+    if (*a.error != 0u) {                                     // an earlier collective of this solve gave up: do not wait
+        if (a.post.host != nullptr && blockIdx.x == 0 && threadIdx.x < 64) post_mailbox(a.post);   // again, let the
+        return;                                               // host see the error word at the next hand-off
+    }
     const int tid = threadIdx.x;
     if (a.rider.part != nullptr) {                            // (single workgroup) final sums that feed this collective
         finish_in_block(a.rider);

@@ -134,13 +134,18 @@ struct sfmba_handle {
     bool f32 = false;                        // fp32 storage of uv, r, t1 and the Jacobian (arithmetic stays fp64)
     bool f32_next = false;                   // takes effect at the next sfmba_set_problem
     bool lds_tab = true, lds_vec = true;     // camera table (K1, K2) / camera vector (sweeps) staged in LDS
+    bool sweep_rc = false;                   // pass A recomputes the blocks from an LDS table (k_point_sweep_rc)
     // test / diagnostic hooks, set through sfmba_debug_option only (nothing reads the environment)
     struct Debug {
         int pcg_fused = -1;                  // 0: two-kernel PCG although the fused launch would fit
         int tab_lds = -1, vec_lds = -1;      // 0: camera table / camera vector read from L2 although LDS would fit
+        int sweep_rc = -1;                   // 0: pass A reads the stored Jacobian although the recomputing form would fit
         int cam_chunk = 0;                   // > 0: chunk length of the camera-major kernels
         int pcg_guess_bias = 0;              // added to the number of speculatively enqueued PCG iterations
         int trace_pcg = 0, trace_stalls = 0, trace_timing = 0;   // stderr diagnostics
+        int wait_deadline_s = 120;           // a hand-off that does not arrive within this many seconds fails the solve (-3)
+        int p2p_delay_ms = 0;                // test: sleep this long before the first collective of a solve
+        int p2p_timeout_ms = 0;              // test: > 0 overrides both time-outs of the direct all-reduce
     } dbg;
 
     DevBuf cam_idx, pt_idx, pt_ptr, uv, ranges, wsteps, steps;
@@ -159,8 +164,10 @@ struct sfmba_handle {
     int64_t arena_doubles = 0;
     sfmba_allreduce_fn ar_fn = nullptr;
     void* ar_ctx = nullptr;
+    sfmba_print_fn print_fn = nullptr;       // verbose = 2 lines go here (null: stdout of the C library)
+    void* print_ctx = nullptr;
     ncclComm_t comm = nullptr;               // native RCCL communicator (sfmba_comm_init)
-    int64_t n_collectives = 0;
+    int64_t n_collectives = 0, n_launches = 0;
     // direct all-reduce over peer-mapped staging buffers (k_p2p_allreduce); preferred over RCCL / the
     // callback for every vector that fits a slot
     struct P2p {
@@ -173,6 +180,7 @@ struct sfmba_handle {
         unsigned long long* flags[kP2pMaxRanks] = {};
         unsigned* words = nullptr;           // [0] ticket, [1] error, [2..3] uint64 count of performed collectives
         int64_t calls = 0;
+        bool first_in_solve = true;          // the next collective is the rendezvous of a solve (long timeout)
     } p2p;
     double* h_scal = nullptr;                // pinned
     void* h_stage = nullptr;                 // pinned staging of set_problem's uploads (grow-only)
@@ -225,6 +233,13 @@ int fail(sfmba_handle* h, int code, const char* fmt, ...) {
                         hipGetErrorString(e_), __FILE__, __LINE__);                             \
     } while (0)
 
+// after every kernel launch: count it (sfmba_get_counters) and pick up a launch failure
+#define LAUNCHED(h)                            \
+    do {                                       \
+        ++(h)->n_launches;                     \
+        HIPCHK(h, hipGetLastError());          \
+    } while (0)
+
 #define CHK(expr)                  \
     do {                           \
         int rc_ = (expr);          \
@@ -241,7 +256,9 @@ int enter(sfmba_handle* h) {
 // All-reduce `count` doubles of the exchange arena in place over the ranks, on the handle's stream:
 // natively with RCCL when a communicator is set, else through the host callback, else a no-op.
 void p2p_release(sfmba_handle* h);
+void p2p_close_peers(sfmba_handle* h);
 bool multi_rank(const sfmba_handle* h) { return h->p2p.ready || h->comm != nullptr || h->ar_fn != nullptr; }
+const unsigned* p2p_error_word(const sfmba_handle* h) { return h->p2p.ready ? h->p2p.words + 1 : nullptr; }
 
 constexpr size_t kP2pFlagBytes = sizeof(unsigned long long) * 2 * kP2pMaxRanks * kP2pFlagStride;
 
@@ -260,10 +277,15 @@ int p2p_allreduce(sfmba_handle* h, double* ptr, int64_t count, int op, const int
     a.skip = skip;
     if ((rider || post) && count > 512) return fail(h, -1, "rider / post need a single-workgroup collective");
     a.ticket = p.words; a.error = p.words + 1;
-    a.timeout = 300000000ll;                              // 3 s of the 100 MHz wall clock
+    // Ticks of the 100 MHz wall clock.  Steady state: 3 s.  The FIRST collective of a solve is the rendezvous of
+    // ranks that entered sfmba_solve at different times (Python skew, first-use code-object loads; no barrier is
+    // required before a solve): it waits up to 60 s.
+    a.timeout = p.first_in_solve ? 6000000000ll : 300000000ll;
+    if (h->dbg.p2p_timeout_ms > 0) a.timeout = 100000ll * h->dbg.p2p_timeout_ms;       // test hook
+    p.first_in_solve = false;
     const int grid = (int)std::min<int64_t>(kP2pMaxBlocks, std::max<int64_t>(1, (count + 511) / 512));
     hipLaunchKernelGGL(k_p2p_allreduce, dim3(grid), dim3(256), 0, h->stream, ptr, (int)count, op, a);
-    HIPCHK(h, hipGetLastError());
+    LAUNCHED(h);
     ++p.calls;
     return 0;
 }
@@ -345,22 +367,31 @@ int wait_stream(sfmba_handle* h) {
 // speculative launches cost 5.8 us before the first kernel of the next iteration.  The post of an iteration
 // arrives a few hundred microseconds after the host has finished enqueueing it; only past 5 ms is the stream
 // queried (every millisecond), to notice a failed launch instead of spinning forever.
+int mailbox_arrived(sfmba_handle* h, const char* where, double t0) {
+    report_stall(h, where, now_s() - t0);
+    if (h->mbox[kMboxErr] != 0.0)          // published with every post: a direct all-reduce gave up waiting for a peer
+        return fail(h, -5, "a direct all-reduce timed out waiting for a peer rank");
+    return 0;
+}
+
 int wait_mailbox(sfmba_handle* h, unsigned long long seq) {
     unsigned long long* word = reinterpret_cast<unsigned long long*>(h->mbox + kMboxSeq);
     const double t0 = now_s();
     double t_check = t0 + 5e-3;
     for (int spin = 0;; ++spin) {
-        if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) { report_stall(h, "wait_mailbox", now_s() - t0); return 0; }
+        if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) return mailbox_arrived(h, "wait_mailbox", t0);
         __builtin_ia32_pause();
         if ((spin & 15) != 15) continue;
         const double t = now_s();
         if (t < t_check) continue;
         const hipError_t e = hipStreamQuery(h->stream);
         if (e == hipSuccess) {                               // everything enqueued has run: the post is visible
-            if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) { report_stall(h, "wait_mailbox (stream idle)", now_s() - t0); return 0; }
+            if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) return mailbox_arrived(h, "wait_mailbox (stream idle)", t0);
             return fail(h, -3, "hand-off mailbox was not written");
         }
         if (e != hipErrorNotReady) return fail(h, -3, "hipStreamQuery failed: %s", hipGetErrorString(e));
+        if (t - t0 > h->dbg.wait_deadline_s)   // a kernel that never drains, a peer that died inside a library collective
+            return fail(h, -3, "hand-off not posted within %d s: the device queue is stuck", h->dbg.wait_deadline_s);
         t_check = t + 1e-3;
     }
 }
@@ -369,7 +400,7 @@ int wait_mailbox(sfmba_handle* h, unsigned long long seq) {
 
 int launch_cam_table(sfmba_handle* h, const double* x, double* tab) {
     hipLaunchKernelGGL(k_cam_table, dim3((h->C + 255) / 256), dim3(256), 0, h->stream, x, (int)h->C, tab);
-    HIPCHK(h, hipGetLastError());
+    LAUNCHED(h);
     return 0;
 }
 
@@ -394,7 +425,7 @@ int launch_resjac_v(sfmba_handle* h, const double* x, const double* tab, int gri
                            h->r.as<double>(), h->J.as<double>(), (int)h->N,
                            h->ld, (int)h->C, h->K, h->part.as<double>(), h->skip);
     }
-    HIPCHK(h, hipGetLastError());
+    LAUNCHED(h);
     return 0;
 }
 
@@ -418,7 +449,7 @@ int launch_finish(sfmba_handle* h, const double* part, int nparts, int nq, int s
     for (int k = 0; k < kFinishCols; ++k) { job.slot[0][k] = slot + k; job.slot[1][k] = -1; }
     hipLaunchKernelGGL(k_finish, dim3(1), dim3(64 * nq), 0, h->stream, part, job, nq, 0, h->scal(), h->skip,
                        h->post);
-    HIPCHK(h, hipGetLastError());
+    LAUNCHED(h);
     return 0;
 }
 
@@ -443,7 +474,7 @@ int launch_finish_slices(sfmba_handle* h, int q_lo, int q_hi) {
     const FinishJob job = slices_job(h, q_lo, q_hi);
     hipLaunchKernelGGL(k_finish, dim3(2), dim3(64 * kNQ), 0, h->stream, h->part.as<double>(), job, kNQ, 1, h->scal(),
                        (const double*)nullptr, Mailbox{});
-    HIPCHK(h, hipGetLastError());
+    LAUNCHED(h);
     return 0;
 }
 
@@ -456,7 +487,7 @@ int launch_cam_combine(sfmba_handle* h, int ncols, double* out, int cs, int ks, 
     if (!h->cam_multi) return 0;
     hipLaunchKernelGGL(k_cam_combine, dim3((int)((h->C * ncols + 255) / 256)), dim3(256), 0, h->stream,
                        h->cam_chunk_ptr.as<int>(), h->cam_partial.as<double>(), (int)h->C, ncols, out, cs, ks, skip, done);
-    HIPCHK(h, hipGetLastError());
+    LAUNCHED(h);
     return 0;
 }
 
@@ -477,10 +508,10 @@ int launch_normal_blocks_v(sfmba_handle* h, const double* x, const double* tab) 
                            h->cam_idx.as<int>(), h->pt_idx.as<int>(), h->uv.as<double>(), tab, pts, (int)h->C, h->K,
                            h->V.as<double>(), h->gp.as<double>(), h->skip);
     }
-    HIPCHK(h, hipGetLastError());
+    LAUNCHED(h);
     hipLaunchKernelGGL((k_cam_blocks<F32>), dim3(h->n_chunks), dim3(kCamThreads), 0, h->stream, cam_major(h), tab, pts,
                        h->K, h->Ugc(), h->cam_partial.as<double>(), h->skip);
-    HIPCHK(h, hipGetLastError());
+    LAUNCHED(h);
     return launch_cam_combine(h, 27, h->Ugc(), 27, 1, h->skip, nullptr);
 }
 int launch_normal_blocks(sfmba_handle* h, const double* x, const double* tab) {
@@ -492,6 +523,17 @@ int launch_normal_blocks(sfmba_handle* h, const double* x, const double* tab) {
 // plane-major when it is staged in LDS, camera-major otherwise; ctrl2 = nullptr.
 int launch_point_sweep(sfmba_handle* h, const double* vin, const PcgCtrl* ctrl2, int L) {
     const int grid = (h->n_ranges + kWavesPerSweepBlock - 1) / kWavesPerSweepBlock;
+    if (h->sweep_rc) {                    // recomputing form: vin plane-major (or the base of the vector sets)
+        const size_t lds = sizeof(double) * kRcRow * (size_t)h->C;
+        auto kern = k_point_sweep_rc<false>;
+        CHK(set_lds(h, kern, lds));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), lds, h->stream, step_table(h), (const int*)h->cam_idx.as<int>(),
+                           (const int*)h->pt_idx.as<int>(), (const double*)h->tab, (const double*)(h->x + 6 * h->C), h->K, vin,
+                           (const double*)h->Vinv.as<double>(), h->z.as<double>(), (const double*)h->acc(), (int)h->C, ctrl2, L,
+                           PcgFused{});
+        LAUNCHED(h);
+        return 0;
+    }
     if (h->lds_vec) {
         const size_t lds = sizeof(double) * 6 * (size_t)h->C;
         auto kern = k_point_sweep<true, false>;
@@ -503,22 +545,34 @@ int launch_point_sweep(sfmba_handle* h, const double* vin, const PcgCtrl* ctrl2,
                            obs_arrays(h), vin, h->Vinv.as<double>(), h->z.as<double>(), (const double*)h->acc(),
                            (int)h->C, ctrl2, L, PcgFused{});
     }
-    HIPCHK(h, hipGetLastError());
+    LAUNCHED(h);
     return 0;
 }
 
 // pass A fused with the PCG update of the previous product (one launch)
 int launch_pcg_fused(sfmba_handle* h, int L) {
     const int grid = (h->n_ranges + kWavesPerSweepBlock - 1) / kWavesPerSweepBlock;
+    PcgFused pf{h->Dc.as<double>(), h->Minv.as<double>(), h->Ugc(), h->vecs.as<double>(), h->ctrl.as<PcgCtrl>(),
+                h->pcg_tol, h->pcg_cap};
+    if (h->sweep_rc) {
+        const size_t lds_rc = sizeof(double) * kRcRow * (size_t)h->C;
+        auto kern_rc = k_point_sweep_rc<true>;
+        CHK(set_lds(h, kern_rc, lds_rc));
+        hipLaunchKernelGGL(kern_rc, dim3(grid), dim3(kSweepThreads), lds_rc, h->stream, step_table(h),
+                           (const int*)h->cam_idx.as<int>(), (const int*)h->pt_idx.as<int>(), (const double*)h->tab,
+                           (const double*)(h->x + 6 * h->C), h->K, (const double*)h->vecs.as<double>(),
+                           (const double*)h->Vinv.as<double>(), h->z.as<double>(), (const double*)h->acc(), (int)h->C,
+                           (const PcgCtrl*)h->ctrl.as<PcgCtrl>(), L, pf);
+        LAUNCHED(h);
+        return 0;
+    }
     const size_t lds = sizeof(double) * 6 * (size_t)h->C;
     auto kern = k_point_sweep<true, true>;
     CHK(set_lds(h, kern, lds));
-    PcgFused pf{h->Dc.as<double>(), h->Minv.as<double>(), h->Ugc(), h->vecs.as<double>(), h->ctrl.as<PcgCtrl>(),
-                h->pcg_tol, h->pcg_cap};
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), lds, h->stream, step_table(h), obs_arrays(h),
                        (const double*)h->vecs.as<double>(), h->Vinv.as<double>(), h->z.as<double>(),
                        (const double*)h->acc(), (int)h->C, (const PcgCtrl*)h->ctrl.as<PcgCtrl>(), L, pf);
-    HIPCHK(h, hipGetLastError());
+    LAUNCHED(h);
     return 0;
 }
 
@@ -527,7 +581,7 @@ int launch_pcg_fused(sfmba_handle* h, int L) {
 template <int MODE>
 int launch_cam_schur(sfmba_handle* h, const double* vin, const double* zin, const PcgCtrl* ctrl_done, int set) {
     const double* pts = h->x + 6 * h->C;
-    if (h->f32)
+    if (h->f32 && !h->sweep_rc)           // pass A applies the stored fp32 blocks: pass B rounds its own the same way
         hipLaunchKernelGGL((k_cam_schur<MODE, true>), dim3(h->n_chunks), dim3(kCamThreads), 0, h->stream, cam_major(h),
                            (const double*)h->tab, pts, h->K, vin, zin, (int)h->C, h->acc(), h->cam_partial.as<double>(),
                            ctrl_done, set);
@@ -535,17 +589,17 @@ int launch_cam_schur(sfmba_handle* h, const double* vin, const double* zin, cons
         hipLaunchKernelGGL((k_cam_schur<MODE, false>), dim3(h->n_chunks), dim3(kCamThreads), 0, h->stream, cam_major(h),
                            (const double*)h->tab, pts, h->K, vin, zin, (int)h->C, h->acc(), h->cam_partial.as<double>(),
                            ctrl_done, set);
-    HIPCHK(h, hipGetLastError());
+    LAUNCHED(h);
     return launch_cam_combine(h, 6, h->acc(), 1, (int)h->C, nullptr, ctrl_done ? &ctrl_done->done : nullptr);
 }
 
 // acc = (S - Dc) v for a plane-major vector v outside the PCG (test and timing entries): pass A, pass B
 int schur_product_standalone(sfmba_handle* h, const double* v_planes) {
     const double* va = v_planes;
-    if (!h->lds_vec) {                    // pass A gathers v from a camera-major copy in L2
+    if (!h->lds_vec && !h->sweep_rc) {    // pass A gathers v from a camera-major copy in L2
         hipLaunchKernelGGL(k_transpose, dim3((unsigned)((6 * h->C + 255) / 256)), dim3(256), 0, h->stream, v_planes,
                            6, (int)h->C, h->vcm.as<double>(), (const PcgCtrl*)nullptr, 0);
-        HIPCHK(h, hipGetLastError());
+        LAUNCHED(h);
         va = h->vcm.as<double>();
     }
     CHK(launch_point_sweep(h, va, nullptr, 0));
@@ -570,7 +624,7 @@ int launch_jdot(sfmba_handle* h, int* nparts) {
         hipLaunchKernelGGL(k_jdot<false>, dim3(launch_grid), dim3(kSweepThreads), 0, h->stream, obs_arrays(h),
                            sgc, sgp, (int)h->N, (int)h->C, h->t1.as<double>(), h->partB(), pb);
     }
-    HIPCHK(h, hipGetLastError());
+    LAUNCHED(h);
     h->pending_scale_sums = false;
     *nparts = grid;
     return 0;
@@ -598,7 +652,7 @@ int launch_backsub(sfmba_handle* h, int* nparts) {
                            h->partB(), (int)h->C, (const PcgCtrl*)nullptr, 0, h->g.as<double>(),
                            h->si.as<double>(), h->sg.as<double>());
     }
-    HIPCHK(h, hipGetLastError());
+    LAUNCHED(h);
     *nparts = grid;
     return 0;
 }
@@ -609,7 +663,7 @@ int launch_update_scale(sfmba_handle* h, int first, bool defer = false) {
     hipLaunchKernelGGL(k_update_scale, dim3(h->red_grid), dim3(256), 0, h->stream, h->Ugc(), h->V.as<double>(),
                        h->gp.as<double>(), h->x, (int)h->C, (int)h->P, first, h->red_bc, h->si.as<double>(),
                        h->g.as<double>(), h->sg.as<double>(), h->part.as<double>());
-    HIPCHK(h, hipGetLastError());
+    LAUNCHED(h);
     if (defer) { h->pending_scale_sums = true; return 0; }
     return launch_finish_slices(h, 0, 4);
 }
@@ -629,7 +683,7 @@ int launch_finish_backsub(sfmba_handle* h, int nparts) {
     const Piggyback pb = backsub_rider(h, nparts);
     hipLaunchKernelGGL(k_finish, dim3(1), dim3(64 * kBacksubCols), 0, h->stream, pb.part, pb.job, kBacksubCols, 0,
                        h->scal(), (const double*)nullptr, Mailbox{});
-    HIPCHK(h, hipGetLastError());
+    LAUNCHED(h);
     return 0;
 }
 
@@ -652,9 +706,9 @@ int exchange_tail(sfmba_handle* h) {            // G12, G22, q5..q8
 // bring all 32 scalars to the host (h_scal) and wait: one small kernel posts them into the mailbox (no blit
 // copy, no marker packet in the queue, no stream polling)
 int fetch_scalars(sfmba_handle* h) {
-    const Mailbox mb{h->mbox_dev, h->scal(), nullptr, ++h->mbox_seq};
+    const Mailbox mb{h->mbox_dev, h->scal(), nullptr, ++h->mbox_seq, p2p_error_word(h)};
     hipLaunchKernelGGL(k_post, dim3(1), dim3(64), 0, h->stream, mb);
-    HIPCHK(h, hipGetLastError());
+    LAUNCHED(h);
     CHK(wait_mailbox(h, h->mbox_seq));
     memcpy(h->h_scal, h->mbox, sizeof(double) * kScalSlots);
     return 0;
@@ -731,7 +785,7 @@ int pcg_start(sfmba_handle* h, const sfmba_options& opt) {
     hipLaunchKernelGGL(k_pcg_init, dim3(1), dim3(1024), 0, h->stream, h->Ugc(), (const double*)h->acc(),
                        h->Minv.as<double>(), (int)h->C, h->vecs.as<double>(), opt.pcg_tol, pcg_max_iters(h, opt),
                        h->ctrl.as<PcgCtrl>());
-    HIPCHK(h, hipGetLastError());
+    LAUNCHED(h);
     return 0;
 }
 
@@ -757,7 +811,7 @@ int pcg_enqueue(sfmba_handle* h, int count) {
         CHK(exchange(h, h->acc(), 6 * h->C, 0, &cd->done));
         hipLaunchKernelGGL(k_pcg_update, dim3(kPcgUpdateBlocks), dim3(1024), 0, h->stream, (const double*)h->acc(),
                            h->Dc.as<double>(), h->Minv.as<double>(), (int)h->C, h->vecs.as<double>(), ctrl2, L);
-        HIPCHK(h, hipGetLastError());
+        LAUNCHED(h);
         h->pcg_L = L + 1;
     }
     return 0;
@@ -785,29 +839,36 @@ int pcg_finish_polling(sfmba_handle* h, const sfmba_options& opt, PcgCtrl* hc) {
     }
 }
 
-void print_center(const char* s) {
+void append_center(std::string& line, const char* s) {          // Python's format spec ^15
     const int w = 15, len = (int)strlen(s);
     const int left = (w - len) / 2 > 0 ? (w - len) / 2 : 0;
     const int right = w - len - left > 0 ? w - len - left : 0;
-    printf("%*s%s%*s", left, "", s, right, "");
+    line.append((size_t)left, ' ').append(s).append((size_t)right, ' ');
+}
+void emit_line(sfmba_handle* h, const std::string& line) {
+    if (h->print_fn) { h->print_fn(h->print_ctx, line.c_str()); return; }
+    fputs(line.c_str(), stdout);
+    fputc('\n', stdout);
+    fflush(stdout);
 }
 
-// scipy's iteration table (SCIPY common.py:545-563)
-void print_header() {
+// scipy's iteration table (SCIPY common.py:545-563: print_header_nonlinear / print_iteration_nonlinear)
+void print_header(sfmba_handle* h) {
     const char* cols[6] = {"Iteration", "Total nfev", "Cost", "Cost reduction", "Step norm", "Optimality"};
-    for (auto c : cols) print_center(c);
-    printf("\n");
+    std::string line;
+    for (auto c : cols) append_center(line, c);
+    emit_line(h, line);
 }
-void print_iter(int64_t it, int64_t nfev, double cost, bool have, double red, double step, double opt) {
+void print_iter(sfmba_handle* h, int64_t it, int64_t nfev, double cost, bool have, double red, double step, double opt) {
     char b[64];
-    snprintf(b, sizeof b, "%lld", (long long)it); print_center(b);
-    snprintf(b, sizeof b, "%lld", (long long)nfev); print_center(b);
-    snprintf(b, sizeof b, "%.4e", cost); print_center(b);
-    if (have) { snprintf(b, sizeof b, "%.2e", red); print_center(b); snprintf(b, sizeof b, "%.2e", step); print_center(b); }
-    else { print_center(""); print_center(""); }
-    snprintf(b, sizeof b, "%.2e", opt); print_center(b);
-    printf("\n");
-    fflush(stdout);
+    std::string line;
+    snprintf(b, sizeof b, "%lld", (long long)it); append_center(line, b);
+    snprintf(b, sizeof b, "%lld", (long long)nfev); append_center(line, b);
+    snprintf(b, sizeof b, "%.4e", cost); append_center(line, b);
+    if (have) { snprintf(b, sizeof b, "%.2e", red); append_center(line, b); snprintf(b, sizeof b, "%.2e", step); append_center(line, b); }
+    else { append_center(line, ""); append_center(line, ""); }
+    snprintf(b, sizeof b, "%.2e", opt); append_center(line, b);
+    emit_line(h, line);
 }
 
 }  // namespace
@@ -876,12 +937,20 @@ int sfmba_set_stream(sfmba_handle* h, void* hip_stream) {
     return 0;
 }
 
+int sfmba_set_print(sfmba_handle* h, sfmba_print_fn fn, void* ctx) {
+    CHK(enter(h));
+    h->print_fn = fn;
+    h->print_ctx = ctx;
+    return 0;
+}
+
 int sfmba_debug_option(sfmba_handle* h, const char* name, int64_t value) {
     CHK(enter(h));
     if (!name) return fail(h, -1, "option name is NULL");
     const std::string n(name);
     const int v = (int)value;
     if (n == "pcg_fused") h->dbg.pcg_fused = v;
+    else if (n == "sweep_rc") h->dbg.sweep_rc = v;
     else if (n == "tab_lds") h->dbg.tab_lds = v;
     else if (n == "vec_lds") h->dbg.vec_lds = v;
     else if (n == "cam_chunk") h->dbg.cam_chunk = v;
@@ -889,6 +958,9 @@ int sfmba_debug_option(sfmba_handle* h, const char* name, int64_t value) {
     else if (n == "trace_pcg") h->dbg.trace_pcg = v;
     else if (n == "trace_stalls") h->dbg.trace_stalls = v;
     else if (n == "trace_timing") h->dbg.trace_timing = v;
+    else if (n == "wait_deadline_s") h->dbg.wait_deadline_s = v;
+    else if (n == "p2p_delay_ms") h->dbg.p2p_delay_ms = v;
+    else if (n == "p2p_timeout_ms") h->dbg.p2p_timeout_ms = v;
     else return fail(h, -1, "unknown debug option '%s'", name);
     return 0;
 }
@@ -1069,6 +1141,13 @@ int sfmba_p2p_detach(sfmba_handle* h) {
 
 int64_t sfmba_p2p_calls(const sfmba_handle* h) { return h ? h->p2p.calls : 0; }
 
+int sfmba_get_counters(const sfmba_handle* h, int64_t* kernel_launches, int64_t* collectives) {
+    if (!h) return -1;
+    if (kernel_launches) *kernel_launches = h->n_launches;
+    if (collectives) *collectives = h->n_collectives;
+    return 0;
+}
+
 static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, const int64_t* cam, const int64_t* pt,
                             const double* uv, const int64_t* uv_i64, const double* K);
 
@@ -1118,7 +1197,12 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     }
     tp1 = now_s();
     h->f32 = h->f32_next;
-    if (h->p2p.own && 27 * C > h->p2p.stride) p2p_release(h);     // slots too small for the new camera count
+    // A new problem returns the handle to single-process operation: every transport (direct link, RCCL
+    // communicator, callback) is torn down and has to be set up again after this call (include/sfmba.h).  The
+    // staging buffer of the direct link stays allocated until sfmba_p2p_detach / _export / _destroy, because
+    // peers may still have it mapped.
+    if (h->p2p.ready) p2p_close_peers(h);
+    if (h->comm) { if (RcclApi* api = rccl_api()) (void)api->CommDestroy(h->comm); h->comm = nullptr; }
     h->C = C; h->P = P; h->N = N; h->n = 6 * C + 3 * P;
     h->N_total = N;
     h->ld = (N + 255) / 256 * 256;
@@ -1242,7 +1326,8 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     h->lds_vec = (size_t)C * 6 * sizeof(double) <= kLdsDynMax;
     if (h->dbg.tab_lds == 0) h->lds_tab = false;               // test hooks (sfmba_debug_option): force the L2 placements
     if (h->dbg.vec_lds == 0) h->lds_vec = false;
-    h->pcg_fused = h->lds_vec && C <= kSweepThreads;
+    h->sweep_rc = C <= kRcMaxCams && (size_t)C * kRcRow * sizeof(double) <= kLdsDynMax && h->dbg.sweep_rc != 0;
+    h->pcg_fused = (h->lds_vec || h->sweep_rc) && C <= kSweepThreads;
     if (h->dbg.pcg_fused == 0) h->pcg_fused = false;
 
     const size_t ld = (size_t)h->ld;
@@ -1256,8 +1341,8 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     HIPCHK(h, h->steps.ensure(sizeof(int2) * std::max<size_t>(1, steps.size())));
     HIPCHK(h, h->xa.ensure(sizeof(double) * h->n));
     HIPCHK(h, h->xb.ensure(sizeof(double) * h->n));
-    HIPCHK(h, h->tabA.ensure(sizeof(double) * kCamTab * C));
-    HIPCHK(h, h->tabB.ensure(sizeof(double) * kCamTab * C));
+    HIPCHK(h, h->tabA.ensure(sizeof(double) * cam_table_doubles((int)C)));
+    HIPCHK(h, h->tabB.ensure(sizeof(double) * cam_table_doubles((int)C)));
     HIPCHK(h, h->r.ensure(esz * 2 * ld));
     HIPCHK(h, h->J.ensure(esz * 12 * ld));
     HIPCHK(h, h->cm_perm.ensure(sizeof(int) * ld));
@@ -1319,7 +1404,7 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     hipLaunchKernelGGL(k_build_cam_major, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, h->stream, h->cm_perm.as<int>(),
                        h->pt_idx.as<int>(), h->uv.as<double>(), h->f32 ? 1 : 0, (int)N, h->cm_pt.as<int>(),
                        h->cm_uv.as<double>());
-    HIPCHK(h, hipGetLastError());
+    LAUNCHED(h);
     tp3 = now_s();
     HIPCHK(h, hipStreamSynchronize(h->stream));     // the staging buffer is reused by the next call
     if (timing)
@@ -1353,7 +1438,7 @@ int sfmba_residual_jacobian(sfmba_handle* h, const double* x, double* r_out, dou
     HIPCHK(h, jp_rm.ensure(sizeof(double) * 6 * h->N));
     hipLaunchKernelGGL(k_unpack_jac, dim3((h->N + 255) / 256), dim3(256), 0, h->stream, h->J.as<double>(),
                        (int)h->N, h->ld, h->f32 ? 1 : 0, jc_rm.as<double>(), jp_rm.as<double>());
-    HIPCHK(h, hipGetLastError());
+    LAUNCHED(h);
     std::vector<double> tc(12 * h->N), tp(6 * h->N);
     CHK(download_residuals(h, r_out));
     HIPCHK(h, hipMemcpyAsync(tc.data(), jc_rm.p, sizeof(double) * 12 * h->N, hipMemcpyDeviceToHost, h->stream));
@@ -1408,7 +1493,7 @@ int sfmba_schur_matvec(sfmba_handle* h, const double* x, const double* dc, const
     hipLaunchKernelGGL(k_point_prep, dim3((h->P + 255) / 256), dim3(256), 0, h->stream, h->V.as<double>(),
                        h->gp.as<double>(), (const double*)nullptr, h->e.as<double>(), (int)h->P, 0.0,
                        h->Vinv.as<double>(), (double*)nullptr);
-    HIPCHK(h, hipGetLastError());
+    LAUNCHED(h);
     CHK(schur_product_standalone(h, h->vtmp.as<double>()));
     CHK(exchange(h, h->acc(), 6 * C, 0));
     std::vector<double> a(6 * C);
@@ -1434,7 +1519,7 @@ int sfmba_time_kernel(sfmba_handle* h, const double* x, int32_t which, int32_t r
         hipLaunchKernelGGL(k_point_prep, dim3((h->P + 255) / 256), dim3(256), 0, h->stream, h->V.as<double>(),
                            h->gp.as<double>(), h->si.as<double>() + 6 * h->C, (const double*)nullptr, (int)h->P,
                            1e-6, h->Vinv.as<double>(), h->e.as<double>());
-        HIPCHK(h, hipGetLastError());
+        LAUNCHED(h);
         // v = the camera slice of the gradient, as plane-major planes (and camera-major when v is not staged in LDS)
         hipLaunchKernelGGL(k_transpose, dim3((unsigned)((6 * h->C + 255) / 256)), dim3(256), 0, h->stream,
                            (const double*)h->g.as<double>(), (int)h->C, 6, h->vtmp.as<double>(), (const PcgCtrl*)nullptr, 0);
@@ -1455,7 +1540,7 @@ int sfmba_time_kernel(sfmba_handle* h, const double* x, int32_t which, int32_t r
             case 1: CHK((launch_resjac<false, false>(h, h->x, h->tab, &np))); break;
             case 2: CHK(launch_normal_blocks(h, h->x, h->tab)); break;
             case 3: CHK(schur_product_standalone(h, h->vtmp.as<double>())); break;
-            case 4: CHK(launch_point_sweep(h, h->lds_vec ? h->vtmp.as<double>() : h->vcm.as<double>(), nullptr, 0)); break;
+            case 4: CHK(launch_point_sweep(h, (h->lds_vec || h->sweep_rc) ? h->vtmp.as<double>() : h->vcm.as<double>(), nullptr, 0)); break;
             case 5: CHK(launch_cam_schur<0>(h, h->vtmp.as<double>(), h->z.as<double>(), nullptr, 0)); break;
             case 6: CHK(launch_cam_schur<1>(h, nullptr, h->e.as<double>(), nullptr, 0)); break;
             case 10:   // streaming-store ceiling: fill the Jacobian planes, 16 B per lane, one stream
@@ -1474,7 +1559,27 @@ int sfmba_time_kernel(sfmba_handle* h, const double* x, int32_t which, int32_t r
     return 0;
 }
 
+static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, sfmba_result* out);
+
 int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, sfmba_result* out) {
+    const int rc = solve_impl(h, x_inout, opt_in, out);
+    if (rc != 0 && h) {
+        // Leave the handle reusable: drain what was enqueued (speculative launches may still be in flight) and,
+        // after a collective failure, unmap the peers -- sequence numbers no longer agree across ranks, so the
+        // direct link is dead; the transport registered before it (RCCL / callback) serves later solves.
+        const std::string msg = h->err;
+        h->skip = nullptr; h->post = Mailbox{};
+        if (h->stream) (void)hipStreamSynchronize(h->stream);
+        if (rc == -5 && h->p2p.ready) {
+            p2p_close_peers(h);
+            if (h->p2p.words) (void)hipMemset(h->p2p.words, 0, 4 * sizeof(unsigned));
+        }
+        h->err = msg;
+    }
+    return rc;
+}
+
+static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, sfmba_result* out) {
     CHK(enter(h));
     CHK(check_ready(h, x_inout));
     if (!out) return fail(h, -1, "result is NULL");
@@ -1484,6 +1589,8 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
     h->solved = false;
     h->skip = nullptr; h->post = Mailbox{};
     h->pending_scale_sums = false;
+    h->p2p.first_in_solve = true;
+    if (h->dbg.p2p_delay_ms > 0) std::this_thread::sleep_for(std::chrono::milliseconds(h->dbg.p2p_delay_ms));
     const double t_begin = now_s();
     const int64_t C = h->C, P = h->P, n = h->n;
     const int64_t max_nfev = opt.max_nfev > 0 ? opt.max_nfev : 100 * (6 * C + 3 * P);
@@ -1557,7 +1664,7 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
     // nothing uses them before the next trial overwrites them, except the rare exits handled below.
     const bool pcg_debug = h->dbg.trace_pcg != 0;
     const int pcg_bias = h->dbg.pcg_guess_bias;                 // test hook (sfmba_debug_option)
-    if (opt.verbose >= 2) print_header();
+    if (opt.verbose >= 2) print_header(h);
 
     for (;;) {                                                  // trf.py:450
         if (!nb_valid) {                                        // a rejected trial overwrote the blocks and no
@@ -1598,7 +1705,7 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
                                h->V.as<double>(), h->gp.as<double>(), h->si.as<double>(), (int)C, (int)P, bc,
                                h->Dc.as<double>(), h->Minv.as<double>(), h->Vinv.as<double>(),
                                h->e.as<double>(), one_rank ? (const double*)h->partB() : (const double*)nullptr, np);
-            HIPCHK(h, hipGetLastError());
+            LAUNCHED(h);
         }
         CHK(launch_cam_schur<1>(h, nullptr, h->e.as<double>(), nullptr, 0));      // reduced rhs term -> acc
         CHK(exchange(h, h->acc(), 6 * C, 0));
@@ -1636,12 +1743,12 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
             hipLaunchKernelGGL(k_step_table, dim3(bc + grid_1d(3 * P, 256, 2048)), dim3(256), 0, h->stream, h->x,
                                h->sg.as<double>(), h->p.as<double>(), c1, c2, coef_dev, (int)C, n, bc, h->x_new,
                                h->tab_new, h->skip);
-            HIPCHK(h, hipGetLastError());
+            LAUNCHED(h);
             // the trial point is evaluated WITH its Jacobian, into the same buffers: when
             // the step is accepted (the common case) nothing has to be recomputed
             // The cost reduction that ends the evaluation also posts the hand-off (scalars + PCG control
             // block) into the host mailbox; with several ranks the post follows the all-reduce of the cost.
-            const Mailbox mb{h->mbox_dev, sc, h->ctrl.as<PcgCtrl>() + (h->pcg_L & 1), ++h->mbox_seq};
+            const Mailbox mb{h->mbox_dev, sc, h->ctrl.as<PcgCtrl>() + (h->pcg_L & 1), ++h->mbox_seq, p2p_error_word(h)};
             const bool ranks = multi_rank(h);
             if (ranks && h->p2p.ready) {
                 // direct path: ONE single-workgroup launch sums K1's cost partials, reduces the cost over the
@@ -1661,7 +1768,7 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
             CHK(exchange(h, sc, 1, 0));
             if (ranks) {
                 hipLaunchKernelGGL(k_post, dim3(1), dim3(64), 0, h->stream, mb);
-                HIPCHK(h, hipGetLastError());
+                LAUNCHED(h);
             }
             return 0;
         };
@@ -1684,7 +1791,7 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
             hipLaunchKernelGGL(k_tr_step, dim3(1), dim3(one_rank ? 1024 : 64), 0, h->stream, sc, Delta,
                                speculative ? (const PcgCtrl*)(h->ctrl.as<PcgCtrl>() + (h->pcg_L & 1)) : (const PcgCtrl*)nullptr,
                                one_rank ? backsub_rider(h, np_tail) : Piggyback{});
-            HIPCHK(h, hipGetLastError());
+            LAUNCHED(h);
             h->skip = sc + 30;                                  // k_tr_step's verdict gates every launch below
             int rc_trial = enqueue_trial(sc + 25, 0.0, 0.0);
             if (rc_trial == 0) rc_trial = handoff(speculative); // THE hand-off of this iteration
@@ -1716,7 +1823,7 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
         // ---- loop head of trf.py:450-459, evaluated now that the scalars are on the host -----------
         g_norm = std::max(h->h_scal[kMaxSlot], h->h_scal[kCamSlot + 0]);
         if (g_norm < opt.gtol) status = 1;
-        if (opt.verbose >= 2) print_iter(iteration, nfev, cost, have_red, actual_reduction, step_norm, g_norm);
+        if (opt.verbose >= 2) print_iter(h, iteration, nfev, cost, have_red, actual_reduction, step_norm, g_norm);
         if (status != -1 || nfev >= max_nfev || (opt.max_iter > 0 && iteration >= opt.max_iter)) break;
         pcg_total += hc.iters;
         if (pcg_debug)
@@ -1782,7 +1889,7 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
             }
             CHK(fetch_scalars(h));
             g_norm = std::max(h->h_scal[kMaxSlot], h->h_scal[kCamSlot + 0]);
-            if (opt.verbose >= 2) print_iter(iteration, nfev, cost, have_red, actual_reduction, step_norm, g_norm);
+            if (opt.verbose >= 2) print_iter(h, iteration, nfev, cost, have_red, actual_reduction, step_norm, g_norm);
             break;
         }
     }

@@ -19,7 +19,7 @@ SYMBOLS = (
     "sfmba_residual_jacobian", "sfmba_solve", "sfmba_get_fun_grad", "sfmba_time_kernel",
     "sfmba_normal_blocks", "sfmba_schur_matvec", "sfmba_comm_get_unique_id", "sfmba_comm_init",
     "sfmba_comm_destroy", "sfmba_set_precision", "sfmba_p2p_export", "sfmba_p2p_attach", "sfmba_p2p_detach",
-    "sfmba_p2p_calls", "sfmba_tr2d_solve", "sfmba_debug_option",
+    "sfmba_p2p_calls", "sfmba_tr2d_solve", "sfmba_debug_option", "sfmba_set_print", "sfmba_get_counters",
 )
 
 
@@ -40,6 +40,7 @@ class Result(C.Structure):
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32)
+PRINT_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p)
 
 _lib = None
 
@@ -85,6 +86,10 @@ def load():
     lib.sfmba_p2p_attach.argtypes = [P, P, C.c_int32, C.c_int32]
     lib.sfmba_p2p_detach.argtypes = [P]
     lib.sfmba_debug_option.argtypes = [P, C.c_char_p, C.c_int64]
+    lib.sfmba_get_counters.argtypes = [P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    lib.sfmba_get_counters.restype = C.c_int
+    lib.sfmba_set_print.argtypes = [P, PRINT_FN, P]
+    lib.sfmba_set_print.restype = C.c_int
     lib.sfmba_p2p_calls.argtypes = [P]
     lib.sfmba_p2p_calls.restype = C.c_int64
     for name in ("sfmba_set_stream", "sfmba_set_problem", "sfmba_set_problem_i64", "sfmba_set_exchange", "sfmba_residuals",

@@ -153,7 +153,7 @@ def least_squares(fun, x0, jac="2-point", bounds=(-np.inf, np.inf), method="trf"
                   gtol=1e-8, x_scale=1.0, loss="linear", f_scale=1.0, diff_step=None, tr_solver=None,
                   tr_options=None, jac_sparsity=None, max_nfev=None, verbose=0, args=(), kwargs=None,
                   device=0, max_iter=None, pcg_tol=None, profile=False, return_jac=False, storage_bits=64,
-                  check_fun=True):
+                  check_fun=True, backend=None):
     """Drop-in for the reference's ``least_squares(compute_residuals, x0, jac_sparsity=..., verbose=...,
     x_scale='jac', ftol=tol, method='trf', args=(...))`` (sfm.py:266-268).
 
@@ -169,6 +169,7 @@ def least_squares(fun, x0, jac="2-point", bounds=(-np.inf, np.inf), method="trf"
     ``result.x`` in scipy's CSR layout (2N x (6C+3P), 9 entries per row); by default it is ``None``
     because the reference only reads ``result.x`` (sfm.py:271,281).  ``storage_bits=32`` keeps the
     per-observation streams (pixels, residuals, Jacobian) in fp32 with fp64 arithmetic and accumulation.
+    ``backend``: a :class:`Backend` to run on instead of the calling thread's own (``device`` is then ignored).
     """
     if method != "trf":
         raise ValueError("sfmba.least_squares implements method='trf' only (the reference's choice).")
@@ -199,7 +200,7 @@ def least_squares(fun, x0, jac="2-point", bounds=(-np.inf, np.inf), method="trf"
     if check_fun and fun is not compute_residuals:
         _check_fun(fun, x0, int(n_cameras), int(n_points), camera_indices, point_indices, points_2d, K)
 
-    be = get_backend(device)
+    be = backend if backend is not None else get_backend(device)
     be.set_precision(storage_bits)
     be.set_problem(n_cameras, n_points, camera_indices, point_indices, points_2d, K)
     opt = be.default_options()
@@ -313,40 +314,55 @@ def _matrix_from_rotvec(w):
     return np.eye(3) + a * Wx + b * (Wx @ Wx)
 
 
-def pack_cameras_points(H_list, registered, X3d, observations):
+def pack_cameras_points(H_list, registered, X3d, observations, pose_convention="reference"):
     """What sfm.py:248-262 builds from the graph: ``observations`` iterates
     (point_idx, cam_id, (x, y)) in ``Graph.pt3ds_pt2ds`` order; ``H_list[k]`` / ``registered[k]``
-    describe node k.  T is ``H[:3, 3]`` verbatim (the reference's convention)."""
+    describe node k.
+
+    ``pose_convention="reference"`` (default) copies ``T = H[:3, 3]`` verbatim, as the reference does
+    (sfm.py:252,255) although its residual treats T as the camera CENTRE (bundle_adjustment.py:27,
+    SURVEY.md section 3.4).  ``"rt"`` is the consistent reading of ``H = [R | t]`` with ``x_cam = R X + t``
+    (sfm.py:135,212): the centre ``-R^T t`` is handed to the model, and :func:`unpack_cameras_points` maps
+    it back."""
+    if pose_convention not in ("reference", "rt"):
+        raise ValueError("pose_convention must be 'reference' or 'rt'")
     data = list(observations)
     pt_indices = np.array([d[0] for d in data])
     cam_ids = [d[1] for d in data]
     pt2ds = np.array([d[2] for d in data])
     reg = [k for k, f in enumerate(registered) if f]
     camera_map = {k: i for i, k in enumerate(reg)}
-    params = [np.hstack([_rotvec_from_matrix(np.asarray(H_list[k])[:3, :3]),
-                         np.asarray(H_list[k], dtype=np.float64)[:3, 3].flatten()]) for k in reg]
+    params = []
+    for k in reg:
+        H = np.asarray(H_list[k], dtype=np.float64)
+        T = H[:3, 3].flatten() if pose_convention == "reference" else -H[:3, :3].T @ H[:3, 3]
+        params.append(np.hstack([_rotvec_from_matrix(H[:3, :3]), T]))
     camera_indices = np.array([camera_map[c] for c in cam_ids])
     X3d = np.asarray(X3d, dtype=np.float64)
     x0 = np.hstack([np.hstack(params).ravel(), X3d.ravel()])
     return x0, len(reg), len(X3d), camera_indices, pt_indices, pt2ds, camera_map
 
 
-def unpack_cameras_points(x, n_cam, n_points, camera_map, H_list):
+def unpack_cameras_points(x, n_cam, n_points, camera_map, H_list, pose_convention="reference"):
     """sfm.py:271-281: new 4x4 poses for the registered cameras and the (n_points, 3) cloud."""
     cams = np.asarray(x[:n_cam * 6]).reshape((n_cam, 6))
     H_out = [np.array(H, dtype=np.float64, copy=True) for H in H_list]
     for cam_id, k in camera_map.items():
         H = np.eye(4)
         H[:3, :3] = _matrix_from_rotvec(cams[k, :3])
-        H[:3, 3] = cams[k, 3:]
+        H[:3, 3] = cams[k, 3:] if pose_convention == "reference" else -H[:3, :3] @ cams[k, 3:]
         H_out[cam_id] = H
     return H_out, np.asarray(x[n_cam * 6:]).reshape((n_points, 3))
 
 
-def apply_bundle_adjustment(H_list, registered, X3d, observations, K, tol=1e-10, verbose=2, device=0):
-    """The whole of ``SFM._apply_bundle_adjustment`` (sfm.py:243-281) on plain arrays."""
-    x0, n_cam, n_points, ci, pi, uv, cmap = pack_cameras_points(H_list, registered, X3d, observations)
-    jac_sparsity = None    # the reference builds one (sfm.py:264); its content is implied by ci, pi
+def apply_bundle_adjustment(H_list, registered, X3d, observations, K, tol=1e-10, verbose=2, device=0,
+                            pose_convention="reference"):
+    """The whole of ``SFM._apply_bundle_adjustment`` (sfm.py:243-281) on plain arrays: pack, the sparsity
+    pattern of sfm.py:264 (built lazily: the solver reads its shape only), the ``least_squares`` call of
+    sfm.py:266-268, unpack."""
+    x0, n_cam, n_points, ci, pi, uv, cmap = pack_cameras_points(H_list, registered, X3d, observations,
+                                                                pose_convention)
+    jac_sparsity = create_sparsity_matrix(n_cam, n_points, len(ci), ci, pi)
     res = least_squares(compute_residuals, x0, jac_sparsity=jac_sparsity, verbose=verbose, x_scale="jac",
                         ftol=tol, method="trf", args=(n_cam, n_points, ci, pi, uv, K), device=device)
-    return unpack_cameras_points(res.x, n_cam, n_points, cmap, H_list) + (res,)
+    return unpack_cameras_points(res.x, n_cam, n_points, cmap, H_list, pose_convention) + (res,)

@@ -34,6 +34,10 @@ class Backend:
         self.device = int(device)
         self.n_cameras = self.n_points = self.n_obs = 0
         self._keep = []          # arrays / callbacks the library borrows beyond one call
+        # the verbose = 2 iteration table goes through Python's sys.stdout, like scipy's print() calls
+        # (looked up at call time, so contextlib.redirect_stdout and notebook capture see it)
+        self._print_cb = _capi.PRINT_FN(lambda ctx, line: print(line.decode("utf-8", "replace")))
+        self._lib.sfmba_set_print(self._h, self._print_cb, None)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -153,6 +157,12 @@ class Backend:
 
     def p2p_detach(self):
         self._check(self._lib.sfmba_p2p_detach(self._h))
+
+    def counters(self):
+        """(kernel launches, collectives) enqueued by this handle so far."""
+        a, b = C.c_int64(), C.c_int64()
+        self._lib.sfmba_get_counters(self._h, C.byref(a), C.byref(b))
+        return int(a.value), int(b.value)
 
     def p2p_calls(self) -> int:
         return int(self._lib.sfmba_p2p_calls(self._h))

@@ -1,0 +1,229 @@
+"""GPU tests of the drop-in surface around the solver: the functions a maintainer of the reference would rebind
+(`project_points`, `_apply_bundle_adjustment`, the verbose table, `load_calibration_data`) and the calling
+conventions of include/sfmba.h (threads, int64 pixels).  Reference lines are cited per test."""
+import contextlib
+import io
+import json
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import ba_oracle
+    return ba_oracle
+
+
+def test_project_points_matches_oracle_and_reference_fixtures(orc):
+    """sfmba.project_points <-> /root/reference/sfm_lite/bundle_adjustment.py:20-32 (one camera row per point).
+    Checked against the oracle's per-observation loop and, through residual + uv, against every residual
+    fixture captured from the reference."""
+    import sfmba
+    rng = np.random.default_rng(5)
+    n = 257
+    pts = rng.normal(size=(n, 3)) + np.array([0.0, 0.0, 10.0])
+    cams = np.hstack([rng.normal(0, 0.3, (n, 3)), rng.normal(0, 0.5, (n, 3))])
+    cams[0, :3] = 0.0                                    # theta = 0: series branch
+    cams[1, :3] = np.array([np.pi, 0.0, 0.0]) * (1 - 1e-9)
+    for K in (sfmba.K_SCEAUX, np.array([[1000.0, 2.5, 500.0], [0.1, 990.0, 400.0], [1e-4, -2e-4, 1.0]])):
+        got = sfmba.project_points(pts, cams, K)
+        ref = np.asarray(orc.project_points_loop(pts, cams, K))
+        assert got.shape == (n, 2)
+        assert np.abs(got - ref).max() <= 1e-11 * max(3000.0, np.abs(ref).max())
+    g = np.load(os.path.join(GOLDEN, "residual_cases.npz"))
+    for k in range(int(g["n_cases"])):
+        pre = f"c{k:02d}_"
+        C, P, N = (int(v) for v in g[pre + "dims"])
+        x, ci, pi = g[pre + "x"], g[pre + "ci"], g[pre + "pi"]
+        cam_rows = x[:6 * C].reshape(C, 6)[ci]
+        pt_rows = x[6 * C:].reshape(P, 3)[pi]
+        proj = sfmba.project_points(pt_rows, cam_rows, g[pre + "K"])
+        ref = g[pre + "r"].reshape(N, 2) + g[pre + "uv"]           # reference residual + pixels = its projection
+        assert np.abs(proj - ref).max() <= 1e-11 * max(3000.0, np.abs(ref).max()), str(g[pre + "tag"])
+
+
+def _synthetic_graph(seed=3, n_nodes=7, n_points=60):
+    """What SFM._apply_bundle_adjustment reads from its graph (sfm.py:248-256): 4x4 poses, registered flags,
+    the cloud, and (point, camera, pixel) tuples in Graph.pt3ds_pt2ds order (graph.py:186-191), with node 2
+    unregistered and one (camera, point) pair seen twice (track sets merge, graph.py:86)."""
+    import sfmba
+    from sfmba import api
+    rng = np.random.default_rng(seed)
+    registered = [True] * n_nodes
+    registered[2] = False
+    H_list = []
+    for k in range(n_nodes):
+        H = np.eye(4)
+        H[:3, :3] = api._matrix_from_rotvec(rng.normal(0, 0.15, 3))
+        H[:3, 3] = rng.normal(0, 0.4, 3)
+        H_list.append(H)
+    X3d = rng.normal(size=(n_points, 3)) + np.array([0.0, 0.0, 9.0])
+    K = sfmba.K_SCEAUX
+    obs = []
+    for p in range(n_points):
+        cams = [c for c in rng.permutation(n_nodes)[:rng.integers(2, n_nodes)] if registered[c]]
+        if p == 5:
+            cams = cams + [cams[0]]                      # duplicated (camera, point) pair
+        for c in sorted(cams):
+            R, T = H_list[c][:3, :3], H_list[c][:3, 3]
+            q = K @ (R @ (X3d[p] - T))                   # the BA model: T is the camera centre (bundle_adjustment.py:27)
+            uv = np.trunc(q[:2] / q[2] + rng.normal(0, 0.5, 2)).astype(np.int64)     # integer pixels, graph.py:112
+            obs.append((p, c, uv))
+    H0 = [H.copy() for H in H_list]
+    for k in range(n_nodes):                             # perturbed start
+        H0[k][:3, :3] = api._matrix_from_rotvec(api._rotvec_from_matrix(H_list[k][:3, :3]) + rng.normal(0, 0.01, 3))
+        H0[k][:3, 3] += rng.normal(0, 0.01, 3)
+    return H0, registered, X3d + rng.normal(0, 0.01, X3d.shape), obs, K
+
+
+def test_apply_bundle_adjustment_end_to_end(orc):
+    """sfmba.apply_bundle_adjustment <-> SFM._apply_bundle_adjustment (/root/reference/sfm_lite/sfm.py:243-281),
+    against the oracle's pack_problem -> trf_schur -> unpack_result on the same graph."""
+    import sfmba
+    H0, registered, X0, obs, K = _synthetic_graph()
+    x0, n_cam, n_pts, ci, pi, uv, cmap = orc.pack_problem(H0, registered, X0, obs)
+    px0, pn_cam, pn_pts, pci, ppi, puv, pcmap = sfmba.pack_cameras_points(H0, registered, X0, obs)
+    assert (pn_cam, pn_pts, pcmap) == (n_cam, n_pts, cmap) and n_cam == 6
+    assert np.array_equal(pci, ci) and np.array_equal(ppi, pi) and np.array_equal(puv, uv)
+    assert np.abs(px0 - x0).max() < 1e-13
+    o = orc.trf_schur(x0, n_cam, n_pts, ci, pi, uv, K, ftol=1e-10, linear="pcg", pcg_tol=1e-3)
+    H_ref, X_ref = orc.unpack_result(o.x, n_cam, n_pts, cmap, H0)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        H_new, X_new, res = sfmba.apply_bundle_adjustment(H0, registered, X0, obs, K, tol=1e-10, verbose=2)
+    assert "Iteration" in buf.getvalue() and "termination condition is satisfied" in buf.getvalue()
+    assert (res.status, res.nfev, res.njev) == (o.status, o.nfev, o.njev)
+    assert abs(res.cost - o.cost) <= 1e-9 * o.cost
+    assert np.array_equal(H_new[2], H0[2])                        # the unregistered node keeps its pose
+    for k in range(len(H0)):
+        assert np.abs(H_new[k] - H_ref[k]).max() < 1e-6
+        if registered[k]:
+            R = H_new[k][:3, :3]
+            assert np.abs(R @ R.T - np.eye(3)).max() < 1e-12 and np.array_equal(H_new[k][3], [0, 0, 0, 1])
+    assert np.abs(X_new - X_ref).max() < 1e-6
+
+
+def test_verbose_table_matches_scipy_format():
+    """verbose=2 (forwarded at sfm.py:266): header and rows are scipy's print_header_nonlinear /
+    print_iteration_nonlinear (SCIPY/optimize/_lsq/common.py:545-563) character for character, reach Python's
+    sys.stdout in order with the verbose>=1 summary (least_squares.py:966-970), and row 0 carries the values of
+    the recorded scipy run on the same problem."""
+    import sfmba
+    from scipy.optimize._lsq import common as sc_common
+    rec = json.load(open(os.path.join(GOLDEN, "scipy_cfg2_run.json")))
+    pb = sfmba.make_config("cfg2")
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        res = sfmba.least_squares(sfmba.compute_residuals, pb.x0, x_scale="jac", ftol=1e-10, method="trf",
+                                  args=pb.args, verbose=2)
+    lines = buf.getvalue().splitlines()
+    hdr = io.StringIO()
+    with contextlib.redirect_stdout(hdr):
+        sc_common.print_header_nonlinear()
+    assert lines[0] == hdr.getvalue().rstrip("\n")
+    rows = lines[1:-2]
+    assert len(rows) == res.iterations + 1 and all(len(r) == 90 for r in rows)
+    assert lines[-2] == res.message
+    assert lines[-1] == (f"Function evaluations {res.nfev}, initial cost {res.cost0:.4e}, final cost "
+                         f"{res.cost:.4e}, first-order optimality {res.optimality:.2e}.")
+    for k, row in enumerate(rows):
+        cols = [row[15 * j:15 * (j + 1)].strip() for j in range(6)]
+        it, nfev, cost, opt = int(cols[0]), int(cols[1]), float(cols[2]), float(cols[5])
+        red = float(cols[3]) if cols[3] else None
+        step = float(cols[4]) if cols[4] else None
+        assert it == k and (k == 0) == (red is None) == (step is None)
+        again = io.StringIO()
+        with contextlib.redirect_stdout(again):
+            sc_common.print_iteration_nonlinear(it, nfev, cost, red, step, opt)
+        assert again.getvalue().rstrip("\n") == row               # same widths, centring and number formats
+    # iteration 0 is evaluated at x0 by both: same cost and first-order optimality as scipy recorded
+    t0 = rec["table"][0]
+    c0 = [rows[0][15 * j:15 * (j + 1)].strip() for j in range(6)]
+    assert (int(c0[0]), int(c0[1])) == (int(t0[0]), int(t0[1]))
+    assert abs(float(c0[2]) - t0[2]) <= 1e-3 * t0[2] and abs(float(c0[5]) - t0[3]) <= 1e-2 * t0[3]
+    assert float(rows[-1][30:45]) <= rec["cost"] * (1 + 1e-4)
+
+
+def test_solve_from_worker_thread_while_main_thread_holds_a_backend():
+    """The reference's GUI runs BA in a threading.Thread (/root/reference/app.py:80-85,109); include/sfmba.h:
+    one handle per thread, any thread may call.  The main thread keeps its own Backend (with a problem set)
+    while a worker solves; both results equal the single-threaded ones."""
+    import sfmba
+    pb_main = sfmba.make_problem(5, 40, 300, seed=4)
+    pb_work = sfmba.make_problem(6, 80, 500, seed=12)
+    ref_main = sfmba.least_squares(sfmba.compute_residuals, pb_main.x0, x_scale="jac", ftol=1e-10, method="trf",
+                                   args=pb_main.args)
+    ref_work = sfmba.least_squares(sfmba.compute_residuals, pb_work.x0, x_scale="jac", ftol=1e-10, method="trf",
+                                   args=pb_work.args)
+    main_be = sfmba.get_backend(0)
+    main_be.set_problem(*pb_main.args)
+    out = {}
+
+    def worker():
+        try:
+            out["be_id"] = id(sfmba.get_backend(0))
+            out["res"] = sfmba.least_squares(sfmba.compute_residuals, pb_work.x0, x_scale="jac", ftol=1e-10,
+                                             method="trf", args=pb_work.args)
+        except Exception as exc:                                   # noqa: BLE001
+            out["exc"] = exc
+
+    t = threading.Thread(target=worker)
+    t.start()
+    r_main = main_be.residuals(pb_main.x0)                        # the main thread's handle is used meanwhile
+    t.join(timeout=120)
+    assert not t.is_alive() and "exc" not in out, out.get("exc")
+    assert out["be_id"] != id(main_be)                            # a handle of its own
+    assert np.array_equal(out["res"].x, ref_work.x) and out["res"].cost == ref_work.cost
+    again = sfmba.least_squares(sfmba.compute_residuals, pb_main.x0, x_scale="jac", ftol=1e-10, method="trf",
+                                args=pb_main.args)
+    assert np.array_equal(again.x, ref_main.x)
+    assert np.abs(r_main - sfmba.compute_residuals(pb_main.x0, *pb_main.args)).max() == 0.0
+
+
+def test_load_calibration_data(tmp_path):
+    """sfmba.load_calibration_data <-> /root/reference/sfm_lite/utils.py:24-35: 3x3 whitespace-separated text,
+    shape assert included."""
+    import sfmba
+    f = tmp_path / "K.txt"
+    f.write_text("2905.88 0 1416\n0 2905.88 1064\n0 0 1\n")
+    K = sfmba.load_calibration_data(str(f))
+    assert K.dtype == np.float64 and np.array_equal(K, sfmba.K_SCEAUX)
+    pb = sfmba.make_problem(3, 8, 20, seed=0)
+    r = sfmba.compute_residuals(pb.x0, pb.n_cameras, pb.n_points, pb.camera_indices, pb.point_indices, pb.points_2d, K)
+    assert np.array_equal(r, sfmba.compute_residuals(pb.x0, *pb.args))
+    bad = tmp_path / "bad.txt"
+    bad.write_text("1 2 3\n4 5 6\n")
+    with pytest.raises(AssertionError):
+        sfmba.load_calibration_data(str(bad))
+
+
+def test_int64_pixels_entry_equals_float_entry():
+    """sfmba_set_problem_i64 (the reference's own int64 pixel arrays, graph.py:112-113) and sfmba_set_problem
+    (float64 pixels) are the same problem: bitwise equal residuals, Jacobian, blocks and solve."""
+    import sfmba
+    pb = sfmba.make_problem(7, 90, 700, seed=8)
+    assert pb.points_2d.dtype == np.int64
+    a, b = sfmba.Backend(0), sfmba.Backend(0)
+    try:
+        a.set_problem(pb.n_cameras, pb.n_points, pb.camera_indices, pb.point_indices, pb.points_2d, pb.K)
+        b.set_problem(pb.n_cameras, pb.n_points, pb.camera_indices, pb.point_indices,
+                      pb.points_2d.astype(np.float64), pb.K)
+        for u, v in zip(a.residual_jacobian(pb.x0), b.residual_jacobian(pb.x0)):
+            assert np.array_equal(u, v)
+        for u, v in zip(a.normal_blocks(pb.x0), b.normal_blocks(pb.x0)):
+            assert np.array_equal(u, v)
+        opt = a.default_options()
+        opt.ftol = 1e-10
+        xa, ra, fa, ga = a.solve(pb.x0, opt)
+        xb, rb, fb, gb = b.solve(pb.x0, opt)
+        assert np.array_equal(xa, xb) and ra.cost == rb.cost and np.array_equal(fa, fb) and np.array_equal(ga, gb)
+    finally:
+        a.close()
+        b.close()

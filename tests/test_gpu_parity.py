@@ -220,21 +220,23 @@ def dbg():
             b.debug_option(name, value)
             touched.append((b, name))
     yield set_
-    defaults = dict(pcg_fused=-1, tab_lds=-1, vec_lds=-1, cam_chunk=0, pcg_guess_bias=0)
+    defaults = dict(pcg_fused=-1, tab_lds=-1, vec_lds=-1, cam_chunk=0, pcg_guess_bias=0, sweep_rc=-1)
     for b, name in touched:
         b.debug_option(name, defaults[name])
 
 
 def test_operand_placements_and_camera_chunking(be, orc, dbg):
-    """Placements of the camera-sized operands (camera table / camera vector in LDS or gathered from L2) and
-    the chunking of the camera-major passes (one chunk per camera, written directly; several chunks, combined
-    by k_cam_combine) give the same blocks, the same product and the same solve."""
+    """The two forms of pass A (recomputing from the LDS table R|T|a'|u_T; reading the stored Jacobian, with the
+    camera vector in LDS or gathered from L2), the placement of the camera table, and the chunking of the
+    camera-major passes (one chunk per camera, written directly; several chunks, combined by k_cam_combine) give
+    the same blocks, the same product and the same solve."""
     import sfmba
     pb = sfmba.make_problem(40, 400, 5000, seed=3)
     tls = sfmba.get_backend(0)
     ref = None
-    for tab_lds, vec_lds, chunk in ((-1, -1, 0), (0, -1, 0), (-1, 0, 0), (-1, -1, 64), (0, 0, 50)):
-        for name, v in (("tab_lds", tab_lds), ("vec_lds", vec_lds), ("cam_chunk", chunk)):
+    for tab_lds, vec_lds, chunk, rc in ((-1, -1, 0, -1), (-1, -1, 0, 0), (0, -1, 0, 0), (-1, 0, 0, 0), (-1, -1, 64, -1),
+                                        (0, 0, 50, 0)):
+        for name, v in (("tab_lds", tab_lds), ("vec_lds", vec_lds), ("cam_chunk", chunk), ("sweep_rc", rc)):
             dbg((be, tls), name, v)
         nb = _blocks_case(be, orc, pb)
         y = _matvec_case(be, orc, pb, nb)
@@ -242,9 +244,9 @@ def test_operand_placements_and_camera_chunking(be, orc, dbg):
                                   args=pb.args)
         if ref is None:
             ref = (y, res)
-        assert _rel(y, ref[0]) < 1e-12
+        assert _rel(y, ref[0]) < 1e-11
         assert (res.status, res.nfev) == (ref[1].status, ref[1].nfev)
-        assert abs(res.cost - ref[1].cost) <= 1e-11 * ref[1].cost
+        assert abs(res.cost - ref[1].cost) <= 1e-10 * ref[1].cost
 
 
 def test_results_are_bitwise_reproducible(be):
@@ -368,22 +370,24 @@ def test_fused_pcg_launch_equals_sweep_plus_update(dbg):
     tls = sfmba.get_backend(0)
     for pb in (sfmba.make_config("cfg2"), sfmba.make_problem(300, 4000, 30000, seed=3),
                sfmba.make_problem(6, 80, 500, seed=5, x0_noise=0.2), sfmba.make_problem(1024, 3000, 20000, seed=8)):
-        runs = []
-        for flag in (-1, 0):
-            dbg((tls,), "pcg_fused", flag)
-            runs.append(sfmba.least_squares(sfmba.compute_residuals, pb.x0, x_scale="jac", ftol=1e-10,
-                                            method="trf", args=pb.args))
-        a, b = runs
-        assert (a.status, a.nfev, a.njev, a.pcg_iterations) == (b.status, b.nfev, b.njev, b.pcg_iterations)
-        assert abs(a.cost - b.cost) <= 1e-12 * a.cost
-        assert np.abs(a.x - b.x).max() <= 1e-9 * np.abs(a.x).max()         # the two forms sum their dot products in
+        for rc in (-1, 0):
+            dbg((tls,), "sweep_rc", rc)
+            runs = []
+            for flag in (-1, 0):
+                dbg((tls,), "pcg_fused", flag)
+                runs.append(sfmba.least_squares(sfmba.compute_residuals, pb.x0, x_scale="jac", ftol=1e-10,
+                                                method="trf", args=pb.args))
+            a, b = runs
+            assert (a.status, a.nfev, a.njev, a.pcg_iterations) == (b.status, b.nfev, b.njev, b.pcg_iterations)
+            assert abs(a.cost - b.cost) <= 1e-12 * a.cost
+            assert np.abs(a.x - b.x).max() <= 1e-9 * np.abs(a.x).max()     # the two forms sum their dot products in
                                                                            # different (fixed) orders
 
 
 def test_full_solves_with_many_cameras_vs_oracle(orc):
-    """Camera counts past the single-launch PCG and the LDS-resident tables, end to end: 1300 cameras (camera
-    table of K1 read from L2, normal blocks in three column passes, sweep + k_pcg_update as two kernels) and
-    1800 (accumulator of a camera range in LDS, vector gathered from the camera-major copy)."""
+    """Camera counts past the fused PCG launch, the recomputing pass A and the LDS-resident camera table, end to
+    end: 1300 and 1800 cameras (camera table of K1 read from L2, pass A reading the stored Jacobian, k_pcg_update
+    as a kernel of its own)."""
     import sfmba
     for C, P, N in ((1300, 4000, 40000), (1800, 3000, 30000)):
         pb = sfmba.make_problem(C, P, N, seed=21)

@@ -174,3 +174,28 @@ def test_pack_unpack_mirror_matches_scipy_rotations():
     H2, X2 = sfmba.unpack_cameras_points(x0, nc, npnt, cmap, H)
     assert all(np.allclose(a, b, atol=1e-12) for a, b in zip(H2, H))
     assert np.array_equal(X2, X3d)
+
+
+def test_pack_unpack_rt_convention_round_trip():
+    """pose_convention='rt' (SURVEY.md section 8f-1): H = [R | t] with x_cam = R X + t (sfm.py:135,212) is handed
+    to the model as the camera centre -R^T t, so that the BA residual IS the pipeline's reprojection error
+    (cv2_lite/solve_pnp.py:9-15); 'reference' keeps the reference's verbatim copy (sfm.py:252)."""
+    import sfmba
+    from oracle import ba_oracle as orc
+    g = np.load(os.path.join(GOLDEN, "pack_cases.npz"))
+    H = g["H"][4:8]
+    registered = [True, True, False, True]
+    X3d = np.random.default_rng(0).normal(size=(6, 3)) + np.array([0.0, 0.0, 8.0])
+    obs = [(p, c, (3 * p + c, 7 * p - c)) for p in range(6) for c in (0, 1, 3)]
+    x0, nc, npnt, ci, pi, uv, cmap = sfmba.pack_cameras_points(H, registered, X3d, obs, pose_convention="rt")
+    for cam_id, n in cmap.items():
+        R, t = H[cam_id][:3, :3], H[cam_id][:3, 3]
+        assert np.allclose(x0[6 * n + 3:6 * n + 6], -R.T @ t, atol=1e-13)
+    r = orc.compute_residuals(x0, nc, npnt, ci, pi, uv, sfmba.K_SCEAUX).reshape(-1, 2)
+    for k, (p, c, px) in enumerate(obs):                       # K (R X + t) projected minus the pixel
+        q = sfmba.K_SCEAUX @ (H[c][:3, :3] @ X3d[p] + H[c][:3, 3])
+        assert np.allclose(r[k], q[:2] / q[2] - np.asarray(px, dtype=float), atol=1e-9)
+    H2, X2 = sfmba.unpack_cameras_points(x0, nc, npnt, cmap, H, pose_convention="rt")
+    assert all(np.allclose(a, b, atol=1e-12) for a, b in zip(H2, H)) and np.array_equal(X2, X3d)
+    with pytest.raises(ValueError):
+        sfmba.pack_cameras_points(H, registered, X3d, obs, pose_convention="centre")
