@@ -89,26 +89,46 @@ def cpu_baseline(workload_dims, seconds_budget=25.0):
 
 def per_call_times(workload, storage_bits):
     """What a user of the drop-in sees: wall time of ONE sfmba.least_squares(...) call with the reference's
-    kwargs (sfm.py:266-268) -- argument conversion, set_problem (structure tables + upload), solve, download of
-    x / fun / grad -- for the bench workload and for the SceauxCastle-scale problem the reference itself
-    produces.  `cold`: first call on a fresh handle (allocations, code-object load); `warm`: median of the
-    following calls with the same arrays (every call still rebuilds and re-uploads the problem, as the
-    reference does once per fused edge, sfm.py:59-71)."""
+    kwargs (sfm.py:266-268) -- argument conversion, set_problem (conversion, structure tables, upload), solve,
+    download of x / fun / grad -- for the bench workload and for the SceauxCastle-scale problem the reference itself
+    produces.  The reference calls BA once per fused edge on a growing problem (sfm.py:59-71), so three warm cases
+    are timed besides the cold first call of a handle: `rebuilt` -- the previous problem of the handle differs from
+    the first observation on (everything is converted and uploaded again); `grown` -- the previous problem was the
+    first 99 % of the points of this one (an edge that only triangulates new points: the prefix is re-used, the tail
+    uploaded); `same` -- identical arrays (e.g. a second BA pass)."""
     import sfmba
     out = {}
     for name in dict.fromkeys([workload, "cfg2"]):
         pb = sfmba.make_config(name)
+        n_head = int(np.searchsorted(pb.point_indices, int(0.99 * pb.n_points), side="left"))
+        p_head = int(0.99 * pb.n_points)
+        head_args = (pb.n_cameras, p_head, pb.camera_indices[:n_head], pb.point_indices[:n_head], pb.points_2d[:n_head], pb.K)
+        head_x0 = pb.x0[:6 * pb.n_cameras + 3 * p_head]
+        other_uv = pb.points_2d.copy()
+        other_uv[0, 0] += 1                                   # differs from the first observation on
+        other_args = pb.args[:4] + (other_uv, pb.K)
         be = sfmba.Backend(0)
-        times = []
-        for k in range(6):
+
+        def call(x0, args):
             t = time.perf_counter()
-            res = sfmba.least_squares(sfmba.compute_residuals, pb.x0, jac_sparsity=None, verbose=0, x_scale="jac",
-                                      ftol=1e-10, method="trf", args=pb.args, storage_bits=storage_bits, backend=be)
-            times.append(1e3 * (time.perf_counter() - t))
-        warm = sorted(times[1:])[len(times[1:]) // 2]
-        out[name] = {"cold": round(times[0], 3), "warm": round(warm, 3), "iterations": int(res.iterations),
-                     "solve_only": round(1e3 * float(res.seconds), 3),
-                     "iterations_per_s_per_call": round(res.iterations / (1e-3 * warm), 1)}
+            res = sfmba.least_squares(sfmba.compute_residuals, x0, jac_sparsity=None, verbose=0, x_scale="jac",
+                                      ftol=1e-10, method="trf", args=args, storage_bits=storage_bits, backend=be)
+            return 1e3 * (time.perf_counter() - t), res, be.problem_reuse()[0]
+
+        cold, res, _ = call(pb.x0, pb.args)
+        rebuilt, grown, same, reused_grown = [], [], [], 0
+        for k in range(5):
+            call(pb.x0, other_args)
+            rebuilt.append(call(pb.x0, pb.args)[0])
+            call(head_x0, head_args)
+            t, res, reused_grown = call(pb.x0, pb.args)
+            grown.append(t)
+            same.append(call(pb.x0, pb.args)[0])
+        med = lambda v: round(sorted(v)[len(v) // 2], 3)      # noqa: E731
+        out[name] = {"cold": round(cold, 3), "rebuilt": med(rebuilt), "grown": med(grown), "same": med(same),
+                     "observations_reused_when_grown": int(reused_grown), "n_obs": pb.n_obs,
+                     "iterations": int(res.iterations), "solve_only": round(1e3 * float(res.seconds), 3),
+                     "iterations_per_s_per_call_rebuilt": round(res.iterations / (1e-3 * med(rebuilt)), 1)}
         be.close()
     return out
 

@@ -113,6 +113,13 @@ int  sfmba_set_precision(sfmba_handle* h, int32_t storage_bits);
 int  sfmba_set_problem(sfmba_handle* h, int64_t n_cameras, int64_t n_points, int64_t n_obs,
                        const int64_t* camera_indices, const int64_t* point_indices,
                        const double* points_2d, const double* K);
+/* Incremental re-use: the reference calls BA once per fused edge on a growing reconstruction
+ * (/root/reference/sfm_lite/sfm.py:59-71); once all cameras are registered a new edge only appends points and
+ * observations, so the arrays of one call start with those of the previous call.  Every sfmba_set_problem compares the
+ * arrays with the previous problem of the handle (kept converted in pinned memory and in HBM), finds the first
+ * observation that differs and uploads from there on only; structure tables are always rebuilt from the complete
+ * arrays, so results are bitwise those of a fresh handle.  sfmba_problem_reuse reports what the last call re-used. */
+int  sfmba_problem_reuse(const sfmba_handle* h, int64_t* obs_reused, int64_t* obs_uploaded);
 /* Same with the pixels as the reference holds them, (N,2) int64 (graph.py:112-113): saves the caller a
  * converted copy. */
 int  sfmba_set_problem_i64(sfmba_handle* h, int64_t n_cameras, int64_t n_points, int64_t n_obs,

@@ -21,6 +21,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <numeric>
 #include <string>
 #include <thread>
@@ -61,7 +64,102 @@ struct DevBuf {
         if (e == hipSuccess) bytes = n;
         return e;
     }
+    // grow-only like ensure(), but the first `keep` bytes survive a reallocation (device-to-device copy) and the new
+    // block has headroom, so that a problem that grows call by call does not reallocate every time
+    hipError_t ensure_keep(size_t n, size_t keep) {
+        if (n <= bytes && p) return hipSuccess;
+        if (keep == 0 || !p) return ensure(n + n / 2);
+        void* q = nullptr;
+        const size_t cap = n + n / 2;
+        hipError_t e = hipMalloc(&q, cap);
+        if (e != hipSuccess) return e;
+        e = hipMemcpy(q, p, std::min(keep, bytes), hipMemcpyDeviceToDevice);
+        (void)hipFree(p);
+        p = q; bytes = cap;
+        return e;
+    }
     template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+// pinned host memory, grow-only, optionally keeping a prefix across a reallocation
+struct PinnedBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+    hipError_t ensure(size_t n, size_t keep) {
+        if (n <= bytes && p) return hipSuccess;
+        void* q = nullptr;
+        const size_t cap = n + n / 2 + 64;
+        hipError_t e = hipHostMalloc(&q, cap, hipHostMallocDefault);
+        if (e != hipSuccess) return e;
+        if (p && keep) memcpy(q, p, std::min(keep, bytes));
+        if (p) (void)hipHostFree(p);
+        p = q; bytes = cap;
+        return hipSuccess;
+    }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+// A few persistent host threads for set_problem's passes over the observation arrays (spawning threads per
+// call cost more than the passes themselves at a million observations).  run(parts, fn) calls fn(0..parts-1),
+// part 0 on the calling thread, and returns when all are done.
+class HostPool {
+public:
+    static constexpr int kMax = 8;
+    ~HostPool() {
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; ++gen_; }
+        cv_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    int parts_for(int64_t n) const {
+        const int hw = (int)std::thread::hardware_concurrency();
+        return (int)std::max<int64_t>(1, std::min<int64_t>(std::min(kMax, hw > 0 ? hw : 1), n / 65536));
+    }
+    template <class Fn>
+    void run(int parts, Fn fn) {
+        if (parts <= 1) { fn(0); return; }
+        while ((int)th_.size() < parts - 1) {
+            const int id = (int)th_.size() + 1;
+            th_.emplace_back([this, id] { worker(id); });
+        }
+        std::function<void(int)> f = fn;
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            job_ = &f; job_parts_ = parts; pending_ = parts - 1; ++gen_;
+        }
+        cv_.notify_all();
+        fn(0);
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [this] { return pending_ == 0; });
+        job_ = nullptr;
+    }
+private:
+    void worker(int id) {
+        unsigned long long seen = 0;
+        for (;;) {
+            std::function<void(int)>* f = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
+                if (id >= job_parts_ || job_ == nullptr) continue;
+                f = job_;
+            }
+            (*f)(id);
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                if (--pending_ == 0) done_.notify_one();
+            }
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    std::function<void(int)>* job_ = nullptr;
+    int job_parts_ = 0, pending_ = 0;
+    unsigned long long gen_ = 0;
+    bool stop_ = false;
 };
 
 // RCCL entry points, resolved at run time so that libsfmba.so has no load-time dependency on RCCL
@@ -93,22 +191,6 @@ RcclApi* rccl_api() {
     }
     return api.lib ? &api : nullptr;
 }
-
-// fn(begin, end, part) over [0, n) on a few host threads (set_problem's passes over the observation arrays;
-// small inputs stay on the calling thread)
-template <class Fn>
-void parallel_chunks(int64_t n, int max_parts, Fn fn) {
-    const int hw = (int)std::thread::hardware_concurrency();
-    const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(max_parts, hw > 0 ? hw : 1), n / 131072));
-    if (parts == 1) { fn((int64_t)0, n, 0); return; }
-    std::vector<std::thread> th;
-    const int64_t per = (n + parts - 1) / parts;
-    for (int t = 1; t < parts; ++t)
-        th.emplace_back([=] { fn(std::min<int64_t>(n, t * per), std::min<int64_t>(n, (t + 1) * per), t); });
-    fn((int64_t)0, std::min<int64_t>(n, per), 0);
-    for (auto& x : th) x.join();
-}
-constexpr int kHostParts = 8;
 
 double now_s() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -183,8 +265,15 @@ struct sfmba_handle {
         bool first_in_solve = true;          // the next collective is the rendezvous of a solve (long timeout)
     } p2p;
     double* h_scal = nullptr;                // pinned
-    void* h_stage = nullptr;                 // pinned staging of set_problem's uploads (grow-only)
-    size_t h_stage_bytes = 0;
+    // set_problem: converted arrays of the current problem in pinned memory (upload source, and what the next
+    // call is compared with), host copies of the structure tables, worker threads
+    struct Stage { PinnedBuf uv, ci, pi, perm, ptr, uvf; } stage;
+    struct Prev { bool valid = false; bool f32 = false; int64_t N = 0, P = 0; } prev;
+    std::vector<int2> host_ranges, host_wsteps, host_steps;
+    std::vector<int4> host_chunks;
+    std::vector<int> host_chunk_ptr;
+    HostPool pool;
+    int64_t obs_reused = 0, obs_uploaded = 0;    // of the last sfmba_set_problem
     double* mbox = nullptr;                  // coherent pinned block the device posts the hand-off into (Mailbox)
     double* mbox_dev = nullptr;              // its device-visible address
     unsigned long long mbox_seq = 0;
@@ -728,16 +817,6 @@ int ensure_h_x(sfmba_handle* h) {
     return 0;
 }
 
-// pinned staging for the arrays set_problem uploads (an async copy from pageable memory is staged by the
-// runtime in small synchronous pieces: ~3 ms for the 32 MB of a 1M-observation problem)
-int ensure_stage(sfmba_handle* h, size_t bytes) {
-    if (h->h_stage && h->h_stage_bytes >= bytes) return 0;
-    if (h->h_stage) { (void)hipHostFree(h->h_stage); h->h_stage = nullptr; h->h_stage_bytes = 0; }
-    HIPCHK(h, hipHostMalloc(&h->h_stage, bytes, hipHostMallocDefault));
-    h->h_stage_bytes = bytes;
-    return 0;
-}
-
 int upload_x(sfmba_handle* h, const double* x_host) {
     CHK(ensure_h_x(h));
     HIPCHK(h, hipStreamSynchronize(h->stream));      // the staging buffer may still be in flight
@@ -922,7 +1001,6 @@ void sfmba_destroy(sfmba_handle* h) {
     if (h->h_scal) (void)hipHostFree(h->h_scal);
     if (h->mbox) (void)hipHostFree(h->mbox);
     if (h->h_x) (void)hipHostFree(h->h_x);
-    if (h->h_stage) (void)hipHostFree(h->h_stage);
     delete h;
 }
 
@@ -1141,6 +1219,13 @@ int sfmba_p2p_detach(sfmba_handle* h) {
 
 int64_t sfmba_p2p_calls(const sfmba_handle* h) { return h ? h->p2p.calls : 0; }
 
+int sfmba_problem_reuse(const sfmba_handle* h, int64_t* obs_reused, int64_t* obs_uploaded) {
+    if (!h) return -1;
+    if (obs_reused) *obs_reused = h->obs_reused;
+    if (obs_uploaded) *obs_uploaded = h->obs_uploaded;
+    return 0;
+}
+
 int sfmba_get_counters(const sfmba_handle* h, int64_t* kernel_launches, int64_t* collectives) {
     if (!h) return -1;
     if (kernel_launches) *kernel_launches = h->n_launches;
@@ -1173,80 +1258,141 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     if (!cam || !pt || (!uv && !uv_i64) || !K) return fail(h, -1, "NULL array argument");
     if (N >= (int64_t)1 << 30 || 6 * C + 3 * P >= (int64_t)1 << 31)
         return fail(h, -1, "problem too large for 32-bit observation indices");
-    bool sorted = true;
-    {   // bounds of every index (numpy's fancy indexing would raise IndexError in the reference) and order
-        int64_t bad[kHostParts];
-        bool unsorted[kHostParts] = {};
-        for (int t = 0; t < kHostParts; ++t) bad[t] = -1;
-        parallel_chunks(N, kHostParts, [&](int64_t b, int64_t e, int t) {
-            for (int64_t i = b; i < e; ++i) {
-                if ((cam[i] < 0 || cam[i] >= C || pt[i] < 0 || pt[i] >= P) && bad[t] < 0) bad[t] = i;
-                if (i > 0 && pt[i] < pt[i - 1]) unsorted[t] = true;
-            }
-        });
-        for (int t = 0; t < kHostParts; ++t) {
-            const int64_t i = bad[t];
-            if (i >= 0 && (cam[i] < 0 || cam[i] >= C)) return fail(h, -1, "camera_indices[%lld]=%lld out of range [0,%lld)", (long long)i, (long long)cam[i], (long long)C);
-            if (i >= 0) return fail(h, -1, "point_indices[%lld]=%lld out of range [0,%lld)", (long long)i, (long long)pt[i], (long long)P);
-            sorted = sorted && !unsorted[t];
-        }
-    }
-    for (int k = 0; k < 9; ++k) {
+    for (int k = 0; k < 9; ++k)
         if (!std::isfinite(K[k])) return fail(h, -1, "K is not finite");
-        h->K.k[k] = K[k];
-    }
-    tp1 = now_s();
-    h->f32 = h->f32_next;
     // A new problem returns the handle to single-process operation: every transport (direct link, RCCL
     // communicator, callback) is torn down and has to be set up again after this call (include/sfmba.h).  The
     // staging buffer of the direct link stays allocated until sfmba_p2p_detach / _export / _destroy, because
     // peers may still have it mapped.
     if (h->p2p.ready) p2p_close_peers(h);
     if (h->comm) { if (RcclApi* api = rccl_api()) (void)api->CommDestroy(h->comm); h->comm = nullptr; }
-    h->C = C; h->P = P; h->N = N; h->n = 6 * C + 3 * P;
-    h->N_total = N;
-    h->ld = (N + 255) / 256 * 256;
+    HIPCHK(h, hipStreamSynchronize(h->stream));                  // a previous upload may still read the staging
+
+    // ---- incremental re-use ---------------------------------------------------------
+    // The reference calls BA once per fused edge on a growing reconstruction (/root/reference/sfm_lite/sfm.py:59-71):
+    // once every camera is registered, a new edge only appends points and their observations, so the argument
+    // arrays of one call start with those of the previous call.  The converted arrays of the last problem stay in
+    // pinned host memory and in HBM; this call compares as it converts, finds the first observation that differs
+    // and uploads from there on only.  The structure tables are always rebuilt from the (complete) host arrays, by
+    // the same code whatever was re-used: results are bitwise those of a fresh handle.
+    auto& prev = h->prev;
+    const bool f32 = h->f32_next;
+    const int64_t ld = (N + 255) / 256 * 256;
+    const size_t ldz = (size_t)ld;
+    const int64_t n_cmp = (prev.valid && prev.f32 == f32) ? std::min(prev.N, N) : 0;
+    prev.valid = false;                                          // until this call has completed
+    auto& sg = h->stage;
+    const size_t keep_obs = (size_t)n_cmp;
+    HIPCHK(h, sg.uv.ensure(sizeof(double) * 2 * ldz, sizeof(double) * 2 * keep_obs));
+    HIPCHK(h, sg.ci.ensure(sizeof(int) * ldz, sizeof(int) * keep_obs));
+    HIPCHK(h, sg.pi.ensure(sizeof(int) * ldz, sizeof(int) * keep_obs));
+    HIPCHK(h, sg.perm.ensure(sizeof(int) * ldz, 0));
+    HIPCHK(h, sg.ptr.ensure(sizeof(int) * ((size_t)P + 1), 0));
+    if (f32) HIPCHK(h, sg.uvf.ensure(sizeof(float) * 2 * ldz, sizeof(float) * 2 * keep_obs));
+    double* uvs = sg.uv.as<double>();
+    float* uvf = f32 ? sg.uvf.as<float>() : nullptr;
+    int* ci = sg.ci.as<int>();
+    int* pi = sg.pi.as<int>();
+    int* perm = sg.perm.as<int>();
+    int* ptr = sg.ptr.as<int>();
+
+    // ---- pass 1 (parallel): range check, order check, conversion with comparison, camera histogram -------------
+    const int parts = h->pool.parts_for(N);
+    std::vector<int> hist((size_t)parts * (size_t)C, 0);
+    std::vector<int64_t> bad((size_t)parts, -1), first_diff((size_t)parts, N);
+    std::vector<char> unsorted((size_t)parts, 0);
+    const int64_t per = (N + parts - 1) / parts;
+    auto convert = [&](const int64_t* ord, int64_t n_compare) {
+        h->pool.run(parts, [&](int t) {
+            const int64_t b = std::min<int64_t>(N, t * per), e = std::min<int64_t>(N, (t + 1) * per);
+            int* hc = hist.data() + (size_t)t * (size_t)C;
+            for (int64_t c = 0; c < C; ++c) hc[c] = 0;
+            int64_t fd = N;
+            for (int64_t k = b; k < e; ++k) {
+                const int64_t s = ord ? ord[k] : k;
+                const int64_t cv = cam[s], pv = pt[s];
+                if (cv < 0 || cv >= C || pv < 0 || pv >= P) { if (bad[t] < 0) bad[t] = s; continue; }
+                if (!ord && k > 0 && pv < pt[k - 1]) unsorted[t] = 1;
+                double u0, u1;
+                if (uv) { u0 = uv[2 * s]; u1 = uv[2 * s + 1]; }
+                else { u0 = (double)uv_i64[2 * s]; u1 = (double)uv_i64[2 * s + 1]; }          // as numpy promotes
+                ++hc[cv];
+                if (k < n_compare && ci[k] == (int)cv && pi[k] == (int)pv && uvs[2 * k] == u0 && uvs[2 * k + 1] == u1)
+                    continue;
+                if (fd == N) fd = k;
+                ci[k] = (int)cv; pi[k] = (int)pv; uvs[2 * k] = u0; uvs[2 * k + 1] = u1;
+                if (uvf) { uvf[2 * k] = (float)u0; uvf[2 * k + 1] = (float)u1; }    // integer pixels up to 2^24 are exact
+            }
+            first_diff[t] = fd;
+        });
+    };
+    convert(nullptr, n_cmp);
+    auto report_bad = [&]() -> int {
+        for (int t = 0; t < parts; ++t) {
+            const int64_t i = bad[t];
+            if (i < 0) continue;
+            if (cam[i] < 0 || cam[i] >= C)
+                return fail(h, -1, "camera_indices[%lld]=%lld out of range [0,%lld)", (long long)i, (long long)cam[i], (long long)C);
+            return fail(h, -1, "point_indices[%lld]=%lld out of range [0,%lld)", (long long)i, (long long)pt[i], (long long)P);
+        }
+        return 0;
+    };
+    CHK(report_bad());                  // (numpy's fancy indexing would raise IndexError in the reference)
+    bool sorted = true;
+    for (int t = 0; t < parts; ++t) sorted = sorted && !unsorted[t];
     h->permuted = !sorted;
     h->order.clear();
-    if (!sorted) {                       // any order is accepted; the kernels want point-major
+    if (!sorted) {                       // any order is accepted; the kernels want point-major.  No re-use on this path.
         h->order.resize(N);
         std::iota(h->order.begin(), h->order.end(), (int64_t)0);
         std::stable_sort(h->order.begin(), h->order.end(), [&](int64_t a, int64_t b) { return pt[a] < pt[b]; });
+        convert(h->order.data(), 0);
     }
-    // device-bound arrays are built directly in pinned memory:
-    // [uv 2 ld doubles | cam ld | pt ld | camera-major permutation ld | ptr P+1 ints | fp32 storage: uv once more as floats]
-    const size_t ldz = (size_t)h->ld;
-    HIPCHK(h, hipStreamSynchronize(h->stream));                  // a previous upload may still read the staging
-    const size_t stage_ints = 3 * ldz + (((size_t)P + 1 + 3) & ~(size_t)3);      // keeps what follows 16-byte aligned
-    CHK(ensure_stage(h, sizeof(double) * 2 * ldz + sizeof(int) * stage_ints + sizeof(float) * 2 * ldz));
-    double* uvs = static_cast<double*>(h->h_stage);
-    int* ci = reinterpret_cast<int*>(uvs + 2 * ldz);
-    int* pi = ci + ldz;
-    int* perm = pi + ldz;
-    int* ptr = perm + ldz;
-    for (size_t k = (size_t)N; k < ldz; ++k) { ci[k] = 0; pi[k] = 0; uvs[2 * k] = 0.0; uvs[2 * k + 1] = 0.0; }
-    const int64_t* ord = sorted ? nullptr : h->order.data();
-    parallel_chunks(N, kHostParts, [&](int64_t b, int64_t e, int) {
-        for (int64_t k = b; k < e; ++k) {
-            const int64_t s = ord ? ord[k] : k;
-            ci[k] = (int)cam[s]; pi[k] = (int)pt[s];
-            if (uv) { uvs[2 * k] = uv[2 * s]; uvs[2 * k + 1] = uv[2 * s + 1]; }
-            else { uvs[2 * k] = (double)uv_i64[2 * s]; uvs[2 * k + 1] = (double)uv_i64[2 * s + 1]; }   // as numpy promotes
+    int64_t fdiff = N;
+    for (int t = 0; t < parts; ++t) fdiff = std::min(fdiff, first_diff[t]);
+    fdiff = std::min(fdiff, n_cmp);      // nothing beyond the compared prefix is on the device
+    for (size_t k = (size_t)N; k < ldz; ++k) {                       // padding up to the next multiple of 256
+        ci[k] = 0; pi[k] = 0; uvs[2 * k] = 0.0; uvs[2 * k + 1] = 0.0;
+        if (uvf) { uvf[2 * k] = 0.f; uvf[2 * k + 1] = 0.f; }
+    }
+    tp1 = now_s();
+
+    // ---- camera-major order: stable counting sort of the positions by camera (per-part histograms, so that the
+    // parts scatter independently and the order inside a camera stays the point-major one) -----------------------
+    std::vector<int> cam_ptr((size_t)C + 1);
+    {
+        int run = 0;
+        for (int64_t c = 0; c < C; ++c) {
+            cam_ptr[c] = run;
+            for (int t = 0; t < parts; ++t) { int& v = hist[(size_t)t * (size_t)C + c]; const int n = v; v = run; run += n; }
         }
-    });
-    // ptr[p] = first position whose point index is >= p (pi is non-decreasing now): every run start k writes
-    // the entries (pi[k-1], pi[k]], so the chunks touch disjoint parts of ptr
-    parallel_chunks(N, kHostParts, [&](int64_t b, int64_t e, int) {
+        cam_ptr[C] = run;
+    }
+    // ---- pass 2 (parallel): run offsets of the points, camera-major permutation ---------------------------------
+    // ptr[p] = first position whose point index is >= p (pi is non-decreasing): every run start k writes the
+    // entries (pi[k-1], pi[k]], so the parts touch disjoint pieces of ptr
+    h->pool.run(parts, [&](int t) {
+        const int64_t b = std::min<int64_t>(N, t * per), e = std::min<int64_t>(N, (t + 1) * per);
+        int* off = hist.data() + (size_t)t * (size_t)C;
         for (int64_t k = b; k < e; ++k) {
             const int lo = k == 0 ? -1 : pi[k - 1];
             for (int q = lo + 1; q <= pi[k]; ++q) ptr[q] = (int)k;
+            perm[off[ci[k]]++] = (int)k;
         }
     });
     for (int64_t q = (int64_t)pi[N - 1] + 1; q <= P; ++q) ptr[q] = (int)N;
+    for (size_t k = (size_t)N; k < ldz; ++k) perm[k] = 0;
+
+    for (int k = 0; k < 9; ++k) h->K.k[k] = K[k];
+    h->f32 = f32;
+    h->C = C; h->P = P; h->N = N; h->n = 6 * C + 3 * P;
+    h->N_total = N;
+    h->ld = ld;
     // wave ranges: cut at point boundaries, >= T observations each
     const int64_t total_waves = (int64_t)h->n_cu * kWavesPerSweepBlock;
     const int64_t T = std::max<int64_t>(64, (N + total_waves - 1) / total_waves);
-    std::vector<int2> ranges;
+    std::vector<int2>& ranges = h->host_ranges;
+    ranges.clear();
     {
         int64_t start = 0;
         for (int64_t p = 0; p < P; ++p) {
@@ -1260,7 +1406,10 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     h->n_ranges = (int)ranges.size();
     // step table of the sweeps: per wave range, batches of <= 64 observations that end on a point
     // boundary; a point with more than 64 observations is one step of its own
-    std::vector<int2> wsteps(ranges.size()), steps;
+    std::vector<int2>& wsteps = h->host_wsteps;
+    std::vector<int2>& steps = h->host_steps;
+    wsteps.resize(ranges.size());
+    steps.clear();
     for (size_t w = 0; w < ranges.size(); ++w) {
         const int first = (int)steps.size();
         int64_t pos = ranges[w].x;
@@ -1282,30 +1431,13 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
         wsteps[w] = make_int2(first, (int)steps.size() - first);
     }
     h->n_steps = (int)steps.size();
-    // Camera-major order: stable counting sort of the point-major positions by camera (per-part histograms, so
-    // that the parts scatter independently and the order inside a camera stays the point-major one), and the
     // chunk table of the camera-major kernels: every camera gets at least one chunk (an empty one writes its
-    // zeros), runs longer than chunk_len are cut; one 256-thread workgroup per chunk.
-    std::vector<int4> chunks;
-    std::vector<int> chunk_ptr((size_t)C + 1);
+    // zeros), runs longer than chunk_len are cut; one 256-thread workgroup per chunk
+    std::vector<int4>& chunks = h->host_chunks;
+    std::vector<int>& chunk_ptr = h->host_chunk_ptr;
+    chunks.clear();
+    chunk_ptr.resize((size_t)C + 1);
     {
-        std::vector<int> hist((size_t)kHostParts * (size_t)C, 0);
-        parallel_chunks(N, kHostParts, [&](int64_t b, int64_t e, int t) {
-            int* hcount = hist.data() + (size_t)t * (size_t)C;
-            for (int64_t k = b; k < e; ++k) ++hcount[ci[k]];
-        });
-        std::vector<int> cam_ptr((size_t)C + 1);
-        int run = 0;
-        for (int64_t c = 0; c < C; ++c) {
-            cam_ptr[c] = run;
-            for (int t = 0; t < kHostParts; ++t) { int& v = hist[(size_t)t * (size_t)C + c]; const int n = v; v = run; run += n; }
-        }
-        cam_ptr[C] = run;
-        parallel_chunks(N, kHostParts, [&](int64_t b, int64_t e, int t) {
-            int* off = hist.data() + (size_t)t * (size_t)C;
-            for (int64_t k = b; k < e; ++k) perm[off[ci[k]]++] = (int)k;
-        });
-        for (size_t k = (size_t)N; k < ldz; ++k) perm[k] = 0;
         int64_t chunk_len = std::max<int64_t>(1024, (N + 2 * h->n_cu - 1) / (2 * h->n_cu));
         if (h->dbg.cam_chunk > 0) chunk_len = h->dbg.cam_chunk;
         h->cam_multi = false;
@@ -1330,12 +1462,16 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     h->pcg_fused = (h->lds_vec || h->sweep_rc) && C <= kSweepThreads;
     if (h->dbg.pcg_fused == 0) h->pcg_fused = false;
 
-    const size_t ld = (size_t)h->ld;
-    HIPCHK(h, h->cam_idx.ensure(sizeof(int) * ld));
-    HIPCHK(h, h->pt_idx.ensure(sizeof(int) * ld));
-    HIPCHK(h, h->pt_ptr.ensure(sizeof(int) * (P + 1)));
-    const size_t esz = h->f32 ? sizeof(float) : sizeof(double);     // element size of the per-observation streams
-    HIPCHK(h, h->uv.ensure(esz * 2 * ld));
+    // ---- device arrays: grow-only; the index / pixel arrays keep their re-used prefix when they grow -------------
+    const size_t esz = f32 ? sizeof(float) : sizeof(double);     // element size of the per-observation streams
+    const size_t keep = (size_t)fdiff;
+    HIPCHK(h, h->cam_idx.ensure_keep(sizeof(int) * ldz, sizeof(int) * keep));
+    HIPCHK(h, h->pt_idx.ensure_keep(sizeof(int) * ldz, sizeof(int) * keep));
+    HIPCHK(h, h->uv.ensure_keep(esz * 2 * ldz, esz * 2 * keep));
+    // run offsets of the points before the first changed observation's point are unchanged
+    // (entries up to the point of the last unchanged observation are determined by unchanged positions alone)
+    const int64_t p_keep = keep == 0 ? 0 : std::min<int64_t>(std::min<int64_t>(prev.P, P), (int64_t)pi[fdiff - 1] + 1);
+    HIPCHK(h, h->pt_ptr.ensure_keep(sizeof(int) * ((size_t)P + 1), sizeof(int) * (size_t)p_keep));
     HIPCHK(h, h->ranges.ensure(sizeof(int2) * std::max<size_t>(1, ranges.size())));
     HIPCHK(h, h->wsteps.ensure(sizeof(int2) * std::max<size_t>(1, wsteps.size())));
     HIPCHK(h, h->steps.ensure(sizeof(int2) * std::max<size_t>(1, steps.size())));
@@ -1343,16 +1479,16 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     HIPCHK(h, h->xb.ensure(sizeof(double) * h->n));
     HIPCHK(h, h->tabA.ensure(sizeof(double) * cam_table_doubles((int)C)));
     HIPCHK(h, h->tabB.ensure(sizeof(double) * cam_table_doubles((int)C)));
-    HIPCHK(h, h->r.ensure(esz * 2 * ld));
-    HIPCHK(h, h->J.ensure(esz * 12 * ld));
-    HIPCHK(h, h->cm_perm.ensure(sizeof(int) * ld));
-    HIPCHK(h, h->cm_pt.ensure(sizeof(int) * ld));
-    HIPCHK(h, h->cm_uv.ensure(esz * 2 * ld));
+    HIPCHK(h, h->r.ensure(esz * 2 * ldz));
+    HIPCHK(h, h->J.ensure(esz * 12 * ldz));
+    HIPCHK(h, h->cm_perm.ensure(sizeof(int) * ldz));
+    HIPCHK(h, h->cm_pt.ensure(sizeof(int) * ldz));
+    HIPCHK(h, h->cm_uv.ensure(esz * 2 * ldz));
     HIPCHK(h, h->cam_chunks.ensure(sizeof(int4) * chunks.size()));
     HIPCHK(h, h->cam_chunk_ptr.ensure(sizeof(int) * chunk_ptr.size()));
     HIPCHK(h, h->cam_partial.ensure(sizeof(double) * 27 * chunks.size()));
     HIPCHK(h, h->z.ensure(sizeof(double) * 3 * P));
-    HIPCHK(h, h->t1.ensure(esz * 2 * ld));
+    HIPCHK(h, h->t1.ensure(esz * 2 * ldz));
     HIPCHK(h, h->V.ensure(sizeof(double) * 6 * P));
     HIPCHK(h, h->Vinv.ensure(sizeof(double) * 6 * P));
     HIPCHK(h, h->gp.ensure(sizeof(double) * 3 * P));
@@ -1376,16 +1512,18 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     h->x = h->xa.as<double>(); h->x_new = h->xb.as<double>();
     h->tab = h->tabA.as<double>(); h->tab_new = h->tabB.as<double>();
 
-    HIPCHK(h, hipMemcpyAsync(h->cam_idx.p, ci, sizeof(int) * ld, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->pt_idx.p, pi, sizeof(int) * ld, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->pt_ptr.p, ptr, sizeof(int) * (P + 1), hipMemcpyHostToDevice, h->stream));
-    if (h->f32) {                            // integer pixels up to 2^24 are exact in fp32
-        float* uvf = reinterpret_cast<float*>(ci + stage_ints);
-        for (size_t k = 0; k < 2 * ld; ++k) uvf[k] = (float)uvs[k];
-        HIPCHK(h, hipMemcpyAsync(h->uv.p, uvf, sizeof(float) * 2 * ld, hipMemcpyHostToDevice, h->stream));
-    } else {
-        HIPCHK(h, hipMemcpyAsync(h->uv.p, uvs, sizeof(double) * 2 * ld, hipMemcpyHostToDevice, h->stream));
-    }
+    // ---- uploads: observations from the first changed one on, run offsets from its point on, structure tables ----
+    auto up = [&](void* dst, const void* src, size_t elem, size_t from, size_t to) -> hipError_t {
+        if (to <= from) return hipSuccess;
+        return hipMemcpyAsync(static_cast<char*>(dst) + elem * from, static_cast<const char*>(src) + elem * from,
+                              elem * (to - from), hipMemcpyHostToDevice, h->stream);
+    };
+    HIPCHK(h, up(h->cam_idx.p, ci, sizeof(int), keep, ldz));
+    HIPCHK(h, up(h->pt_idx.p, pi, sizeof(int), keep, ldz));
+    HIPCHK(h, up(h->uv.p, f32 ? (const void*)uvf : (const void*)uvs, 2 * esz, keep, ldz));
+    HIPCHK(h, up(h->pt_ptr.p, ptr, sizeof(int), (size_t)p_keep, (size_t)P + 1));
+    h->obs_reused = fdiff;
+    h->obs_uploaded = ld - fdiff;
     if (!ranges.empty()) {
         HIPCHK(h, hipMemcpyAsync(h->ranges.p, ranges.data(), sizeof(int2) * ranges.size(), hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipMemcpyAsync(h->wsteps.p, wsteps.data(), sizeof(int2) * wsteps.size(), hipMemcpyHostToDevice, h->stream));
@@ -1396,20 +1534,22 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     HIPCHK(h, hipMemsetAsync(h->V.p, 0, sizeof(double) * 6 * P, h->stream));
     HIPCHK(h, hipMemsetAsync(h->gp.p, 0, sizeof(double) * 3 * P, h->stream));
     HIPCHK(h, hipMemsetAsync(h->p.p, 0, sizeof(double) * h->n, h->stream));      // ... and their step is 0
-    HIPCHK(h, hipMemsetAsync(h->r.p, 0, esz * 2 * ld, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->r.p, 0, esz * 2 * ldz, h->stream));
     HIPCHK(h, hipMemsetAsync(h->z.p, 0, sizeof(double) * 3 * P, h->stream));      // points without observations keep z = 0
-    HIPCHK(h, hipMemcpyAsync(h->cm_perm.p, perm, sizeof(int) * ld, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->cm_perm.p, perm, sizeof(int) * ldz, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->cam_chunks.p, chunks.data(), sizeof(int4) * chunks.size(), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->cam_chunk_ptr.p, chunk_ptr.data(), sizeof(int) * chunk_ptr.size(), hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(k_build_cam_major, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, h->stream, h->cm_perm.as<int>(),
-                       h->pt_idx.as<int>(), h->uv.as<double>(), h->f32 ? 1 : 0, (int)N, h->cm_pt.as<int>(),
+                       h->pt_idx.as<int>(), h->uv.as<double>(), f32 ? 1 : 0, (int)N, h->cm_pt.as<int>(),
                        h->cm_uv.as<double>());
     LAUNCHED(h);
     tp3 = now_s();
-    HIPCHK(h, hipStreamSynchronize(h->stream));     // the staging buffer is reused by the next call
+    HIPCHK(h, hipStreamSynchronize(h->stream));     // the host tables are rebuilt by the next call
     if (timing)
-        fprintf(stderr, "sfmba: set_problem  validate %.2f ms  build %.2f ms  allocate+enqueue %.2f ms  upload wait %.2f ms\n",
-                1e3 * (tp1 - tp0), 1e3 * (tp2 - tp1), 1e3 * (tp3 - tp2), 1e3 * (now_s() - tp3));
+        fprintf(stderr, "sfmba: set_problem  convert+compare %.2f ms  structure %.2f ms  allocate+enqueue %.2f ms  upload wait %.2f ms"
+                        "  (%lld of %lld observations re-used)\n",
+                1e3 * (tp1 - tp0), 1e3 * (tp2 - tp1), 1e3 * (tp3 - tp2), 1e3 * (now_s() - tp3), (long long)fdiff, (long long)N);
+    if (sorted) { prev.valid = true; prev.f32 = f32; prev.N = N; prev.P = P; }
     h->have_problem = true;
     return 0;
 }

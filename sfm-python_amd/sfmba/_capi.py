@@ -19,7 +19,7 @@ SYMBOLS = (
     "sfmba_residual_jacobian", "sfmba_solve", "sfmba_get_fun_grad", "sfmba_time_kernel",
     "sfmba_normal_blocks", "sfmba_schur_matvec", "sfmba_comm_get_unique_id", "sfmba_comm_init",
     "sfmba_comm_destroy", "sfmba_set_precision", "sfmba_p2p_export", "sfmba_p2p_attach", "sfmba_p2p_detach",
-    "sfmba_p2p_calls", "sfmba_tr2d_solve", "sfmba_debug_option", "sfmba_set_print", "sfmba_get_counters",
+    "sfmba_p2p_calls", "sfmba_tr2d_solve", "sfmba_debug_option", "sfmba_set_print", "sfmba_get_counters", "sfmba_problem_reuse",
 )
 
 
@@ -86,6 +86,8 @@ def load():
     lib.sfmba_p2p_attach.argtypes = [P, P, C.c_int32, C.c_int32]
     lib.sfmba_p2p_detach.argtypes = [P]
     lib.sfmba_debug_option.argtypes = [P, C.c_char_p, C.c_int64]
+    lib.sfmba_problem_reuse.argtypes = [P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    lib.sfmba_problem_reuse.restype = C.c_int
     lib.sfmba_get_counters.argtypes = [P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.sfmba_get_counters.restype = C.c_int
     lib.sfmba_set_print.argtypes = [P, PRINT_FN, P]

@@ -158,6 +158,13 @@ class Backend:
     def p2p_detach(self):
         self._check(self._lib.sfmba_p2p_detach(self._h))
 
+    def problem_reuse(self):
+        """(observations re-used from the previous problem of this handle, observations uploaded) of the last
+        set_problem (include/sfmba.h: incremental re-use)."""
+        a, b = C.c_int64(), C.c_int64()
+        self._lib.sfmba_problem_reuse(self._h, C.byref(a), C.byref(b))
+        return int(a.value), int(b.value)
+
     def counters(self):
         """(kernel launches, collectives) enqueued by this handle so far."""
         a, b = C.c_int64(), C.c_int64()

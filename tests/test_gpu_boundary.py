@@ -227,3 +227,89 @@ def test_int64_pixels_entry_equals_float_entry():
     finally:
         a.close()
         b.close()
+
+
+def _stage_problem(pb, cams_registered, n_points):
+    """The least_squares arguments SFM._apply_bundle_adjustment would build (sfm.py:248-262) when only
+    `cams_registered` (node ids) are registered and the cloud holds the first `n_points` points of `pb`: observations
+    of unregistered cameras are skipped (graph.py:186-191), registered cameras are compacted in node order
+    (sfm.py:251-256), points without any remaining observation are dropped from the cloud."""
+    C = pb.n_cameras
+    reg = sorted(cams_registered)
+    cmap = -np.ones(C, dtype=np.int64)
+    cmap[reg] = np.arange(len(reg))
+    keep = (pb.point_indices < n_points) & (cmap[pb.camera_indices] >= 0)
+    pts_seen = np.unique(pb.point_indices[keep])
+    pmap = -np.ones(pb.n_points, dtype=np.int64)
+    pmap[pts_seen] = np.arange(len(pts_seen))
+    ci, pi, uv = cmap[pb.camera_indices[keep]], pmap[pb.point_indices[keep]], pb.points_2d[keep]
+    cams = pb.x0[:6 * C].reshape(C, 6)[reg]
+    pts = pb.x0[6 * C:].reshape(-1, 3)[pts_seen]
+    return np.concatenate([cams.ravel(), pts.ravel()]), (len(reg), len(pts_seen), ci, pi, uv, pb.K)
+
+
+def test_growing_reconstruction_reuses_the_previous_problem():
+    """SURVEY.md section 8f-3.  The reference runs BA after every fused edge on a growing problem
+    (/root/reference/sfm_lite/sfm.py:59-71).  While cameras are still being registered the compact camera indices
+    of existing observations shift (sfm.py:251-256) and little can be re-used; once all are registered an edge
+    only appends points and observations, and the whole previous problem is re-used (only the tail crosses PCIe).
+    One handle is taken through the whole sequence; every stage must equal, bit for bit, what a fresh handle
+    computes."""
+    import sfmba
+    pb = sfmba.make_problem(8, 600, 5000, seed=17)
+    order = [0, 5, 2, 7, 1, 6, 3, 4]                               # node ids in the order they get registered
+    stages = [(order[:k], 300) for k in range(2, 9)] + [(order, n) for n in (350, 420, 421, 500, 600)]
+    inc = sfmba.Backend(0)
+    opt = inc.default_options()
+    opt.ftol = 1e-10
+    prev_n = None
+    appended = 0
+    try:
+        for k, (cams, npts) in enumerate(stages):
+            x0, args = _stage_problem(pb, cams, npts)
+            inc.set_problem(*args)
+            reused, uploaded = inc.problem_reuse()
+            n_obs = len(args[2])
+            if len(cams) == 8 and k > 7:                           # all cameras registered before this stage: append
+                assert reused == prev_n and uploaded <= (n_obs - prev_n) + 256
+                appended += 1
+            fresh = sfmba.Backend(0)
+            try:
+                fresh.set_problem(*args)
+                assert fresh.problem_reuse()[0] == 0
+                for u, v in zip(inc.residual_jacobian(x0), fresh.residual_jacobian(x0)):
+                    assert np.array_equal(u, v)
+                for u, v in zip(inc.normal_blocks(x0), fresh.normal_blocks(x0)):
+                    assert np.array_equal(u, v)
+                xa, ra, fa, ga = inc.solve(x0, opt)
+                xb, rb, fb, gb = fresh.solve(x0, opt)
+                assert np.array_equal(xa, xb) and ra.cost == rb.cost and (ra.nfev, ra.status) == (rb.nfev, rb.status)
+                assert np.array_equal(fa, fb) and np.array_equal(ga, gb)
+                assert ra.status > 0
+            finally:
+                fresh.close()
+            prev_n = n_obs
+        assert appended == 4
+        # the same arrays again: everything is re-used; a changed pixel in the middle: re-use up to it
+        x0, args = _stage_problem(pb, order, 600)
+        inc.set_problem(*args)
+        assert inc.problem_reuse() == (prev_n, (prev_n + 255) // 256 * 256 - prev_n)
+        uv2 = args[4].copy()
+        uv2[1234, 0] += 1
+        inc.set_problem(args[0], args[1], args[2], args[3], uv2, args[5])
+        assert inc.problem_reuse()[0] == 1234
+        fresh = sfmba.Backend(0)
+        try:
+            fresh.set_problem(args[0], args[1], args[2], args[3], uv2, args[5])
+            assert np.array_equal(inc.residuals(x0), fresh.residuals(x0))
+            # fp32 storage after fp64 on the same handle: nothing of the fp64 arrays is re-used
+            inc.set_precision(32)
+            inc.set_problem(*args)
+            assert inc.problem_reuse()[0] == 0
+            fresh.set_precision(32)
+            fresh.set_problem(*args)
+            assert np.array_equal(inc.residuals(x0), fresh.residuals(x0))
+        finally:
+            fresh.close()
+    finally:
+        inc.close()
