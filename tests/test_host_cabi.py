@@ -199,3 +199,53 @@ def test_pack_unpack_rt_convention_round_trip():
     assert all(np.allclose(a, b, atol=1e-12) for a, b in zip(H2, H)) and np.array_equal(X2, X3d)
     with pytest.raises(ValueError):
         sfmba.pack_cameras_points(H, registered, X3d, obs, pose_convention="centre")
+
+
+def test_bal_reader_round_trip_and_model_mapping(tmp_path):
+    """the published BAL text format.  A file generated in the test (no such file ships
+    with the reference): camera-major observation order, BAL's own conventions (P = R X + t, p = -P / P.z, pixel =
+    f p), read back into the reference's args tuple (sfm.py:268); the BA residual of the mapped problem must be
+    BAL's reprojection error, and write_bal -> read_bal must reproduce the problem exactly."""
+    import sfmba
+    from oracle import ba_oracle as orc
+    rng = np.random.default_rng(11)
+    C, P = 4, 25
+    f0 = 850.0
+    rot = rng.normal(0, 0.2, (C, 3))
+    t = rng.normal(0, 0.3, (C, 3)) + np.array([0.0, 0.0, -6.0])       # BAL cameras look down -z
+    X = rng.normal(0, 1.0, (P, 3))
+    obs = [(c, p) for c in range(C) for p in range(P) if rng.random() < 0.7]     # camera-major, as BAL files are
+    lines = [f"{C} {P} {len(obs)}"]
+    bal_px = []
+    for c, p in obs:
+        Pc = orc.rodrigues(rot[c]) @ X[p] + t[c]
+        px = -f0 * Pc[:2] / Pc[2] + rng.normal(0, 0.3, 2)
+        bal_px.append(px)
+        lines.append(f"{c} {p} {float(px[0])!r} {float(px[1])!r}")
+    for c in range(C):
+        lines += [repr(float(v)) for v in (*rot[c], *t[c], f0, 0.0, 0.0)]
+    for p in range(P):
+        lines += [repr(float(v)) for v in X[p]]
+    path = tmp_path / "problem.txt"
+    path.write_text("\n".join(lines) + "\n")
+    x0, args, info = sfmba.read_bal(path)
+    nC, nP, ci, pi, uv, K = args
+    assert (nC, nP, len(ci)) == (C, P, len(obs)) and info["exact"] and info["focal_used"] == f0
+    assert np.all(np.diff(pi) >= 0)                                   # point-major
+    r = orc.compute_residuals(x0, *args).reshape(-1, 2)
+    want = np.empty_like(r)
+    for k, j in enumerate(info["file_order"]):                        # BAL's own reprojection error, per observation
+        c, p = obs[j]
+        Pc = orc.rodrigues(rot[c]) @ X[p] + t[c]
+        want[k] = -f0 * Pc[:2] / Pc[2] - bal_px[j]
+    assert np.abs(r - want).max() < 1e-9
+    out = tmp_path / "again.txt.gz"
+    sfmba.write_bal(out, x0, *args)
+    x1, args1, info1 = sfmba.read_bal(out)
+    assert np.array_equal(x1[6 * C:], x0[6 * C:]) and np.abs(x1[:6 * C] - x0[:6 * C]).max() < 1e-12
+    assert all(np.array_equal(a, b) for a, b in zip(args1[2:5], args[2:5])) and np.array_equal(args1[5], K)
+    with pytest.raises(ValueError):
+        (tmp_path / "bad.txt").write_text("3 4 5\n0 0 1.0 2.0\n")
+        sfmba.read_bal(tmp_path / "bad.txt")
+    with pytest.raises(ValueError):
+        sfmba.write_bal(tmp_path / "k.txt", x0, nC, nP, ci, pi, uv, sfmba.K_SCEAUX)      # principal point: not BAL
