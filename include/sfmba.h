@@ -192,12 +192,19 @@ int  sfmba_normal_blocks(sfmba_handle* h, const double* x, double* U, double* V,
 int  sfmba_schur_matvec(sfmba_handle* h, const double* x, const double* dc, const double* dp,
                         const double* v, double* y);
 
+/* Dense reduced-camera path (6 n_cameras <= 128, the reference's own problem sizes): at x, with the diagonals dc
+ * (6C) and dp (3P), form S = U + diag(dc) - W (V + diag(dp))^-1 W^T (S_out: (6C)^2 row-major, may be NULL) and
+ * solve S y = rhs with the in-LDS blocked Cholesky (sol_out: 6C). */
+int  sfmba_dense_schur(sfmba_handle* h, const double* x, const double* dc, const double* dp, const double* rhs,
+                       double* S_out, double* sol_out);
+
 /* Host-only helper for the CPU test-suite (no GPU needed): the 2-D trust-region subproblem of
  * SCIPY/optimize/_lsq/common.py:171-219.  B3 = (B00, B01, B11), g2, Delta -> p2; returns 1 when the Newton step
  * lies inside the region, 0 for a boundary solution. */
 int  sfmba_tr2d_solve(const double* B3, const double* g2, double Delta, double* p2);
 /* Test / diagnostic hooks (nothing in the library reads the environment).  Placement options take effect at
- * the next sfmba_set_problem.  Names: "pcg_fused" (0: two-kernel PCG), "tab_lds" / "vec_lds" (0: camera table /
+ * the next sfmba_set_problem.  Names: "pcg_fused" (0: two-kernel PCG), "dense" (0: PCG although the dense reduced-camera path would
+ * apply), "sweep_rc" (0: pass A of the Schur product reads the stored Jacobian), "tab_lds" / "vec_lds" (0: camera table /
  * camera vector read from L2 although they would fit the LDS), "cam_chunk" (> 0: chunk length of the
  * camera-major kernels), "pcg_guess_bias" (added to the speculative PCG iteration count), "trace_pcg",
  * "trace_stalls", "trace_timing" (stderr diagnostics). */

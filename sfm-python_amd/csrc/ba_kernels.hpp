@@ -1615,6 +1615,248 @@ __global__ __launch_bounds__(kCamThreads) void k_cam_schur(CamMajor cm, const do
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Dense reduced-camera path (6 C <= kDenseMaxN): the size the reference itself produces -- SceauxCastle has 11
+// cameras (BASELINE.json configs[0-1]).  There the iterative solve is all launch latency (46 PCG iterations of
+// two launches each per solve at 11 cameras), while the reduced camera matrix S = U + Dc - W V^-1 W^T is 66 x 66.
+// So S is FORMED -- one wave per 6x6 block pair (a <= b) over the list of points both cameras see, built once
+// per problem; blocks recomputed from the camera rows and the gathered point; no atomics -- and factorised by
+// one workgroup in LDS: blocked Cholesky with 16 x 16 tiles, the trailing updates on the matrix cores
+// (v_mfma_f64_16x16x4_f64), the right-hand side carried along as an extra row, then one back substitution.
+// The Gauss-Newton step is then exact instead of PCG-to-1e-3.
+// ---------------------------------------------------------------------------------------------
+constexpr int kDenseMaxN = 128;                  // 6 C <= 128: C <= 21
+constexpr int kDenseTile = 16;
+// No camera is held fixed (bundle_adjustment.py:6, sfm.py:264), so S is singular along the 7 gauge directions up to
+// the Levenberg-Marquardt term, which scipy's rule lets fall to 1e-10 of the diagonal: the last pivots are then
+// rounding noise.  An unknown whose pivot does not exceed this fraction of its original diagonal entry is dropped
+// from the solve (its step is 0, its column decoupled): a basic solution of the consistent singular system.
+constexpr double kDensePivotTol = 1e-12;
+
+__host__ __device__ constexpr int dense_block_index(int a, int b, int C) {      // a <= b, row-major upper triangle
+    return a * C - a * (a - 1) / 2 + (b - a);
+}
+
+// blk[a][b] (6x6, row-major) = sum over the points p seen by cameras a and b (with multiplicity) of
+// W_a(p) Vinv_p W_b(p)^T,  W_c(p) = Jc^T Jp of camera c at point p.
+__global__ __launch_bounds__(kCamThreads) void k_schur_blocks(const int* __restrict__ cov_ptr, const int* __restrict__ cov_pt,
+                                                     const int2* __restrict__ blk_ab, const double* __restrict__ camtab,
+                                                     const double* __restrict__ pts, const double* __restrict__ Vinv,
+                                                     KMat K, double* __restrict__ Sblk) {
+    __shared__ double red[kCamWaves][36];
+    const int2 ab = blk_ab[blockIdx.x];
+    double ta[kCamTab], tb[kCamTab];
+#pragma unroll
+    for (int k = 0; k < kCamTab; ++k) { ta[k] = camtab[(size_t)ab.x * kCamTab + k]; tb[k] = camtab[(size_t)ab.y * kCamTab + k]; }
+    double s[36];
+#pragma unroll
+    for (int q = 0; q < 36; ++q) s[q] = 0.0;
+    auto w_of = [&](const double* t, double X, double Y, double Z, double (&W)[6][3]) {
+        double jc[12], jp[6], rx, ry;
+        observe<true>(t, X, Y, Z, 0.0, 0.0, K, rx, ry, jc, jp);
+#pragma unroll
+        for (int u = 0; u < 6; ++u)
+#pragma unroll
+            for (int v = 0; v < 3; ++v) W[u][v] = jc[u] * jp[v] + jc[6 + u] * jp[3 + v];
+    };
+    for (int k = cov_ptr[blockIdx.x] + (int)threadIdx.x; k < cov_ptr[blockIdx.x + 1]; k += kCamThreads) {
+        const int p = cov_pt[k];
+        const double* __restrict__ Xp = pts + 3 * (size_t)p;
+        const double* __restrict__ vi = Vinv + 6 * (size_t)p;
+        const double X = Xp[0], Y = Xp[1], Z = Xp[2];
+        const double v0 = vi[0], v1 = vi[1], v2 = vi[2], v3 = vi[3], v4 = vi[4], v5 = vi[5];
+        double Wa[6][3], Wb[6][3];
+        w_of(ta, X, Y, Z, Wa);
+        if (ab.x != ab.y) w_of(tb, X, Y, Z, Wb);
+        else {
+#pragma unroll
+            for (int u = 0; u < 6; ++u)
+#pragma unroll
+                for (int v = 0; v < 3; ++v) Wb[u][v] = Wa[u][v];
+        }
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const double y0 = Wa[u][0] * v0 + Wa[u][1] * v1 + Wa[u][2] * v2;      // row u of W_a Vinv (Vinv packed upper)
+            const double y1 = Wa[u][0] * v1 + Wa[u][1] * v3 + Wa[u][2] * v4;
+            const double y2 = Wa[u][0] * v2 + Wa[u][1] * v4 + Wa[u][2] * v5;
+#pragma unroll
+            for (int v = 0; v < 6; ++v) s[6 * u + v] += y0 * Wb[v][0] + y1 * Wb[v][1] + y2 * Wb[v][2];
+        }
+    }
+    const double tot = cam_block_total<36>(s, red);              // lanes, then the four waves in wave order
+    if (threadIdx.x < 36) Sblk[(size_t)blockIdx.x * 36 + threadIdx.x] = tot;
+}
+
+typedef double dense_acc_t __attribute__((ext_vector_type(4)));
+
+// Solve (U + Dc - blk) dc = -g_c - acc for the camera step.  One workgroup of 256 threads; the matrix lives in LDS
+// as (T + 1) x T tiles of 16 x 16 (lower triangle used; tile row T carries the right-hand side in its first row),
+// leading dimension npad + 1.  The step goes to x of PCG vector set 0 and the control block says "converged, 0
+// iterations, set 0", which is what the back substitution and the host read; a non-positive pivot reports a
+// breakdown (done = 3) with a zero step, like the PCG does.
+__global__ __launch_bounds__(256) void k_dense_schur_solve(const double* __restrict__ Sblk, const double* __restrict__ Ugc,
+                                                           const double* __restrict__ Dc, const double* __restrict__ acc,
+                                                           int C, double* __restrict__ vecs, PcgCtrl* __restrict__ ctrl2) {
+    extern __shared__ __align__(16) double A[];
+    __shared__ double sv[kDenseTile];
+    __shared__ int s_bad;
+    const int n = 6 * C, T = (n + kDenseTile - 1) / kDenseTile, npad = T * kDenseTile, ld = npad + 1;
+    // behind the matrix in the dynamic region (the static part of a kernel that asks for the full 160 KiB has to
+    // stay small): solution, diagonal of S before elimination, unknowns dropped from the solve (kDensePivotTol)
+    double* xv = A + (size_t)(npad + kDenseTile) * ld;
+    double* dg = xv + kDenseMaxN;
+    double* rdg = dg + kDenseMaxN;              // 1 / L_jj (0 for a dropped unknown)
+    double* bsum = rdg + kDenseMaxN;            // [16][16] partial sums of the back substitution
+    int* skipf = reinterpret_cast<int*>(bsum + kDenseTile * kDenseTile);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    auto at = [&](int r, int c) -> double& { return A[(size_t)r * ld + c]; };
+    if (tid == 0) s_bad = 0;
+    for (int e = tid; e < (npad + kDenseTile) * ld; e += blockDim.x) A[e] = 0.0;
+    __syncthreads();
+    // lower triangle from the blocks: entry (6b+v, 6a+u), a <= b, is -blk[a][b][u][v] (+ U, Dc on the diagonal blocks)
+    const int nblk = C * (C + 1) / 2;
+    for (int e = tid; e < nblk * 36; e += blockDim.x) {
+        const int blk = e / 36, uv = e - blk * 36, u = uv / 6, v = uv - 6 * u;
+        int a = 0, rem = blk;
+        while (rem >= C - a) { rem -= C - a; ++a; }                 // blk = dense_block_index(a, b): small C
+        const int b = a + rem;
+        double val = -Sblk[e];
+        if (a == b) {
+            if (u > v) continue;                                     // diagonal block: take (u <= v), store at row v, col u
+            val += Ugc[(size_t)a * 27 + (u * 6 - u * (u - 1) / 2 + (v - u))];
+            if (u == v) val += Dc[(size_t)u * C + a];
+        }
+        at(6 * b + v, 6 * a + u) = val;
+    }
+    for (int e = n + tid; e < npad; e += blockDim.x) at(e, e) = 1.0;  // padding: identity
+    __syncthreads();
+    for (int e = tid; e < npad; e += blockDim.x) { dg[e] = at(e, e); skipf[e] = 0; }
+    for (int e = tid; e < n; e += blockDim.x) {                       // right-hand side row
+        const int c = e / 6, k = e - 6 * c;
+        at(npad, e) = -Ugc[(size_t)c * 27 + 21 + k] - acc[(size_t)k * C + c];
+    }
+    __syncthreads();
+    for (int k = 0; k < T; ++k) {
+        const int o = k * kDenseTile;
+        if (wave == 0) {                          // diagonal tile: lanes 0..15 hold one row each (registers + v_readlane)
+            const int row = lane & 15;
+            double a[kDenseTile];
+#pragma unroll
+            for (int c = 0; c < kDenseTile; ++c) a[c] = at(o + row, o + c);
+            bool bad = false;
+#pragma unroll
+            for (int j = 0; j < kDenseTile; ++j) {
+                double s = a[j];
+#pragma unroll
+                for (int q = 0; q < j; ++q) s -= a[q] * readlane_double(a[q], j);
+                const double d = readlane_double(s, j);
+                if (!isfinite(d)) bad = true;
+                const bool sk = !(d > kDensePivotTol * dg[o + j]);            // wave-uniform
+                const double rpiv = sk ? 1.0 : rsqrt(d);                      // one reciprocal square root instead of
+                const double piv = sk ? 1.0 : d * rpiv;                       // a square root and a division per column
+                a[j] = (row == j) ? piv : (sk ? 0.0 : s * rpiv);
+                if (lane == 0) { skipf[o + j] = sk ? 1 : 0; rdg[o + j] = sk ? 0.0 : rpiv; }
+            }
+            if (lane < kDenseTile) {
+#pragma unroll
+                for (int c = 0; c < kDenseTile; ++c) at(o + row, o + c) = (c <= row) ? a[c] : 0.0;
+                if (bad && lane == 0) s_bad = 1;
+            }
+        }
+        __syncthreads();
+        {   // panel below the diagonal tile (and the right-hand-side row): x L_kk^T = a, one row per thread
+            const int r = o + kDenseTile + tid;
+            if (r < npad + 1) {
+                double x[kDenseTile];
+#pragma unroll
+                for (int c = 0; c < kDenseTile; ++c) x[c] = at(r, o + c);
+#pragma unroll
+                for (int j = 0; j < kDenseTile; ++j) {
+                    double s = x[j];
+#pragma unroll
+                    for (int q = 0; q < j; ++q) s -= x[q] * at(o + j, o + q);
+                    x[j] = s * rdg[o + j];                            // 1 / L_jj, 0 for a dropped unknown
+                }
+#pragma unroll
+                for (int c = 0; c < kDenseTile; ++c) at(r, o + c) = x[c];
+            }
+        }
+        __syncthreads();
+        // trailing update on the matrix cores: tile (i, j), k < j <= i <= T: A_ij -= L_ik L_jk^T
+        {
+            const int m = T - k;                          // tile rows k+1 .. T  (T = the right-hand-side row block)
+            const int ntile = m * (m + 1) / 2 - (T > k ? 1 : 0);      // lower triangle of (m x m) without (T, T)
+            for (int t = wave; t < ntile; t += (int)(blockDim.x >> 6)) {
+                int ii = 0, rem = t;
+                while (rem > ii) { rem -= ii + 1; ++ii; }             // t -> (ii, jj) with jj <= ii, row-major lower
+                const int i = k + 1 + ii, j = k + 1 + rem;
+                const int ri = i * kDenseTile, rj = j * kDenseTile;
+                dense_acc_t c;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) c[q] = at(ri + (lane >> 4) + 4 * q, rj + (lane & 15));
+#pragma unroll
+                for (int mch = 0; mch < 4; ++mch) {
+                    const double av = -at(ri + (lane & 15), o + 4 * mch + (lane >> 4));
+                    const double bv = at(rj + (lane & 15), o + 4 * mch + (lane >> 4));
+                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, c, 0, 0, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) at(ri + (lane >> 4) + 4 * q, rj + (lane & 15)) = c[q];
+            }
+        }
+        __syncthreads();
+    }
+    // back substitution L^T x = y (y = the right-hand-side row after the forward sweep)
+    for (int k = T - 1; k >= 0; --k) {
+        const int o = k * kDenseTile;
+        {   // s_t = y_t - sum_{r below the tile} L[r][t] x_r : 16 columns x 16 row groups, then the groups in order
+            const int t = tid & 15, g = tid >> 4;
+            double s = 0.0;
+            for (int r = o + kDenseTile + g; r < npad; r += 16) s += at(r, o + t) * xv[r];
+            bsum[g * kDenseTile + t] = s;
+        }
+        __syncthreads();
+        if (tid < kDenseTile) {
+            double s = at(npad, o + tid);
+#pragma unroll
+            for (int g = 0; g < 16; ++g) s -= bsum[g * kDenseTile + tid];
+            sv[tid] = s;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const int t = lane & 15;
+            double cl[kDenseTile];
+#pragma unroll
+            for (int q = 0; q < kDenseTile; ++q) cl[q] = at(o + q, o + t);           // column t of L_kk
+            double s = sv[t], xres = 0.0;
+#pragma unroll
+            for (int j = kDenseTile - 1; j >= 0; --j) {
+                const double xj = readlane_double(s * rdg[o + j], j);            // rdg = 0 for a dropped unknown
+                s -= cl[j] * xj;
+                if (t == j) xres = xj;
+            }
+            if (lane < kDenseTile) xv[o + t] = xres;
+        }
+        __syncthreads();
+    }
+    const bool bad = s_bad != 0;
+    const size_t n6 = (size_t)n;
+    for (int e = tid; e < n; e += blockDim.x) {
+        const int c = e / 6, k = e - 6 * c;
+        const double x = xv[e];
+        vecs[kPcgX * n6 + (size_t)k * C + c] = (bad || !isfinite(x)) ? 0.0 : x;
+    }
+    if (tid == 0) {
+        PcgCtrl c0;
+        c0.rz = 0.0; c0.rz0 = 0.0; c0.tol2 = 0.0; c0.rz_prev = 1.0; c0.alpha_prev = 1.0;
+        int nskip = 0;
+        for (int e = 0; e < n; ++e) nskip += skipf[e];
+        c0.iters = 0; c0.max_iters = nskip; c0.done = bad ? 3 : 1; c0.pad = 2;     // max_iters: unknowns dropped
+        ctrl2[0] = c0;
+        ctrl2[1] = c0;
+    }
+}
+
 // PCG on the reduced camera system S dc = rhs in the single-reduction (Chronopoulos-Gear) form, so
 // that one sweep (w = S u) and ONE small update kernel make an iteration:
 //     delta = (w,u); beta = gamma/gamma_prev; alpha = gamma / (delta - beta gamma / alpha_prev)

@@ -217,11 +217,15 @@ struct sfmba_handle {
     bool f32_next = false;                   // takes effect at the next sfmba_set_problem
     bool lds_tab = true, lds_vec = true;     // camera table (K1, K2) / camera vector (sweeps) staged in LDS
     bool sweep_rc = false;                   // pass A recomputes the blocks from an LDS table (k_point_sweep_rc)
+    bool dense = false;                      // reduced camera matrix formed and factorised (6 C <= kDenseMaxN) instead of PCG
+    DevBuf cov_ptr, cov_pt, blk_ab, Sblk;    // dense path: per block pair (a <= b) the points both cameras see
+    int n_blk = 0;
     // test / diagnostic hooks, set through sfmba_debug_option only (nothing reads the environment)
     struct Debug {
         int pcg_fused = -1;                  // 0: two-kernel PCG although the fused launch would fit
         int tab_lds = -1, vec_lds = -1;      // 0: camera table / camera vector read from L2 although LDS would fit
         int sweep_rc = -1;                   // 0: pass A reads the stored Jacobian although the recomputing form would fit
+        int dense = -1;                      // 0: PCG although the dense reduced-camera path would apply
         int cam_chunk = 0;                   // > 0: chunk length of the camera-major kernels
         int pcg_guess_bias = 0;              // added to the number of speculatively enqueued PCG iterations
         int trace_pcg = 0, trace_stalls = 0, trace_timing = 0;   // stderr diagnostics
@@ -682,6 +686,27 @@ int launch_cam_schur(sfmba_handle* h, const double* vin, const double* zin, cons
     return launch_cam_combine(h, 6, h->acc(), 1, (int)h->C, nullptr, ctrl_done ? &ctrl_done->done : nullptr);
 }
 
+// Dense reduced-camera path: form the block pairs of W V^-1 W^T, factorise S = U + Dc - (...) in one workgroup and
+// leave the camera step where the PCG would have left it (x of vector set 0, control block "converged").
+// acc must hold the reduced right-hand-side term (pass B, MODE 1).
+int launch_dense_solve(sfmba_handle* h) {
+    hipLaunchKernelGGL(k_schur_blocks, dim3(h->n_blk), dim3(kCamThreads), 0, h->stream, (const int*)h->cov_ptr.as<int>(),
+                       (const int*)h->cov_pt.as<int>(), (const int2*)h->blk_ab.as<int2>(), (const double*)h->tab,
+                       (const double*)(h->x + 6 * h->C), (const double*)h->Vinv.as<double>(), h->K, h->Sblk.as<double>());
+    LAUNCHED(h);
+    const int n = 6 * (int)h->C, npad = (n + kDenseTile - 1) / kDenseTile * kDenseTile;
+    const size_t lds = sizeof(double) * ((size_t)(npad + kDenseTile) * (size_t)(npad + 1) + 3 * kDenseMaxN +
+                                         kDenseTile * kDenseTile) + sizeof(int) * kDenseMaxN;
+                                         // matrix | solution | diagonal | 1 / L_jj | partial sums | dropped flags
+    CHK(set_lds(h, k_dense_schur_solve, lds));
+    hipLaunchKernelGGL(k_dense_schur_solve, dim3(1), dim3(256), lds, h->stream, (const double*)h->Sblk.as<double>(),
+                       (const double*)h->Ugc(), (const double*)h->Dc.as<double>(), (const double*)h->acc(), (int)h->C,
+                       h->vecs.as<double>(), h->ctrl.as<PcgCtrl>());
+    LAUNCHED(h);
+    h->pcg_L = 0;
+    return 0;
+}
+
 // acc = (S - Dc) v for a plane-major vector v outside the PCG (test and timing entries): pass A, pass B
 int schur_product_standalone(sfmba_handle* h, const double* v_planes) {
     const double* va = v_planes;
@@ -1029,6 +1054,7 @@ int sfmba_debug_option(sfmba_handle* h, const char* name, int64_t value) {
     const int v = (int)value;
     if (n == "pcg_fused") h->dbg.pcg_fused = v;
     else if (n == "sweep_rc") h->dbg.sweep_rc = v;
+    else if (n == "dense") h->dbg.dense = v;
     else if (n == "tab_lds") h->dbg.tab_lds = v;
     else if (n == "vec_lds") h->dbg.vec_lds = v;
     else if (n == "cam_chunk") h->dbg.cam_chunk = v;
@@ -1453,6 +1479,34 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
         chunk_ptr[C] = (int)chunks.size();
         h->n_chunks = (int)chunks.size();
     }
+    // dense reduced-camera path (few cameras): for every block pair (a <= b) the points seen by both cameras, with
+    // multiplicity (a point seen m_a, m_b times contributes m_a m_b times); two counting passes over the runs
+    h->dense = 6 * C <= kDenseMaxN && h->dbg.dense != 0;
+    std::vector<int> cov_ptr, cov_pt;
+    std::vector<int2> blk_ab;
+    if (h->dense) {
+        const int nblk = (int)(C * (C + 1) / 2);
+        cov_ptr.assign((size_t)nblk + 1, 0);
+        int64_t total = 0;
+        for (int64_t p = 0; p < P && total <= ((int64_t)1 << 26); ++p)
+            for (int i = ptr[p]; i < ptr[p + 1]; ++i)
+                for (int j = ptr[p]; j < ptr[p + 1]; ++j)
+                    if (ci[i] <= ci[j]) { ++cov_ptr[(size_t)dense_block_index(ci[i], ci[j], (int)C) + 1]; ++total; }
+        if (total > ((int64_t)1 << 26)) h->dense = false;      // very long tracks: the pair lists would not pay
+        else {
+            for (int b = 0; b < nblk; ++b) cov_ptr[(size_t)b + 1] += cov_ptr[b];
+            cov_pt.resize((size_t)std::max<int64_t>(1, total));
+            std::vector<int> fill(cov_ptr.begin(), cov_ptr.end() - 1);
+            for (int64_t p = 0; p < P; ++p)
+                for (int i = ptr[p]; i < ptr[p + 1]; ++i)
+                    for (int j = ptr[p]; j < ptr[p + 1]; ++j)
+                        if (ci[i] <= ci[j]) cov_pt[(size_t)fill[dense_block_index(ci[i], ci[j], (int)C)]++] = (int)p;
+            blk_ab.resize((size_t)nblk);
+            for (int a = 0; a < (int)C; ++a)
+                for (int b = a; b < (int)C; ++b) blk_ab[(size_t)dense_block_index(a, b, (int)C)] = make_int2(a, b);
+            h->n_blk = nblk;
+        }
+    }
     tp2 = now_s();
     h->lds_tab = (size_t)C * kCamTab * sizeof(double) <= kLdsDynMax;
     h->lds_vec = (size_t)C * 6 * sizeof(double) <= kLdsDynMax;
@@ -1488,6 +1542,12 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     HIPCHK(h, h->cam_chunk_ptr.ensure(sizeof(int) * chunk_ptr.size()));
     HIPCHK(h, h->cam_partial.ensure(sizeof(double) * 27 * chunks.size()));
     HIPCHK(h, h->z.ensure(sizeof(double) * 3 * P));
+    if (h->dense) {
+        HIPCHK(h, h->cov_ptr.ensure(sizeof(int) * cov_ptr.size()));
+        HIPCHK(h, h->cov_pt.ensure(sizeof(int) * cov_pt.size()));
+        HIPCHK(h, h->blk_ab.ensure(sizeof(int2) * blk_ab.size()));
+        HIPCHK(h, h->Sblk.ensure(sizeof(double) * 36 * blk_ab.size()));
+    }
     HIPCHK(h, h->t1.ensure(esz * 2 * ldz));
     HIPCHK(h, h->V.ensure(sizeof(double) * 6 * P));
     HIPCHK(h, h->Vinv.ensure(sizeof(double) * 6 * P));
@@ -1536,6 +1596,11 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     HIPCHK(h, hipMemsetAsync(h->p.p, 0, sizeof(double) * h->n, h->stream));      // ... and their step is 0
     HIPCHK(h, hipMemsetAsync(h->r.p, 0, esz * 2 * ldz, h->stream));
     HIPCHK(h, hipMemsetAsync(h->z.p, 0, sizeof(double) * 3 * P, h->stream));      // points without observations keep z = 0
+    if (h->dense) {      // pageable sources: these copies are synchronous, the vectors may go out of scope afterwards
+        HIPCHK(h, hipMemcpyAsync(h->cov_ptr.p, cov_ptr.data(), sizeof(int) * cov_ptr.size(), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->cov_pt.p, cov_pt.data(), sizeof(int) * cov_pt.size(), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->blk_ab.p, blk_ab.data(), sizeof(int2) * blk_ab.size(), hipMemcpyHostToDevice, h->stream));
+    }
     HIPCHK(h, hipMemcpyAsync(h->cm_perm.p, perm, sizeof(int) * ldz, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->cam_chunks.p, chunks.data(), sizeof(int4) * chunks.size(), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->cam_chunk_ptr.p, chunk_ptr.data(), sizeof(int) * chunk_ptr.size(), hipMemcpyHostToDevice, h->stream));
@@ -1642,6 +1707,62 @@ int sfmba_schur_matvec(sfmba_handle* h, const double* x, const double* dc, const
     for (int64_t c = 0; c < C; ++c)
         for (int k = 0; k < 6; ++k) y[6 * c + k] = a[k * C + c] + dc[6 * c + k] * v[6 * c + k];
     HIPCHK(h, hipMemsetAsync(h->acc(), 0, sizeof(double) * 6 * C, h->stream));
+    return 0;
+}
+
+int sfmba_dense_schur(sfmba_handle* h, const double* x, const double* dc, const double* dp, const double* rhs,
+                      double* S_out, double* sol_out) {
+    CHK(enter(h));
+    CHK(check_ready(h, x));
+    if (!dc || !dp || !rhs || !sol_out) return fail(h, -1, "NULL argument");
+    if (!h->dense) return fail(h, -1, "the dense reduced-camera path needs 6 * n_cameras <= %d", kDenseMaxN);
+    const int64_t C = h->C;
+    CHK(upload_x(h, x));
+    CHK(launch_cam_table(h, h->x, h->tab));
+    int np = 0;
+    CHK((launch_resjac<true, true>(h, h->x, h->tab, &np)));
+    CHK(launch_normal_blocks(h, h->x, h->tab));
+    CHK(exchange(h, h->Ugc(), 27 * C, 0));
+    std::vector<double> ugc(27 * C), planes(6 * C), accp(6 * C);
+    HIPCHK(h, hipMemcpyAsync(ugc.data(), h->Ugc(), sizeof(double) * 27 * C, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int64_t c = 0; c < C; ++c)
+        for (int k = 0; k < 6; ++k) {
+            planes[k * C + c] = dc[6 * c + k];
+            accp[k * C + c] = -ugc[27 * c + 21 + k] - rhs[6 * c + k];      // the kernel solves S y = -g_c - acc
+        }
+    HIPCHK(h, hipMemcpyAsync(h->e.p, dp, sizeof(double) * 3 * h->P, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->Dc.p, planes.data(), sizeof(double) * 6 * C, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->acc(), accp.data(), sizeof(double) * 6 * C, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_point_prep, dim3((h->P + 255) / 256), dim3(256), 0, h->stream, h->V.as<double>(),
+                       h->gp.as<double>(), (const double*)nullptr, h->e.as<double>(), (int)h->P, 0.0,
+                       h->Vinv.as<double>(), (double*)nullptr);
+    LAUNCHED(h);
+    CHK(launch_dense_solve(h));
+    std::vector<double> blk(36 * (size_t)h->n_blk), sol(6 * C);
+    HIPCHK(h, hipMemcpyAsync(blk.data(), h->Sblk.p, sizeof(double) * blk.size(), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(sol.data(), h->vecs.p, sizeof(double) * 6 * C, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int64_t c = 0; c < C; ++c)
+        for (int k = 0; k < 6; ++k) sol_out[6 * c + k] = sol[k * C + c];
+    if (S_out) {
+        const int64_t n = 6 * C;
+        for (int64_t a = 0; a < C; ++a)
+            for (int64_t b = a; b < C; ++b) {
+                const double* B = blk.data() + 36 * (size_t)dense_block_index((int)a, (int)b, (int)C);
+                for (int u = 0; u < 6; ++u)
+                    for (int v = 0; v < 6; ++v) {
+                        double val = -B[6 * u + v];
+                        if (a == b) {
+                            const int lo = std::min(u, v), hi = std::max(u, v);
+                            val += ugc[27 * a + (lo * 6 - lo * (lo - 1) / 2 + (hi - lo))];
+                            if (u == v) val += dc[6 * a + u];
+                        }
+                        S_out[(6 * a + u) * n + 6 * b + v] = val;
+                        if (a != b) S_out[(6 * b + v) * n + 6 * a + u] = val;
+                    }
+            }
+    }
     return 0;
 }
 
@@ -1849,9 +1970,12 @@ static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt
         }
         CHK(launch_cam_schur<1>(h, nullptr, h->e.as<double>(), nullptr, 0));      // reduced rhs term -> acc
         CHK(exchange(h, h->acc(), 6 * C, 0));
-        CHK(pcg_start(h, opt));                                 // replaces lsmr, trf.py:477-480
+        const bool dense = h->dense && one_rank;               // (sharded: the block pairs would need their own all-reduce)
+        if (!dense) CHK(pcg_start(h, opt));                     // replaces lsmr, trf.py:477-480
         PcgCtrl hc{};
-        if (pcg_guess > 0) {
+        if (dense) {
+            CHK(launch_dense_solve(h));                         // exact solve of the reduced camera system
+        } else if (pcg_guess > 0) {
             // speculative: no read-back; surplus launches are no-ops.  Fused launches apply the update of
             // iteration k in launch k + 1, so k iterations need k + 1 launches; one spare either way.
             CHK(pcg_enqueue(h, pcg_guess + (h->pcg_fused ? 2 : 1)));
@@ -1925,7 +2049,7 @@ static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt
             if (with_ctrl) memcpy(&hc, h->mbox + kMboxCtrl, sizeof hc);
             return 0;
         };
-        const bool speculated = pcg_guess > 0;
+        const bool speculated = pcg_guess > 0 || dense;         // dense: the control block always says "finished"
         bool missed = false;
         for (bool speculative = speculated;;) {
             hipLaunchKernelGGL(k_tr_step, dim3(1), dim3(one_rank ? 1024 : 64), 0, h->stream, sc, Delta,

@@ -19,7 +19,7 @@ SYMBOLS = (
     "sfmba_residual_jacobian", "sfmba_solve", "sfmba_get_fun_grad", "sfmba_time_kernel",
     "sfmba_normal_blocks", "sfmba_schur_matvec", "sfmba_comm_get_unique_id", "sfmba_comm_init",
     "sfmba_comm_destroy", "sfmba_set_precision", "sfmba_p2p_export", "sfmba_p2p_attach", "sfmba_p2p_detach",
-    "sfmba_p2p_calls", "sfmba_tr2d_solve", "sfmba_debug_option", "sfmba_set_print", "sfmba_get_counters", "sfmba_problem_reuse",
+    "sfmba_p2p_calls", "sfmba_tr2d_solve", "sfmba_debug_option", "sfmba_set_print", "sfmba_get_counters", "sfmba_problem_reuse", "sfmba_dense_schur",
 )
 
 
@@ -77,6 +77,8 @@ def load():
     lib.sfmba_time_kernel.argtypes = [P, P, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
     lib.sfmba_normal_blocks.argtypes = [P, P, P, P, P, P]
     lib.sfmba_schur_matvec.argtypes = [P, P, P, P, P, P]
+    lib.sfmba_dense_schur.argtypes = [P, P, P, P, P, P, P]
+    lib.sfmba_dense_schur.restype = C.c_int
     lib.sfmba_tr2d_solve.argtypes = [P, P, C.c_double, P]
     lib.sfmba_comm_get_unique_id.argtypes = [P]
     lib.sfmba_comm_init.argtypes = [P, P, C.c_int32, C.c_int32, C.c_int64]

@@ -210,6 +210,17 @@ class Backend:
                                                  _capi.ptr(v), _capi.ptr(y)))
         return y
 
+    def dense_schur(self, x, dc, dp, rhs):
+        """(S, y): the reduced camera matrix formed by the dense path and the solution of S y = rhs."""
+        x = _f64(x, (self.n_params,), "x")
+        dc, dp, rhs = _f64(dc).reshape(-1), _f64(dp).reshape(-1), _f64(rhs).reshape(-1)
+        n = 6 * self.n_cameras
+        S = np.empty((n, n))
+        y = np.empty(n)
+        self._check(self._lib.sfmba_dense_schur(self._h, _capi.ptr(x), _capi.ptr(dc), _capi.ptr(dp), _capi.ptr(rhs),
+                                                _capi.ptr(S), _capi.ptr(y)))
+        return S, y
+
     def time_kernel(self, x, which: int, reps: int) -> float:
         x = _f64(x, (self.n_params,), "x")
         us = C.c_double()

@@ -93,7 +93,7 @@ def test_apply_bundle_adjustment_end_to_end(orc):
     assert (pn_cam, pn_pts, pcmap) == (n_cam, n_pts, cmap) and n_cam == 6
     assert np.array_equal(pci, ci) and np.array_equal(ppi, pi) and np.array_equal(puv, uv)
     assert np.abs(px0 - x0).max() < 1e-13
-    o = orc.trf_schur(x0, n_cam, n_pts, ci, pi, uv, K, ftol=1e-10, linear="pcg", pcg_tol=1e-3)
+    o = orc.trf_schur(x0, n_cam, n_pts, ci, pi, uv, K, ftol=1e-10, linear="dense")     # 6 cameras: dense path
     H_ref, X_ref = orc.unpack_result(o.x, n_cam, n_pts, cmap, H0)
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
@@ -103,11 +103,18 @@ def test_apply_bundle_adjustment_end_to_end(orc):
     assert abs(res.cost - o.cost) <= 1e-9 * o.cost
     assert np.array_equal(H_new[2], H0[2])                        # the unregistered node keeps its pose
     for k in range(len(H0)):
-        assert np.abs(H_new[k] - H_ref[k]).max() < 1e-6
         if registered[k]:
             R = H_new[k][:3, :3]
             assert np.abs(R @ R.T - np.eye(3)).max() < 1e-12 and np.array_equal(H_new[k][3], [0, 0, 0, 1])
-    assert np.abs(X_new - X_ref).max() < 1e-6
+    # No camera is held fixed (sfm.py:264), so poses and cloud are determined up to a similarity transform, and the
+    # component of a step along those 7 directions is rounding noise divided by the damping term: it differs between
+    # two factorisations of the same matrix.  What is determined is compared: the reprojection of every observation.
+    xg = orc.pack_problem(H_new, registered, X_new, obs)[0]
+    xr = orc.pack_problem(H_ref, registered, X_ref, obs)[0]
+    rg = orc.compute_residuals(xg, n_cam, n_pts, ci, pi, uv, K)
+    rr = orc.compute_residuals(xr, n_cam, n_pts, ci, pi, uv, K)
+    assert np.abs(rg - rr).max() < 1e-5 and np.abs(rg - res.fun).max() < 1e-8
+    assert np.abs(H_new[0] - H_ref[0]).max() < 5e-2 and np.abs(X_new - X_ref).max() < 5e-2      # same basin
 
 
 def test_verbose_table_matches_scipy_format():

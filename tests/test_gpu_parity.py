@@ -220,7 +220,7 @@ def dbg():
             b.debug_option(name, value)
             touched.append((b, name))
     yield set_
-    defaults = dict(pcg_fused=-1, tab_lds=-1, vec_lds=-1, cam_chunk=0, pcg_guess_bias=0, sweep_rc=-1)
+    defaults = dict(pcg_fused=-1, tab_lds=-1, vec_lds=-1, cam_chunk=0, pcg_guess_bias=0, sweep_rc=-1, dense=-1)
     for b, name in touched:
         b.debug_option(name, defaults[name])
 
@@ -269,19 +269,27 @@ def test_results_are_bitwise_reproducible(be):
 
 # ---- A5-A9: the solver -------------------------------------------------------------------------------
 
-def test_solve_matches_scipy_on_tiny_problems(orc):
+def _oracle_kwargs(dense):
+    """The reduced camera system is solved exactly (formed and factorised) when 6 C <= 128, by block-Jacobi PCG to
+    1e-3 otherwise or when the debug option `dense` is 0: the oracle restates both."""
+    return dict(linear="dense") if dense else dict(linear="pcg", pcg_tol=1e-3)
+
+
+def test_solve_matches_scipy_on_tiny_problems(orc, dbg):
     """Stated tolerance (BASELINE.json north_star): final reprojection RMSE within 1e-6 px of the scipy
     reference on identical inputs.  scipy stops in a slow tail (optimality ~1e-1), so our cost may only
     be lower; the residual vectors agree to 5e-2 px."""
     import sfmba
     g = np.load(os.path.join(GOLDEN, "lsq_tiny_cases.npz"))
-    for k in range(int(g["n_cases"])):
+    for k, dense in [(k, d) for k in range(int(g["n_cases"])) for d in (True, False)]:
+        dbg((sfmba.get_backend(0),), "dense", -1 if dense else 0)
         pre = f"l{k}_"
         C, P, N = (int(v) for v in g[pre + "dims"])
         pb = sfmba.make_problem(C, P, N, seed=int(g[pre + "seed"]))
         status, nfev, njev, cost, rmse, opt = g[pre + "summary"]
         res = sfmba.least_squares(sfmba.compute_residuals, pb.x0, jac_sparsity=None, verbose=0,
                                   x_scale="jac", ftol=1e-10, method="trf", args=pb.args)
+        assert (res.pcg_iterations == 0) == dense
         assert res.success and res.status in (1, 2, 3, 4)
         my_rmse = float(np.sqrt(np.mean(res.fun ** 2)))
         assert abs(my_rmse - rmse) < 1e-6
@@ -289,8 +297,9 @@ def test_solve_matches_scipy_on_tiny_problems(orc):
         assert res.cost <= cost * (1 + 1e-9)
         assert np.abs(res.fun - g[pre + "fun"]).max() < 5e-2
         # and against the oracle's restatement of the same algorithm
-        o = orc.trf_schur(pb.x0, *pb.args, ftol=1e-10, linear="pcg", pcg_tol=1e-3)
+        o = orc.trf_schur(pb.x0, *pb.args, ftol=1e-10, **_oracle_kwargs(dense))
         assert abs(res.cost - o.cost) <= 1e-8 * o.cost
+        assert (res.status, res.nfev, res.njev) == (o.status, o.nfev, o.njev)
         # result.fun / result.grad are consistent with result.x
         r = orc.compute_residuals(res.x, *pb.args)
         assert np.abs(r - res.fun).max() < 1e-8
@@ -313,30 +322,45 @@ def test_solve_cfg2_matches_recorded_scipy_run(orc):
     assert res.nfev <= rec["nfev"]
 
 
-def test_rejected_steps_and_nfev_limit_follow_the_oracle(orc):
+@pytest.mark.parametrize("dense", [True, False])
+def test_rejected_steps_and_nfev_limit_follow_the_oracle(orc, dbg, dense):
     """Far starts (x0 noise 0.2) make the trust region reject steps: the retry path (2-D model re-solved
     with a smaller radius, speculative normal blocks discarded) and the max_nfev exit must follow the
-    oracle's restatement of trf_no_bounds."""
+    oracle's restatement of trf_no_bounds.
+
+    With the exact (dense) step the comparison is made on what the problem determines.  No camera is held fixed
+    (bundle_adjustment.py:6), so the reduced camera matrix is singular along the 7 gauge directions up to the
+    damping term; the component of an exact step along them is rounding noise over that term and differs between
+    numpy's pivoted LU and the in-LDS Cholesky.  It moves x (and the step norm of the xtol test, so the final status
+    may read 2 where the oracle's reads 4) but neither cost nor residuals."""
     import sfmba
+    dbg((sfmba.get_backend(0),), "dense", -1 if dense else 0)
     saw_rejection = False
     for seed in (1, 2, 5):
         pb = sfmba.make_problem(6, 80, 500, seed=seed, x0_noise=0.2)
-        o = orc.trf_schur(pb.x0, *pb.args, ftol=1e-10, linear="pcg", pcg_tol=1e-3)
+        o = orc.trf_schur(pb.x0, *pb.args, ftol=1e-10, **_oracle_kwargs(dense))
         res = sfmba.least_squares(sfmba.compute_residuals, pb.x0, x_scale="jac", ftol=1e-10, method="trf",
                                   args=pb.args)
-        assert res.status == o.status
+        if dense:
+            assert res.status in (2, 3, 4) and o.status in (2, 3, 4)
+            assert abs(res.nfev - o.nfev) <= 1 and abs(res.njev - o.njev) <= 1
+        else:
+            assert res.status == o.status
+            assert (res.nfev, res.njev) == (o.nfev, o.njev)
         assert abs(res.cost - o.cost) <= 1e-8 * o.cost
-        assert (res.nfev, res.njev) == (o.nfev, o.njev)
         saw_rejection |= res.nfev > res.njev
     assert saw_rejection
     pb = sfmba.make_problem(6, 80, 500, seed=5, x0_noise=0.2)
     for max_nfev in range(2, 14):
-        o = orc.trf_schur(pb.x0, *pb.args, ftol=1e-10, linear="pcg", pcg_tol=1e-3, max_nfev=max_nfev)
+        o = orc.trf_schur(pb.x0, *pb.args, ftol=1e-10, max_nfev=max_nfev, **_oracle_kwargs(dense))
         res = sfmba.least_squares(sfmba.compute_residuals, pb.x0, x_scale="jac", ftol=1e-10, method="trf",
                                   args=pb.args, max_nfev=max_nfev)
         assert res.status == o.status == 0 and res.nfev == o.nfev == max_nfev
         assert abs(res.cost - o.cost) <= 1e-8 * o.cost
-        assert np.abs(res.x - o.x).max() <= 1e-6 * np.abs(o.x).max()
+        if dense:
+            assert np.abs(res.fun - o.fun).max() <= 1e-5 * max(1.0, np.abs(o.fun).max())
+        else:
+            assert np.abs(res.x - o.x).max() <= 1e-6 * np.abs(o.x).max()
         r = orc.compute_residuals(res.x, *pb.args)
         assert np.abs(r - res.fun).max() < 1e-8            # result.fun belongs to result.x
 
@@ -348,6 +372,7 @@ def test_speculative_pcg_miss_changes_nothing(dbg):
     (debug option pcg_guess_bias shifts the guess; -5 makes every speculative batch fall short.)"""
     import sfmba
     tls = sfmba.get_backend(0)
+    dbg((tls,), "dense", 0)                    # these sizes would take the dense path, which has no PCG to speculate on
     for pb in (sfmba.make_config("cfg2"), sfmba.make_problem(6, 80, 500, seed=5, x0_noise=0.2)):
         runs = []
         for bias in (0, -5, 4):
@@ -368,6 +393,7 @@ def test_fused_pcg_launch_equals_sweep_plus_update(dbg):
     k_pcg_update (debug option pcg_fused = 0, read at set_problem)."""
     import sfmba
     tls = sfmba.get_backend(0)
+    dbg((tls,), "dense", 0)
     for pb in (sfmba.make_config("cfg2"), sfmba.make_problem(300, 4000, 30000, seed=3),
                sfmba.make_problem(6, 80, 500, seed=5, x0_noise=0.2), sfmba.make_problem(1024, 3000, 20000, seed=8)):
         for rc in (-1, 0):
@@ -430,7 +456,8 @@ def test_unobserved_camera_and_point(orc):
     assert np.abs(res.jac.T @ res.fun - res.grad).max() <= 1e-9 * max(1.0, np.abs(res.grad).max())
 
 
-def test_ring_scene_large_rotations(orc):
+@pytest.mark.parametrize("dense", [True, False])
+def test_ring_scene_large_rotations(orc, dbg, dense):
     """Rotation vectors of every magnitude up to pi inside the solver (not only in K1): against scipy's
     recorded result and the oracle."""
     import sfmba
@@ -438,9 +465,10 @@ def test_ring_scene_large_rotations(orc):
     g = np.load(os.path.join(GOLDEN, "lsq_tiny_cases.npz"))
     pb = make_ring_problem(12, 150, 900, seed=1)
     status, nfev, njev, cost, rmse, opt = g["ring_summary"]
+    dbg((sfmba.get_backend(0),), "dense", -1 if dense else 0)
     res = sfmba.least_squares(sfmba.compute_residuals, pb.x0, x_scale="jac", ftol=1e-10, method="trf",
                               args=pb.args)
-    o = orc.trf_schur(pb.x0, *pb.args, ftol=1e-10, linear="pcg", pcg_tol=1e-3)
+    o = orc.trf_schur(pb.x0, *pb.args, ftol=1e-10, **_oracle_kwargs(dense))
     assert res.success and abs(res.rmse - rmse) < 1e-6 and res.cost <= cost * (1 + 1e-9)
     assert (res.status, res.nfev, res.njev) == (o.status, o.nfev, o.njev)
     assert abs(res.cost - o.cost) <= 1e-9 * o.cost
@@ -560,7 +588,7 @@ def test_fp32_storage_mode(orc):
 
 # ---- the N>1 code path on one GPU: world_size-1 RCCL through the same Exchange / callback plumbing -------
 
-def test_exchange_path_world1_nccl():
+def test_exchange_path_world1_nccl(dbg):
     """Runs a solve with the all-reduce callback active (torch.distributed backend nccl = RCCL, world
     size 1, exchange arena = a torch CUDA tensor, kernels and collectives on one torch stream) and
     checks that it reproduces the single-process result exactly."""
@@ -570,6 +598,7 @@ def test_exchange_path_world1_nccl():
     import sfmba
     from sfmba import dist as sdist
     pb = sfmba.make_problem(11, 3000, 10000, seed=0)
+    dbg((sfmba.get_backend(0),), "dense", 0)       # with a transport registered the solver takes the PCG path
     ref = sfmba.least_squares(sfmba.compute_residuals, pb.x0, x_scale="jac", ftol=1e-10, method="trf",
                               args=pb.args)
     with socket.socket() as s:
@@ -674,7 +703,7 @@ def _run_ranks(world, direct, dims=(11, 3000, 10000, 0, 0.01)):
     return out
 
 
-def test_direct_allreduce_over_peer_mapped_memory():
+def test_direct_allreduce_over_peer_mapped_memory(dbg):
     """The latency path of the collectives (k_p2p_allreduce): ranks map each other's staging buffers through
     hipIpc and all-reduce with one kernel per collective.  Here the ranks are 2 and 3 processes on the one
     GPU (on a node they are one per GPU over xGMI; the code path is the same).  Every collective of the
@@ -682,6 +711,7 @@ def test_direct_allreduce_over_peer_mapped_memory():
     bitwise replicated, result equal to the single-process solve."""
     import sfmba
     pb = sfmba.make_problem(11, 3000, 10000, seed=0)
+    dbg((sfmba.get_backend(0),), "dense", 0)       # sharded solves take the PCG path: so does the reference run
     ref = sfmba.least_squares(sfmba.compute_residuals, pb.x0, x_scale="jac", ftol=1e-10, method="trf",
                               args=pb.args)
     for world in (2, 3):
@@ -704,7 +734,7 @@ def test_direct_allreduce_over_peer_mapped_memory():
         assert abs(out["cost"] - ref.cost) <= 1e-9 * ref.cost
 
 
-def test_two_rank_solve_on_one_gpu_gloo():
+def test_two_rank_solve_on_one_gpu_gloo(dbg):
     """The production solver, observation-sharded over TWO processes that share the single GPU, with the
     callback transport over gloo: replicated cameras bitwise identical on both ranks, merged solution and
     cost equal to the single-process solve (and scipy's RMSE to 1e-6)."""
@@ -713,6 +743,7 @@ def test_two_rank_solve_on_one_gpu_gloo():
     import sfmba
     rec = json.load(open(os.path.join(GOLDEN, "scipy_cfg2_run.json")))
     pb = sfmba.make_problem(11, 3000, 10000, seed=0)
+    dbg((sfmba.get_backend(0),), "dense", 0)       # with a transport registered the solver takes the PCG path
     ref = sfmba.least_squares(sfmba.compute_residuals, pb.x0, x_scale="jac", ftol=1e-10, method="trf",
                               args=pb.args)
     with socket.socket() as s:
@@ -732,3 +763,48 @@ def test_two_rank_solve_on_one_gpu_gloo():
     assert abs(out["cost"] - ref.cost) <= 1e-10 * ref.cost
     assert abs(out["rmse"] - rec["rmse"]) < 1e-6
     assert np.abs(out["x"] - ref.x).max() <= 1e-6 * np.abs(ref.x).max()
+
+
+# ---- dense reduced-camera path (few cameras): S formed and factorised, MFMA f64 Cholesky ---------------------------
+
+def test_dense_reduced_camera_matrix_and_cholesky(be, orc):
+    """6 C <= 128: the reduced camera matrix is formed block pair by block pair and factorised in LDS (blocked
+    Cholesky, trailing updates on v_mfma_f64_16x16x4_f64).  S against the oracle's explicit Schur complement, the
+    solve against numpy's, for sizes that exercise 1 ... 8 tiles of 16, padding, duplicated (camera, point) pairs,
+    an unobserved camera."""
+    import sfmba
+    rng = np.random.default_rng(7)
+    for C, P, N, seed in ((2, 12, 40, 1), (3, 8, 20, 0), (5, 40, 200, 9), (11, 300, 2000, 2), (16, 200, 1500, 4),
+                          (21, 150, 1200, 5)):
+        pb = sfmba.make_problem(C, P, N, seed=seed)
+        if C == 5:
+            pb = sfmba.drop_observations(pb, cameras=(3,), points=(7,))
+        ci = pb.camera_indices.copy()
+        if C == 11:
+            ci[5] = ci[4] if pb.point_indices[5] == pb.point_indices[4] else ci[5]      # duplicated pair
+        args = (pb.n_cameras, pb.n_points, ci, pb.point_indices, pb.points_2d, pb.K)
+        be.set_problem(*args)
+        r, Jc, Jp = orc.jacobian_blocks(pb.x0, *args)
+        nb = orc.normal_blocks(r, Jc, Jp, C, pb.n_points, ci, pb.point_indices)
+        dc = 1e-3 * np.einsum("cii->ci", nb.U) + 1e-6
+        dp = 1e-3 * np.einsum("pii->pi", nb.V) + 1e-6
+        rhs = rng.normal(size=6 * C)
+        S, y = be.dense_schur(pb.x0, dc, dp, rhs)
+        Vd = nb.V.copy()
+        Vd[:, np.arange(3), np.arange(3)] += dp
+        Vinv = np.linalg.inv(Vd)
+        Sref = np.zeros((C, 6, C, 6))
+        Sref[np.arange(C), :, np.arange(C), :] = nb.U
+        Sref = Sref.reshape(6 * C, 6 * C) + np.diag(dc.ravel())
+        Wfull = np.zeros((6 * C, 3 * pb.n_points))
+        for i in range(len(ci)):
+            Wfull[6 * ci[i]:6 * ci[i] + 6, 3 * pb.point_indices[i]:3 * pb.point_indices[i] + 3] += nb.W[i]
+        Vbig = np.zeros((3 * pb.n_points, 3 * pb.n_points))
+        for p in range(pb.n_points):
+            Vbig[3 * p:3 * p + 3, 3 * p:3 * p + 3] = Vinv[p]
+        Sref = Sref - Wfull @ Vbig @ Wfull.T
+        assert np.abs(S - S.T).max() <= 1e-13 * np.abs(S).max()     # diagonal blocks: (u,v) and (v,u) are summed separately
+        assert np.abs(S - Sref).max() <= 1e-10 * np.abs(Sref).max()
+        yref = np.linalg.solve(Sref, rhs)
+        assert np.abs(y - yref).max() <= 1e-8 * np.abs(yref).max(), (C, np.abs(y - yref).max(), np.abs(yref).max())
+        assert np.abs(S @ y - rhs).max() <= 1e-9 * max(1.0, np.abs(rhs).max()) * np.linalg.cond(Sref) ** 0.5
