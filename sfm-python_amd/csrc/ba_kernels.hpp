@@ -31,6 +31,7 @@
 namespace sfmba {
 
 constexpr int kCamTab = 17;          // doubles per camera-table row
+constexpr int kRec = 6;              // doubles per point record X Y Z | z0 z1 z2 (see k_fill_rec)
 constexpr int kSweepThreads = 1024;  // one workgroup per CU, 16 waves sharing one LDS camera table
 constexpr int kWavesPerSweepBlock = kSweepThreads / 64;
 
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(256) void k_step_table(const double* __restrict__ x
                                                     const double* __restrict__ p, double c1, double c2,
                                                     const double* __restrict__ coef,
                                                     int C, int64_t n, int bc, double* __restrict__ x_new,
-                                                    double* __restrict__ tab,
+                                                    double* __restrict__ tab, double* __restrict__ rec_new,
                                                     const double* __restrict__ skip) {
     if (skip != nullptr && *skip != 0.0) return;   // speculative launch cancelled by k_tr_step
     if (coef != nullptr) { c1 = coef[0]; c2 = coef[1]; }       // coefficients decided by k_tr_step
@@ -342,8 +343,24 @@ __global__ __launch_bounds__(256) void k_step_table(const double* __restrict__ x
     }
     const int64_t n6 = 6 * (int64_t)C;
     const int nb = gridDim.x - bc;
-    for (int64_t e = n6 + (blockIdx.x - bc) * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)nb * blockDim.x)
-        x_new[e] = x[e] + c1 * sg[e] + c2 * p[e];
+    for (int64_t e = n6 + (blockIdx.x - bc) * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)nb * blockDim.x) {
+        const double v = x[e] + c1 * sg[e] + c2 * p[e];
+        x_new[e] = v;
+        const int q = (int)(e - n6), pt = q / 3;        // 32-bit: n < 2^31 (checked by set_problem)
+        rec_new[(size_t)kRec * pt + (q - 3 * pt)] = v;  // coordinate slots of the point's record (see k_fill_rec)
+    }
+}
+
+// Point records [P][6] = X Y Z | z0 z1 z2: what the camera-major passes gather per observation.  One 48-byte
+// record is three 16-byte loads; coordinates and the per-point vector z as separate arrays of doubles were six
+// 8-byte loads, and a gathered load costs the texture addresser ~64 cycles per wave whatever its width.  The
+// coordinate half follows x (k_step_table, k_fill_rec); the z half is written by pass A of the Schur product (z_p)
+// and by k_prep (e_p = Vinv g_p, for the reduced right-hand side).
+__global__ void k_fill_rec(const double* __restrict__ pts, int P, double* __restrict__ rec) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= 3 * P) return;
+    const int p = q / 3;
+    rec[(size_t)kRec * p + (q - 3 * p)] = pts[q];
 }
 
 // One observation: residual and (JAC) the 2x6 / 2x3 blocks.
@@ -584,7 +601,7 @@ __device__ __forceinline__ double cam_block_total(double (&a)[NV], double (*red)
 // partial[chunk][27] and k_cam_combine adds them.
 template <bool F32>
 __global__ __launch_bounds__(kCamThreads) void k_cam_blocks(CamMajor cm, const double* __restrict__ camtab,
-                                                            const double* __restrict__ pts, KMat K,
+                                                            const double* __restrict__ rec, KMat K,
                                                             double* __restrict__ Ugc, double* __restrict__ partial,
                                                             const double* __restrict__ skip) {
     __shared__ double red[kCamWaves][27];
@@ -610,9 +627,10 @@ __global__ __launch_bounds__(kCamThreads) void k_cam_blocks(CamMajor cm, const d
             if (k < ch.z) { p[u] = cm.pt[k]; uv[u] = load_pair(cm.uv, F32, k); }
         }
 #pragma unroll
-        for (int u = 0; u < kCamUnroll; ++u) {
-            const double* __restrict__ Xp = pts + 3 * (size_t)(p[u] < 0 ? 0 : p[u]);
-            X[u][0] = Xp[0]; X[u][1] = Xp[1]; X[u][2] = Xp[2];
+        for (int u = 0; u < kCamUnroll; ++u) {            // two 16-byte loads of the point's record: X Y | Z .
+            const double2* __restrict__ rp = reinterpret_cast<const double2*>(rec + (size_t)kRec * (p[u] < 0 ? 0 : p[u]));
+            const double2 xy = rp[0], zz = rp[1];
+            X[u][0] = xy.x; X[u][1] = xy.y; X[u][2] = zz.x;
         }
 #pragma unroll
         for (int u = 0; u < kCamUnroll; ++u) {
@@ -701,18 +719,27 @@ __global__ __launch_bounds__(kPointBlockThreads) void k_point_blocks(
     int i = cur.x + lane, c = 0, p = 0;
     double2 uvi = make_double2(0.0, 0.0);
     if (cur.y <= 64 && lane < cur.y) { c = cam_idx[i]; p = pt_idx[i]; uvi = load_pair(uv, F32, i); }
-    if (LDS_TAB) {                               // stage the camera table while those loads fly
-        const int n2 = (C * kCamTab) >> 1;
-        const double2* __restrict__ src = reinterpret_cast<const double2*>(camtab);
+    // d r / d X and r need R and T only: the compact view of the camera table, rows of 96 bytes, 16-byte aligned,
+    // so that a row is six 16-byte loads (every load of a gathered row costs the texture addresser the same ~64
+    // cycles per wave whatever its width: half as many loads as from the 17-double rows)
+    const double* __restrict__ rt = camtab + cam_rt_offset(C);
+    if (LDS_TAB) {                               // stage it while those loads fly
+        const int n2 = (C * kCamRT) >> 1;
+        const double2* __restrict__ src = reinterpret_cast<const double2*>(rt);
         double2* __restrict__ dst = reinterpret_cast<double2*>(smem);
         for (int k = threadIdx.x; k < n2; k += blockDim.x) dst[k] = src[k];
-        if (((C * kCamTab) & 1) && threadIdx.x == 0) smem[C * kCamTab - 1] = camtab[C * kCamTab - 1];
         __syncthreads();
     }
-    const double* __restrict__ tab = LDS_TAB ? smem : camtab;
+    const double* __restrict__ tab = LDS_TAB ? smem : rt;
     auto terms = [&](int cc, double X, double Y, double Z, double2 px, double* v) {
         double jc[12], jp[6], rx, ry;
-        observe<true>(tab + cc * kCamTab, X, Y, Z, px.x, px.y, K, rx, ry, jc, jp);
+        double t[kCamTab];
+        const double2* __restrict__ row = reinterpret_cast<const double2*>(tab + (size_t)cc * kCamRT);
+#pragma unroll
+        for (int k = 0; k < kCamRT / 2; ++k) { const double2 q = row[k]; t[2 * k] = q.x; t[2 * k + 1] = q.y; }
+#pragma unroll
+        for (int k = kCamRT; k < kCamTab; ++k) t[k] = 0.0;       // the rotation part of the camera block is not used here
+        observe<true>(t, X, Y, Z, px.x, px.y, K, rx, ry, jc, jp);
         v[0] = jp[0] * jp[0] + jp[3] * jp[3]; v[1] = jp[0] * jp[1] + jp[3] * jp[4];
         v[2] = jp[0] * jp[2] + jp[3] * jp[5]; v[3] = jp[1] * jp[1] + jp[4] * jp[4];
         v[4] = jp[1] * jp[2] + jp[4] * jp[5]; v[5] = jp[2] * jp[2] + jp[5] * jp[5];
@@ -986,11 +1013,11 @@ __device__ __forceinline__ void point_prep_one(const double* __restrict__ V, con
     chol3_inverse(a, inv);
 #pragma unroll
     for (int k = 0; k < 6; ++k) Vinv[(size_t)p * 6 + k] = inv[k];
-    if (e) {
+    if (e) {                              // e points at the z slot of the point records: stride kRec
         const double g0 = gp[3 * (size_t)p], g1 = gp[3 * (size_t)p + 1], g2 = gp[3 * (size_t)p + 2];
-        e[3 * (size_t)p + 0] = inv[0] * g0 + inv[1] * g1 + inv[2] * g2;
-        e[3 * (size_t)p + 1] = inv[1] * g0 + inv[3] * g1 + inv[4] * g2;
-        e[3 * (size_t)p + 2] = inv[2] * g0 + inv[4] * g1 + inv[5] * g2;
+        e[(size_t)kRec * p + 0] = inv[0] * g0 + inv[1] * g1 + inv[2] * g2;
+        e[(size_t)kRec * p + 1] = inv[1] * g0 + inv[3] * g1 + inv[4] * g2;
+        e[(size_t)kRec * p + 2] = inv[2] * g0 + inv[4] * g1 + inv[5] * g2;
     }
 }
 
@@ -1355,9 +1382,9 @@ __global__ __launch_bounds__(kSweepThreads) void k_point_sweep(
             y[0] = wave_sum(y[0]); y[1] = wave_sum(y[1]); y[2] = wave_sum(y[2]);
             if (lane == 0) {
                 const double* vi = Vinv + 6 * (size_t)pp;
-                zout[3 * (size_t)pp + 0] = vi[0] * y[0] + vi[1] * y[1] + vi[2] * y[2];
-                zout[3 * (size_t)pp + 1] = vi[1] * y[0] + vi[3] * y[1] + vi[4] * y[2];
-                zout[3 * (size_t)pp + 2] = vi[2] * y[0] + vi[4] * y[1] + vi[5] * y[2];
+                zout[(size_t)kRec * pp + 3] = vi[0] * y[0] + vi[1] * y[1] + vi[2] * y[2];
+                zout[(size_t)kRec * pp + 4] = vi[1] * y[0] + vi[3] * y[1] + vi[4] * y[2];
+                zout[(size_t)kRec * pp + 5] = vi[2] * y[0] + vi[4] * y[1] + vi[5] * y[2];
             }
         } else {
             const bool act = lane < cur.y;
@@ -1375,9 +1402,9 @@ __global__ __launch_bounds__(kSweepThreads) void k_point_sweep(
             seg_reduce<3>(y, key, lane);
             const int prev = __shfl_up(key, 1);
             if (act && (lane == 0 || prev != key)) {              // first lane of the point's run
-                zout[3 * (size_t)p + 0] = vi[0] * y[0] + vi[1] * y[1] + vi[2] * y[2];
-                zout[3 * (size_t)p + 1] = vi[1] * y[0] + vi[3] * y[1] + vi[4] * y[2];
-                zout[3 * (size_t)p + 2] = vi[2] * y[0] + vi[4] * y[1] + vi[5] * y[2];
+                zout[(size_t)kRec * p + 3] = vi[0] * y[0] + vi[1] * y[1] + vi[2] * y[2];
+                zout[(size_t)kRec * p + 4] = vi[1] * y[0] + vi[3] * y[1] + vi[4] * y[2];
+                zout[(size_t)kRec * p + 5] = vi[2] * y[0] + vi[4] * y[1] + vi[5] * y[2];
             }
         }
         cur = nxt; i = in_; c = cn; p = pn;
@@ -1515,9 +1542,9 @@ __global__ __launch_bounds__(kSweepThreads) void k_point_sweep_rc(
             y[0] = wave_sum(y[0]); y[1] = wave_sum(y[1]); y[2] = wave_sum(y[2]);
             if (lane == 0) {
                 const double* vl = Vinv + 6 * (size_t)pp;
-                zout[3 * (size_t)pp + 0] = vl[0] * y[0] + vl[1] * y[1] + vl[2] * y[2];
-                zout[3 * (size_t)pp + 1] = vl[1] * y[0] + vl[3] * y[1] + vl[4] * y[2];
-                zout[3 * (size_t)pp + 2] = vl[2] * y[0] + vl[4] * y[1] + vl[5] * y[2];
+                zout[(size_t)kRec * pp + 3] = vl[0] * y[0] + vl[1] * y[1] + vl[2] * y[2];
+                zout[(size_t)kRec * pp + 4] = vl[1] * y[0] + vl[3] * y[1] + vl[4] * y[2];
+                zout[(size_t)kRec * pp + 5] = vl[2] * y[0] + vl[4] * y[1] + vl[5] * y[2];
             }
         } else {
             const bool act = lane < cur.y;
@@ -1526,9 +1553,9 @@ __global__ __launch_bounds__(kSweepThreads) void k_point_sweep_rc(
             seg_reduce<3>(y, key, lane);
             const int prev = __shfl_up(key, 1);
             if (act && (lane == 0 || prev != key)) {
-                zout[3 * (size_t)p + 0] = vi[0] * y[0] + vi[1] * y[1] + vi[2] * y[2];
-                zout[3 * (size_t)p + 1] = vi[1] * y[0] + vi[3] * y[1] + vi[4] * y[2];
-                zout[3 * (size_t)p + 2] = vi[2] * y[0] + vi[4] * y[1] + vi[5] * y[2];
+                zout[(size_t)kRec * p + 3] = vi[0] * y[0] + vi[1] * y[1] + vi[2] * y[2];
+                zout[(size_t)kRec * p + 4] = vi[1] * y[0] + vi[3] * y[1] + vi[4] * y[2];
+                zout[(size_t)kRec * p + 5] = vi[2] * y[0] + vi[4] * y[1] + vi[5] * y[2];
             }
         }
         cur = nxt; nxt = nn; nn = n3;
@@ -1542,7 +1569,8 @@ __global__ __launch_bounds__(kSweepThreads) void k_point_sweep_rc(
 }
 
 // Pass B: acc_c = sum_{i in c} Jc_i^T ( Jc_i v_c - Jp_i z_p )   (MODE 0; v_c wave-uniform, z gathered), or
-//         acc_c = - sum Jc_i^T Jp_i e_p                          (MODE 1; z = e), over one camera chunk, with the
+//         acc_c = - sum Jc_i^T Jp_i e_p                          (MODE 1; the z slot of the records holds e, written by
+//         k_prep), over one camera chunk, with the
 // blocks recomputed from the camera row and the gathered point.  ROUND (fp32-storage mode, when pass A is the
 // form that reads the stored blocks): the recomputed entries are rounded to float first -- pass A applied the
 // STORED (rounded) blocks, and the product has to be that of one symmetric matrix.  Output: plane-major acc[k][C] for a single-chunk camera, partial[chunk][6] otherwise.
@@ -1551,9 +1579,8 @@ __global__ __launch_bounds__(kSweepThreads) void k_point_sweep_rc(
 //              the sets.  ctrl_done == null: vin is the plane-major vector itself.
 template <int MODE, bool ROUND>
 __global__ __launch_bounds__(kCamThreads) void k_cam_schur(CamMajor cm, const double* __restrict__ camtab,
-                                                           const double* __restrict__ pts, KMat K,
-                                                           const double* __restrict__ vin,
-                                                           const double* __restrict__ zin, int C,
+                                                           const double* __restrict__ rec, KMat K,
+                                                           const double* __restrict__ vin, int C,
                                                            double* __restrict__ acc, double* __restrict__ partial,
                                                            const PcgCtrl* __restrict__ ctrl_done, int set) {
     __shared__ double red[kCamWaves][6];
@@ -1580,10 +1607,11 @@ __global__ __launch_bounds__(kCamThreads) void k_cam_schur(CamMajor cm, const do
             p[u] = k < ch.z ? cm.pt[k] : -1;
         }
 #pragma unroll
-        for (int u = 0; u < kCamUnroll; ++u) {
-            const size_t pp = 3 * (size_t)(p[u] < 0 ? 0 : p[u]);
-            X[u][0] = pts[pp]; X[u][1] = pts[pp + 1]; X[u][2] = pts[pp + 2];
-            z[u][0] = zin[pp]; z[u][1] = zin[pp + 1]; z[u][2] = zin[pp + 2];
+        for (int u = 0; u < kCamUnroll; ++u) {            // the point's record: X Y | Z z0 | z1 z2, three 16-byte loads
+            const double2* __restrict__ rp = reinterpret_cast<const double2*>(rec + (size_t)kRec * (p[u] < 0 ? 0 : p[u]));
+            const double2 r0 = rp[0], r1 = rp[1], r2 = rp[2];
+            X[u][0] = r0.x; X[u][1] = r0.y; X[u][2] = r1.x;
+            z[u][0] = r1.y; z[u][1] = r2.x; z[u][2] = r2.y;
         }
 #pragma unroll
         for (int u = 0; u < kCamUnroll; ++u) {

@@ -241,7 +241,7 @@ struct sfmba_handle {
     int n_chunks = 0;
     bool cam_multi = false;                  // some camera has more than one chunk: k_cam_combine runs
     DevBuf xa, xb, tabA, tabB, r, J, t1;     // ONE Jacobian / residual buffer set
-    DevBuf V, Vinv, gp, e, z;                // z: per-point vector of the Schur product (pass A -> pass B)
+    DevBuf V, Vinv, gp, e, recA, recB;       // rec: point records X Y Z | z (k_fill_rec), one per parameter vector
     DevBuf g, si, sg, p;                     // n-vectors; p = [dc | dp]
     DevBuf Dc, Minv, vecs, vtmp, vcm;               // camera-sized, plane-major [k][C]; vecs = 2 sets x (x r p s u)
     DevBuf part, ctrl;
@@ -296,6 +296,8 @@ struct sfmba_handle {
     double* x_new = nullptr;
     double* tab = nullptr;
     double* tab_new = nullptr;
+    double* rec = nullptr;                   // point records of x / x_new (swapped together with them)
+    double* rec_new = nullptr;
 
     double* acc() const { return arena; }    // product of the implicit Schur complement / reduced rhs term (6C)
     double* Ugc() const { return arena + 18 * C; }
@@ -491,8 +493,11 @@ int wait_mailbox(sfmba_handle* h, unsigned long long seq) {
 
 // ---- kernel launch wrappers --------------------------------------------------------------------
 
-int launch_cam_table(sfmba_handle* h, const double* x, double* tab) {
+// camera table and point records of a freshly uploaded parameter vector
+int launch_cam_table(sfmba_handle* h, const double* x, double* tab, double* rec) {
     hipLaunchKernelGGL(k_cam_table, dim3((h->C + 255) / 256), dim3(256), 0, h->stream, x, (int)h->C, tab);
+    LAUNCHED(h);
+    hipLaunchKernelGGL(k_fill_rec, dim3((unsigned)((3 * h->P + 255) / 256)), dim3(256), 0, h->stream, x + 6 * h->C, (int)h->P, rec);
     LAUNCHED(h);
     return 0;
 }
@@ -587,11 +592,11 @@ int launch_cam_combine(sfmba_handle* h, int ncols, double* out, int cs, int ks, 
 // K2 + K3 at (x, tab): V_p, g_p over the point-major order, [U_c | g_c] over the camera-major order; both
 // recompute the blocks from the camera table and the point (no stored Jacobian is read)
 template <bool F32>
-int launch_normal_blocks_v(sfmba_handle* h, const double* x, const double* tab) {
+int launch_normal_blocks_v(sfmba_handle* h, const double* x, const double* tab, const double* rec) {
     const double* pts = x + 6 * h->C;
     constexpr int wpb = kPointBlockThreads / 64;
     const int grid = (h->n_ranges + wpb - 1) / wpb;
-    const size_t lds = (size_t)h->C * kCamTab * sizeof(double);
+    const size_t lds = (size_t)h->C * kCamRT * sizeof(double);
     if (lds <= 48 * 1024 && h->dbg.tab_lds != 0) {
         hipLaunchKernelGGL((k_point_blocks<true, F32>), dim3(grid), dim3(kPointBlockThreads), lds, h->stream, step_table(h),
                            h->cam_idx.as<int>(), h->pt_idx.as<int>(), h->uv.as<double>(), tab, pts, (int)h->C, h->K,
@@ -602,13 +607,13 @@ int launch_normal_blocks_v(sfmba_handle* h, const double* x, const double* tab) 
                            h->V.as<double>(), h->gp.as<double>(), h->skip);
     }
     LAUNCHED(h);
-    hipLaunchKernelGGL((k_cam_blocks<F32>), dim3(h->n_chunks), dim3(kCamThreads), 0, h->stream, cam_major(h), tab, pts,
+    hipLaunchKernelGGL((k_cam_blocks<F32>), dim3(h->n_chunks), dim3(kCamThreads), 0, h->stream, cam_major(h), tab, rec,
                        h->K, h->Ugc(), h->cam_partial.as<double>(), h->skip);
     LAUNCHED(h);
     return launch_cam_combine(h, 27, h->Ugc(), 27, 1, h->skip, nullptr);
 }
-int launch_normal_blocks(sfmba_handle* h, const double* x, const double* tab) {
-    return h->f32 ? launch_normal_blocks_v<true>(h, x, tab) : launch_normal_blocks_v<false>(h, x, tab);
+int launch_normal_blocks(sfmba_handle* h, const double* x, const double* tab, const double* rec) {
+    return h->f32 ? launch_normal_blocks_v<true>(h, x, tab, rec) : launch_normal_blocks_v<false>(h, x, tab, rec);
 }
 
 // Pass A of the implicit Schur product (z_p for every point).  Inside the two-kernel PCG: vin = base of the
@@ -622,7 +627,7 @@ int launch_point_sweep(sfmba_handle* h, const double* vin, const PcgCtrl* ctrl2,
         CHK(set_lds(h, kern, lds));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), lds, h->stream, step_table(h), (const int*)h->cam_idx.as<int>(),
                            (const int*)h->pt_idx.as<int>(), (const double*)h->tab, (const double*)(h->x + 6 * h->C), h->K, vin,
-                           (const double*)h->Vinv.as<double>(), h->z.as<double>(), (const double*)h->acc(), (int)h->C, ctrl2, L,
+                           (const double*)h->Vinv.as<double>(), h->rec, (const double*)h->acc(), (int)h->C, ctrl2, L,
                            PcgFused{});
         LAUNCHED(h);
         return 0;
@@ -632,10 +637,10 @@ int launch_point_sweep(sfmba_handle* h, const double* vin, const PcgCtrl* ctrl2,
         auto kern = k_point_sweep<true, false>;
         CHK(set_lds(h, kern, lds));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), lds, h->stream, step_table(h), obs_arrays(h), vin,
-                           h->Vinv.as<double>(), h->z.as<double>(), (const double*)h->acc(), (int)h->C, ctrl2, L, PcgFused{});
+                           h->Vinv.as<double>(), h->rec, (const double*)h->acc(), (int)h->C, ctrl2, L, PcgFused{});
     } else {
         hipLaunchKernelGGL((k_point_sweep<false, false>), dim3(grid), dim3(kSweepThreads), 0, h->stream, step_table(h),
-                           obs_arrays(h), vin, h->Vinv.as<double>(), h->z.as<double>(), (const double*)h->acc(),
+                           obs_arrays(h), vin, h->Vinv.as<double>(), h->rec, (const double*)h->acc(),
                            (int)h->C, ctrl2, L, PcgFused{});
     }
     LAUNCHED(h);
@@ -654,7 +659,7 @@ int launch_pcg_fused(sfmba_handle* h, int L) {
         hipLaunchKernelGGL(kern_rc, dim3(grid), dim3(kSweepThreads), lds_rc, h->stream, step_table(h),
                            (const int*)h->cam_idx.as<int>(), (const int*)h->pt_idx.as<int>(), (const double*)h->tab,
                            (const double*)(h->x + 6 * h->C), h->K, (const double*)h->vecs.as<double>(),
-                           (const double*)h->Vinv.as<double>(), h->z.as<double>(), (const double*)h->acc(), (int)h->C,
+                           (const double*)h->Vinv.as<double>(), h->rec, (const double*)h->acc(), (int)h->C,
                            (const PcgCtrl*)h->ctrl.as<PcgCtrl>(), L, pf);
         LAUNCHED(h);
         return 0;
@@ -663,7 +668,7 @@ int launch_pcg_fused(sfmba_handle* h, int L) {
     auto kern = k_point_sweep<true, true>;
     CHK(set_lds(h, kern, lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), lds, h->stream, step_table(h), obs_arrays(h),
-                       (const double*)h->vecs.as<double>(), h->Vinv.as<double>(), h->z.as<double>(),
+                       (const double*)h->vecs.as<double>(), h->Vinv.as<double>(), h->rec,
                        (const double*)h->acc(), (int)h->C, (const PcgCtrl*)h->ctrl.as<PcgCtrl>(), L, pf);
     LAUNCHED(h);
     return 0;
@@ -672,16 +677,15 @@ int launch_pcg_fused(sfmba_handle* h, int L) {
 // Pass B (camera-major): MODE 0  acc = sum Jc^T (Jc v - Jp z) with z from pass A; MODE 1  acc = -sum Jc^T Jp e.
 // ctrl_done / set: see k_cam_schur.
 template <int MODE>
-int launch_cam_schur(sfmba_handle* h, const double* vin, const double* zin, const PcgCtrl* ctrl_done, int set) {
-    const double* pts = h->x + 6 * h->C;
+int launch_cam_schur(sfmba_handle* h, const double* vin, const PcgCtrl* ctrl_done, int set) {
     if (h->f32 && !h->sweep_rc)           // pass A applies the stored fp32 blocks: pass B rounds its own the same way
         hipLaunchKernelGGL((k_cam_schur<MODE, true>), dim3(h->n_chunks), dim3(kCamThreads), 0, h->stream, cam_major(h),
-                           (const double*)h->tab, pts, h->K, vin, zin, (int)h->C, h->acc(), h->cam_partial.as<double>(),
-                           ctrl_done, set);
+                           (const double*)h->tab, (const double*)h->rec, h->K, vin, (int)h->C, h->acc(),
+                           h->cam_partial.as<double>(), ctrl_done, set);
     else
         hipLaunchKernelGGL((k_cam_schur<MODE, false>), dim3(h->n_chunks), dim3(kCamThreads), 0, h->stream, cam_major(h),
-                           (const double*)h->tab, pts, h->K, vin, zin, (int)h->C, h->acc(), h->cam_partial.as<double>(),
-                           ctrl_done, set);
+                           (const double*)h->tab, (const double*)h->rec, h->K, vin, (int)h->C, h->acc(),
+                           h->cam_partial.as<double>(), ctrl_done, set);
     LAUNCHED(h);
     return launch_cam_combine(h, 6, h->acc(), 1, (int)h->C, nullptr, ctrl_done ? &ctrl_done->done : nullptr);
 }
@@ -717,7 +721,7 @@ int schur_product_standalone(sfmba_handle* h, const double* v_planes) {
         va = h->vcm.as<double>();
     }
     CHK(launch_point_sweep(h, va, nullptr, 0));
-    return launch_cam_schur<0>(h, v_planes, h->z.as<double>(), nullptr, 0);
+    return launch_cam_schur<0>(h, v_planes, nullptr, 0);
 }
 
 // partials -> half B.  When k_update_scale's final sums are still pending they ride along (one extra workgroup).
@@ -904,14 +908,14 @@ int pcg_enqueue(sfmba_handle* h, int count) {
             // a launch that found the solve finished (or finished it) produced no z: its control block (written
             // to slot (L+1)&1) says so, and pass B and the collective behind it are void as well
             const PcgCtrl* cd = ctrl2 + ((L + 1) & 1);
-            CHK(launch_cam_schur<0>(h, h->vecs.as<double>(), h->z.as<double>(), cd, L & 1));
+            CHK(launch_cam_schur<0>(h, h->vecs.as<double>(), cd, L & 1));
             CHK(exchange(h, h->acc(), 6 * h->C, 0, &cd->done));
             h->pcg_L = L + 1;
             continue;
         }
         const PcgCtrl* cd = ctrl2 + (L & 1);                     // current until k_pcg_update writes the other one
         CHK(launch_point_sweep(h, h->vecs.as<double>(), ctrl2, L));
-        CHK(launch_cam_schur<0>(h, h->vecs.as<double>(), h->z.as<double>(), cd, -1));
+        CHK(launch_cam_schur<0>(h, h->vecs.as<double>(), cd, -1));
         CHK(exchange(h, h->acc(), 6 * h->C, 0, &cd->done));
         hipLaunchKernelGGL(k_pcg_update, dim3(kPcgUpdateBlocks), dim3(1024), 0, h->stream, (const double*)h->acc(),
                            h->Dc.as<double>(), h->Minv.as<double>(), (int)h->C, h->vecs.as<double>(), ctrl2, L);
@@ -1464,7 +1468,8 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     chunks.clear();
     chunk_ptr.resize((size_t)C + 1);
     {
-        int64_t chunk_len = std::max<int64_t>(1024, (N + 2 * h->n_cu - 1) / (2 * h->n_cu));
+        // a camera of up to 4096 observations is one workgroup (16 per lane) and needs no combine launch
+        int64_t chunk_len = std::max<int64_t>(4096, (N + 2 * h->n_cu - 1) / (2 * h->n_cu));
         if (h->dbg.cam_chunk > 0) chunk_len = h->dbg.cam_chunk;
         h->cam_multi = false;
         for (int64_t c = 0; c < C; ++c) {
@@ -1541,7 +1546,8 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     HIPCHK(h, h->cam_chunks.ensure(sizeof(int4) * chunks.size()));
     HIPCHK(h, h->cam_chunk_ptr.ensure(sizeof(int) * chunk_ptr.size()));
     HIPCHK(h, h->cam_partial.ensure(sizeof(double) * 27 * chunks.size()));
-    HIPCHK(h, h->z.ensure(sizeof(double) * 3 * P));
+    HIPCHK(h, h->recA.ensure(sizeof(double) * kRec * P));
+    HIPCHK(h, h->recB.ensure(sizeof(double) * kRec * P));
     if (h->dense) {
         HIPCHK(h, h->cov_ptr.ensure(sizeof(int) * cov_ptr.size()));
         HIPCHK(h, h->cov_pt.ensure(sizeof(int) * cov_pt.size()));
@@ -1571,6 +1577,7 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     h->ar_fn = nullptr; h->ar_ctx = nullptr;
     h->x = h->xa.as<double>(); h->x_new = h->xb.as<double>();
     h->tab = h->tabA.as<double>(); h->tab_new = h->tabB.as<double>();
+    h->rec = h->recA.as<double>(); h->rec_new = h->recB.as<double>();
 
     // ---- uploads: observations from the first changed one on, run offsets from its point on, structure tables ----
     auto up = [&](void* dst, const void* src, size_t elem, size_t from, size_t to) -> hipError_t {
@@ -1595,7 +1602,8 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     HIPCHK(h, hipMemsetAsync(h->gp.p, 0, sizeof(double) * 3 * P, h->stream));
     HIPCHK(h, hipMemsetAsync(h->p.p, 0, sizeof(double) * h->n, h->stream));      // ... and their step is 0
     HIPCHK(h, hipMemsetAsync(h->r.p, 0, esz * 2 * ldz, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->z.p, 0, sizeof(double) * 3 * P, h->stream));      // points without observations keep z = 0
+    HIPCHK(h, hipMemsetAsync(h->recA.p, 0, sizeof(double) * kRec * P, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->recB.p, 0, sizeof(double) * kRec * P, h->stream));
     if (h->dense) {      // pageable sources: these copies are synchronous, the vectors may go out of scope afterwards
         HIPCHK(h, hipMemcpyAsync(h->cov_ptr.p, cov_ptr.data(), sizeof(int) * cov_ptr.size(), hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipMemcpyAsync(h->cov_pt.p, cov_pt.data(), sizeof(int) * cov_pt.size(), hipMemcpyHostToDevice, h->stream));
@@ -1624,7 +1632,7 @@ int sfmba_residuals(sfmba_handle* h, const double* x, double* r_out) {
     CHK(check_ready(h, x));
     if (!r_out) return fail(h, -1, "r_out is NULL");
     CHK(upload_x(h, x));
-    CHK(launch_cam_table(h, h->x, h->tab));
+    CHK(launch_cam_table(h, h->x, h->tab, h->rec));
     int np = 0;
     CHK((launch_resjac<false, true>(h, h->x, h->tab, &np)));
     return download_residuals(h, r_out);
@@ -1635,7 +1643,7 @@ int sfmba_residual_jacobian(sfmba_handle* h, const double* x, double* r_out, dou
     CHK(check_ready(h, x));
     if (!r_out || !Jc_out || !Jp_out) return fail(h, -1, "NULL output");
     CHK(upload_x(h, x));
-    CHK(launch_cam_table(h, h->x, h->tab));
+    CHK(launch_cam_table(h, h->x, h->tab, h->rec));
     int np = 0;
     CHK((launch_resjac<true, true>(h, h->x, h->tab, &np)));
     DevBuf jc_rm, jp_rm;
@@ -1661,10 +1669,10 @@ int sfmba_normal_blocks(sfmba_handle* h, const double* x, double* U, double* V, 
     CHK(enter(h));
     CHK(check_ready(h, x));
     CHK(upload_x(h, x));
-    CHK(launch_cam_table(h, h->x, h->tab));
+    CHK(launch_cam_table(h, h->x, h->tab, h->rec));
     int np = 0;
     CHK((launch_resjac<true, true>(h, h->x, h->tab, &np)));
-    CHK(launch_normal_blocks(h, h->x, h->tab));
+    CHK(launch_normal_blocks(h, h->x, h->tab, h->rec));
     CHK(exchange(h, h->Ugc(), 27 * h->C, 0));
     std::vector<double> ugc(27 * h->C);
     HIPCHK(h, hipMemcpyAsync(ugc.data(), h->Ugc(), sizeof(double) * 27 * h->C, hipMemcpyDeviceToHost, h->stream));
@@ -1683,10 +1691,10 @@ int sfmba_schur_matvec(sfmba_handle* h, const double* x, const double* dc, const
     CHK(check_ready(h, x));
     if (!dc || !dp || !v || !y) return fail(h, -1, "NULL argument");
     CHK(upload_x(h, x));
-    CHK(launch_cam_table(h, h->x, h->tab));
+    CHK(launch_cam_table(h, h->x, h->tab, h->rec));
     int np = 0;
     CHK((launch_resjac<true, true>(h, h->x, h->tab, &np)));
-    CHK(launch_normal_blocks(h, h->x, h->tab));
+    CHK(launch_normal_blocks(h, h->x, h->tab, h->rec));
     CHK(exchange(h, h->Ugc(), 27 * h->C, 0));
     // stage dp in e (as explicit diagonal), v in pk -- camera vectors are plane-major on the device
     const int64_t C = h->C;
@@ -1718,10 +1726,10 @@ int sfmba_dense_schur(sfmba_handle* h, const double* x, const double* dc, const 
     if (!h->dense) return fail(h, -1, "the dense reduced-camera path needs 6 * n_cameras <= %d", kDenseMaxN);
     const int64_t C = h->C;
     CHK(upload_x(h, x));
-    CHK(launch_cam_table(h, h->x, h->tab));
+    CHK(launch_cam_table(h, h->x, h->tab, h->rec));
     int np = 0;
     CHK((launch_resjac<true, true>(h, h->x, h->tab, &np)));
-    CHK(launch_normal_blocks(h, h->x, h->tab));
+    CHK(launch_normal_blocks(h, h->x, h->tab, h->rec));
     CHK(exchange(h, h->Ugc(), 27 * C, 0));
     std::vector<double> ugc(27 * C), planes(6 * C), accp(6 * C);
     HIPCHK(h, hipMemcpyAsync(ugc.data(), h->Ugc(), sizeof(double) * 27 * C, hipMemcpyDeviceToHost, h->stream));
@@ -1771,15 +1779,15 @@ int sfmba_time_kernel(sfmba_handle* h, const double* x, int32_t which, int32_t r
     CHK(check_ready(h, x));
     if (!avg_us || reps <= 0) return fail(h, -1, "bad reps / avg_us");
     CHK(upload_x(h, x));
-    CHK(launch_cam_table(h, h->x, h->tab));
+    CHK(launch_cam_table(h, h->x, h->tab, h->rec));
     int np = 0;
     CHK((launch_resjac<true, true>(h, h->x, h->tab, &np)));
     if (which >= 2) {
-        CHK(launch_normal_blocks(h, h->x, h->tab));
+        CHK(launch_normal_blocks(h, h->x, h->tab, h->rec));
         CHK(launch_update_scale(h, 1));
         hipLaunchKernelGGL(k_point_prep, dim3((h->P + 255) / 256), dim3(256), 0, h->stream, h->V.as<double>(),
                            h->gp.as<double>(), h->si.as<double>() + 6 * h->C, (const double*)nullptr, (int)h->P,
-                           1e-6, h->Vinv.as<double>(), h->e.as<double>());
+                           1e-6, h->Vinv.as<double>(), h->rec + 3);
         LAUNCHED(h);
         // v = the camera slice of the gradient, as plane-major planes (and camera-major when v is not staged in LDS)
         hipLaunchKernelGGL(k_transpose, dim3((unsigned)((6 * h->C + 255) / 256)), dim3(256), 0, h->stream,
@@ -1799,11 +1807,11 @@ int sfmba_time_kernel(sfmba_handle* h, const double* x, int32_t which, int32_t r
         switch (which) {
             case 0: CHK((launch_resjac<true, true>(h, h->x, h->tab, &np))); break;
             case 1: CHK((launch_resjac<false, false>(h, h->x, h->tab, &np))); break;
-            case 2: CHK(launch_normal_blocks(h, h->x, h->tab)); break;
+            case 2: CHK(launch_normal_blocks(h, h->x, h->tab, h->rec)); break;
             case 3: CHK(schur_product_standalone(h, h->vtmp.as<double>())); break;
             case 4: CHK(launch_point_sweep(h, (h->lds_vec || h->sweep_rc) ? h->vtmp.as<double>() : h->vcm.as<double>(), nullptr, 0)); break;
-            case 5: CHK(launch_cam_schur<0>(h, h->vtmp.as<double>(), h->z.as<double>(), nullptr, 0)); break;
-            case 6: CHK(launch_cam_schur<1>(h, nullptr, h->e.as<double>(), nullptr, 0)); break;
+            case 5: CHK(launch_cam_schur<0>(h, h->vtmp.as<double>(), nullptr, 0)); break;
+            case 6: CHK(launch_cam_schur<1>(h, nullptr, nullptr, 0)); break;
             case 10:   // streaming-store ceiling: fill the Jacobian planes, 16 B per lane, one stream
                 hipLaunchKernelGGL(k_fill16, dim3(h->n_cu * 2), dim3(1024), 0, h->stream, h->J.as<double>(),
                                    (int64_t)((h->f32 ? 3 : 6) * h->ld), 1.0);
@@ -1860,6 +1868,7 @@ static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt
 
     h->x = h->xa.as<double>(); h->x_new = h->xb.as<double>();
     h->tab = h->tabA.as<double>(); h->tab_new = h->tabB.as<double>();
+    h->rec = h->recA.as<double>(); h->rec_new = h->recB.as<double>();
     CHK(upload_x(h, x_inout));
     const double t_dev0 = now_s();
     report_stall(h, "upload_x", t_dev0 - t_begin);
@@ -1873,7 +1882,7 @@ static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt
     } evs;
     int np_cost = 0;                                                  // partial rows of the last K1 launch
     auto eval_jac = [&](const double* x, double* tab, bool table_ready, bool finish = true) -> int {   // K0 + K1, sum r^2 -> scalar 0
-        if (!table_ready) CHK(launch_cam_table(h, x, tab));
+        if (!table_ready) CHK(launch_cam_table(h, x, tab, h->rec));
         int& np = np_cost;
         if (opt.profile) {
             hipEvent_t a, b;
@@ -1894,7 +1903,7 @@ static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt
         return 0;
     };
     auto linearise = [&](int first) -> int {      // normal blocks, scale, gradient, q0..q4 at h->x
-        CHK(launch_normal_blocks(h, h->x, h->tab));
+        CHK(launch_normal_blocks(h, h->x, h->tab, h->rec));
         CHK(exchange(h, h->Ugc(), 27 * C, 0));
         CHK(launch_update_scale(h, first));
         CHK(exchange_linearise(h));
@@ -1930,7 +1939,7 @@ static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt
     for (;;) {                                                  // trf.py:450
         if (!nb_valid) {                                        // a rejected trial overwrote the blocks and no
             CHK(eval_jac(h->x, h->tab, true));         // step was accepted afterwards
-            CHK(launch_normal_blocks(h, h->x, h->tab));                       // (nfev limit)
+            CHK(launch_normal_blocks(h, h->x, h->tab, h->rec));                       // (nfev limit)
             CHK(exchange(h, h->Ugc(), 27 * C, 0));
             nb_valid = true;
         }
@@ -1965,10 +1974,10 @@ static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt
             hipLaunchKernelGGL(k_prep, dim3(bc + bp), dim3(64), 0, h->stream, sc, Delta, opt.reg_min, h->Ugc(),
                                h->V.as<double>(), h->gp.as<double>(), h->si.as<double>(), (int)C, (int)P, bc,
                                h->Dc.as<double>(), h->Minv.as<double>(), h->Vinv.as<double>(),
-                               h->e.as<double>(), one_rank ? (const double*)h->partB() : (const double*)nullptr, np);
+                               h->rec + 3, one_rank ? (const double*)h->partB() : (const double*)nullptr, np);
             LAUNCHED(h);
         }
-        CHK(launch_cam_schur<1>(h, nullptr, h->e.as<double>(), nullptr, 0));      // reduced rhs term -> acc
+        CHK(launch_cam_schur<1>(h, nullptr, nullptr, 0));                          // reduced rhs term -> acc
         CHK(exchange(h, h->acc(), 6 * C, 0));
         const bool dense = h->dense && one_rank;               // (sharded: the block pairs would need their own all-reduce)
         if (!dense) CHK(pcg_start(h, opt));                     // replaces lsmr, trf.py:477-480
@@ -2006,7 +2015,7 @@ static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt
             const int bc = (int)((C + 255) / 256);
             hipLaunchKernelGGL(k_step_table, dim3(bc + grid_1d(3 * P, 256, 2048)), dim3(256), 0, h->stream, h->x,
                                h->sg.as<double>(), h->p.as<double>(), c1, c2, coef_dev, (int)C, n, bc, h->x_new,
-                               h->tab_new, h->skip);
+                               h->tab_new, h->rec_new, h->skip);
             LAUNCHED(h);
             // the trial point is evaluated WITH its Jacobian, into the same buffers: when
             // the step is accepted (the common case) nothing has to be recomputed
@@ -2041,7 +2050,7 @@ static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt
             // (speculating on acceptance, the common case).  They overwrite V / g_p / [U|g_c], which a
             // rejected step does not need: a retry only re-solves the 2-D model (host scalars) and
             // re-applies k_step_table to x, D^2 g and p, all untouched.
-            CHK(launch_normal_blocks(h, h->x_new, h->tab_new));
+            CHK(launch_normal_blocks(h, h->x_new, h->tab_new, h->rec_new));
             CHK(exchange(h, h->Ugc(), 27 * C, 0));
             nb_valid = false;
             CHK(wait_mailbox(h, h->mbox_seq));
@@ -2135,6 +2144,7 @@ static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt
         if (actual_reduction > 0.0) {                           // trf.py:528
             std::swap(h->x, h->x_new);
             std::swap(h->tab, h->tab_new);
+            std::swap(h->rec, h->rec_new);
             nb_valid = true;                                    // J, f and the normal blocks of the accepted
                                                                 // point are already there / in flight
             cost = cost_new;
