@@ -699,31 +699,32 @@ struct StepTable {
 
 // K2: V_p = sum Jp^T Jp (6, packed upper triangle), g_p = sum Jp^T r (3), recomputed from the camera table
 // and the point like K1 does (20 B per observation of indices and pixels instead of 64 B of stored blocks,
-// and exact fp64 in fp32-storage mode too).  256-thread workgroups: the kernel needs ~150 VGPRs, which a
-// 1024-thread workgroup cannot have; the camera table is staged in LDS only while three workgroups' copies fit
-// a CU (C <= 360), beyond that its rows (2.4 KB ... 136 KB, L2-resident) are gathered from global memory.
-constexpr int kPointBlockThreads = 256;
+// and exact fp64 in fp32-storage mode too).  One LANE per point: the lane walks its point's run and keeps the
+// nine sums in registers, so there is no cross-lane reduction at all (the wave-segmented form spent most of its
+// time in the DPP / v_readlane reduction of nine doubles per step).  The trip count of a wave is its longest run;
+// runs longer than kLongRun are left out of the per-lane walk and summed by the whole wave afterwards.
+// d r / d X and r need R and T only: the compact view of the camera table (rows of 96 bytes, 16-byte aligned),
+// staged in LDS when it fits (LDS_TAB), gathered with six 16-byte loads otherwise.
+constexpr int kPointBlockThreads = 512;
+constexpr int kLongRun = 64;
 template <bool LDS_TAB, bool F32>
 __global__ __launch_bounds__(kPointBlockThreads) void k_point_blocks(
-    StepTable st, const int* __restrict__ cam_idx, const int* __restrict__ pt_idx, const double* __restrict__ uv,
-    const double* __restrict__ camtab, const double* __restrict__ pts, int C, KMat K,
+    const int* __restrict__ pt_ptr, const int* __restrict__ cam_idx, const double* __restrict__ uv,
+    const double* __restrict__ camtab, const double* __restrict__ pts, int P, int C, KMat K,
     double* __restrict__ V, double* __restrict__ gp, const double* __restrict__ skip) {
     extern __shared__ __align__(16) double smem[];
     if (skip != nullptr && *skip != 0.0) return;   // speculative launch cancelled by k_tr_step
-    const int wg = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    int s = 0, s_end = 0;
-    if (wg < st.n_waves) { const int2 w = st.wsteps[wg]; s = w.x; s_end = w.x + w.y; }
-    int2 cur = make_int2(0, 0);
-    if (s < s_end) cur = st.steps[s];
-    int i = cur.x + lane, c = 0, p = 0;
-    double2 uvi = make_double2(0.0, 0.0);
-    if (cur.y <= 64 && lane < cur.y) { c = cam_idx[i]; p = pt_idx[i]; uvi = load_pair(uv, F32, i); }
-    // d r / d X and r need R and T only: the compact view of the camera table, rows of 96 bytes, 16-byte aligned,
-    // so that a row is six 16-byte loads (every load of a gathered row costs the texture addresser the same ~64
-    // cycles per wave whatever its width: half as many loads as from the 17-double rows)
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    int b = 0, e = 0;
+    double X = 0.0, Y = 0.0, Z = 0.0;
+    if (p < P) {
+        b = pt_ptr[p]; e = pt_ptr[p + 1];
+        const double* __restrict__ Xp = pts + 3 * (size_t)p;
+        X = Xp[0]; Y = Xp[1]; Z = Xp[2];
+    }
     const double* __restrict__ rt = camtab + cam_rt_offset(C);
-    if (LDS_TAB) {                               // stage it while those loads fly
+    if (LDS_TAB) {                               // stage the table while those loads fly
         const int n2 = (C * kCamRT) >> 1;
         const double2* __restrict__ src = reinterpret_cast<const double2*>(rt);
         double2* __restrict__ dst = reinterpret_cast<double2*>(smem);
@@ -731,7 +732,7 @@ __global__ __launch_bounds__(kPointBlockThreads) void k_point_blocks(
         __syncthreads();
     }
     const double* __restrict__ tab = LDS_TAB ? smem : rt;
-    auto terms = [&](int cc, double X, double Y, double Z, double2 px, double* v) {
+    auto add_terms = [&](int cc, double x_, double y_, double z_, double2 px, double* v) {
         double jc[12], jp[6], rx, ry;
         double t[kCamTab];
         const double2* __restrict__ row = reinterpret_cast<const double2*>(tab + (size_t)cc * kCamRT);
@@ -739,62 +740,56 @@ __global__ __launch_bounds__(kPointBlockThreads) void k_point_blocks(
         for (int k = 0; k < kCamRT / 2; ++k) { const double2 q = row[k]; t[2 * k] = q.x; t[2 * k + 1] = q.y; }
 #pragma unroll
         for (int k = kCamRT; k < kCamTab; ++k) t[k] = 0.0;       // the rotation part of the camera block is not used here
-        observe<true>(t, X, Y, Z, px.x, px.y, K, rx, ry, jc, jp);
-        v[0] = jp[0] * jp[0] + jp[3] * jp[3]; v[1] = jp[0] * jp[1] + jp[3] * jp[4];
-        v[2] = jp[0] * jp[2] + jp[3] * jp[5]; v[3] = jp[1] * jp[1] + jp[4] * jp[4];
-        v[4] = jp[1] * jp[2] + jp[4] * jp[5]; v[5] = jp[2] * jp[2] + jp[5] * jp[5];
-        v[6] = jp[0] * rx + jp[3] * ry; v[7] = jp[1] * rx + jp[4] * ry; v[8] = jp[2] * rx + jp[5] * ry;
+        observe<true>(t, x_, y_, z_, px.x, px.y, K, rx, ry, jc, jp);
+        v[0] += jp[0] * jp[0] + jp[3] * jp[3]; v[1] += jp[0] * jp[1] + jp[3] * jp[4];
+        v[2] += jp[0] * jp[2] + jp[3] * jp[5]; v[3] += jp[1] * jp[1] + jp[4] * jp[4];
+        v[4] += jp[1] * jp[2] + jp[4] * jp[5]; v[5] += jp[2] * jp[2] + jp[5] * jp[5];
+        v[6] += jp[0] * rx + jp[3] * ry; v[7] += jp[1] * rx + jp[4] * ry; v[8] += jp[2] * rx + jp[5] * ry;
     };
-    while (s < s_end) {
-        int2 nxt = make_int2(0, 0);
-        if (s + 1 < s_end) nxt = st.steps[s + 1];
-        const int in_ = nxt.x + lane;
-        int cn = 0, pn = 0;
-        double2 uvn = make_double2(0.0, 0.0);
-        if (nxt.y <= 64 && lane < nxt.y) { cn = cam_idx[in_]; pn = pt_idx[in_]; uvn = load_pair(uv, F32, in_); }
-        double v[9];
-        if (cur.y > 64) {                          // one point with more than 64 observations
-            const int run_end = cur.x + cur.y;
-            const int pp = pt_idx[cur.x];
-            const double* __restrict__ Xp = pts + 3 * (size_t)pp;
-            const double X = Xp[0], Y = Xp[1], Z = Xp[2];
+    const int len = e - b;
+    const bool is_long = len > kLongRun;
+    double v[9];
 #pragma unroll
-            for (int q = 0; q < 9; ++q) v[q] = 0.0;
-            for (int j = cur.x + lane; j < run_end; j += 64) {
-                double w[9];
-                terms(cam_idx[j], X, Y, Z, load_pair(uv, F32, j), w);
+    for (int q = 0; q < 9; ++q) v[q] = 0.0;
+    // the next observation's index and pixel are requested while this one computes
+    int i = b;
+    bool on = !is_long && i < e;
+    int c = 0;
+    double2 px = make_double2(0.0, 0.0);
+    if (on) { c = cam_idx[i]; px = load_pair(uv, F32, i); }
+    while (__ballot(on) != 0ull) {
+        const int in_ = i + 1;
+        const bool on_n = on && in_ < e;
+        int cn = 0;
+        double2 pxn = make_double2(0.0, 0.0);
+        if (on_n) { cn = cam_idx[in_]; pxn = load_pair(uv, F32, in_); }
+        if (on) add_terms(c, X, Y, Z, px, v);
+        i = in_; on = on_n; c = cn; px = pxn;
+    }
+    if (p < P && !is_long) {                      // a point without observations gets its zeros here
 #pragma unroll
-                for (int q = 0; q < 9; ++q) v[q] += w[q];
-            }
+        for (int q = 0; q < 6; ++q) V[(size_t)p * 6 + q] = v[q];
 #pragma unroll
-            for (int q = 0; q < 9; ++q) v[q] = wave_sum(v[q]);
-            if (lane == 0) {
+        for (int q = 0; q < 3; ++q) gp[(size_t)p * 3 + q] = v[6 + q];
+    }
+    unsigned long long todo = __ballot(is_long);  // long runs: the whole wave sums one point at a time
+    while (todo != 0ull) {
+        const int l = __ffsll((long long)todo) - 1;
+        todo &= todo - 1ull;
+        const int pp = __shfl(p, l), bb = __shfl(b, l), ee = __shfl(e, l);
+        const double xl = __shfl(X, l), yl = __shfl(Y, l), zl = __shfl(Z, l);
+        double w[9];
 #pragma unroll
-                for (int q = 0; q < 6; ++q) V[(size_t)pp * 6 + q] = v[q];
+        for (int q = 0; q < 9; ++q) w[q] = 0.0;
+        for (int j = bb + lane; j < ee; j += 64) add_terms(cam_idx[j], xl, yl, zl, load_pair(uv, F32, j), w);
 #pragma unroll
-                for (int q = 0; q < 3; ++q) gp[(size_t)pp * 3 + q] = v[6 + q];
-            }
-        } else {
-            const bool act = lane < cur.y;
-            if (act) {
-                const double* __restrict__ Xp = pts + 3 * (size_t)p;
-                terms(c, Xp[0], Xp[1], Xp[2], uvi, v);
-            } else {
+        for (int q = 0; q < 9; ++q) w[q] = wave_sum(w[q]);
+        if (lane == 0) {
 #pragma unroll
-                for (int q = 0; q < 9; ++q) v[q] = 0.0;
-            }
-            const int key = act ? p : -1 - lane;
-            seg_reduce<9>(v, key, lane);
-            const int prev = __shfl_up(key, 1);
-            if (act && (lane == 0 || prev != key)) {          // first lane of the point's run
+            for (int q = 0; q < 6; ++q) V[(size_t)pp * 6 + q] = w[q];
 #pragma unroll
-                for (int q = 0; q < 6; ++q) V[(size_t)p * 6 + q] = v[q];
-#pragma unroll
-                for (int q = 0; q < 3; ++q) gp[(size_t)p * 3 + q] = v[6 + q];
-            }
+            for (int q = 0; q < 3; ++q) gp[(size_t)pp * 3 + q] = w[6 + q];
         }
-        cur = nxt; i = in_; c = cn; p = pn; uvi = uvn;
-        ++s;
     }
 }
 
@@ -1597,6 +1592,18 @@ __global__ __launch_bounds__(kCamThreads) void k_cam_schur(CamMajor cm, const do
 #pragma unroll
         for (int k = 0; k < 6; ++k) vc[k] = vin[(size_t)k * C + ch.x];
     }
+    // Exact blocks (ROUND = false): with j_k = row k of d r/d X, v = X - T and h = v x a' + v_T + z (a' as in
+    // k_point_sweep_rc), the two residual-space values are u_k = -j_k . h, and the camera sums follow from
+    //     q = sum_k u_k j_k :   translation part  -sum q,   rotation part  -(M - b (M x w) + c ((M x w) x w)),  M = sum q x v
+    // -- the rotation Jacobian is applied ONCE per workgroup to the summed M instead of per observation (it is
+    // linear in M): ~100 flop per observation instead of ~200.  a[0..2] = sum q x v, a[3..5] = sum q.
+    double ap[3] = {0.0, 0.0, 0.0};
+    if (MODE == 0 && !ROUND) {
+        const double wx = t[12], wy = t[13], wz = t[14];
+        const double c0 = wy * vc[2] - wz * vc[1], c1 = wz * vc[0] - wx * vc[2], c2 = wx * vc[1] - wy * vc[0];
+        const double d0 = wy * c2 - wz * c1, d1 = wz * c0 - wx * c2, d2 = wx * c1 - wy * c0;
+        ap[0] = vc[0] - t[15] * c0 + t[16] * d0; ap[1] = vc[1] - t[15] * c1 + t[16] * d1; ap[2] = vc[2] - t[15] * c2 + t[16] * d2;
+    }
     double a[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     for (int k0 = ch.y + (int)threadIdx.x; k0 < ch.z; k0 += kCamThreads * kCamUnroll) {      // see k_cam_blocks
         int p[kCamUnroll];
@@ -1616,30 +1623,77 @@ __global__ __launch_bounds__(kCamThreads) void k_cam_schur(CamMajor cm, const do
 #pragma unroll
         for (int u = 0; u < kCamUnroll; ++u) {
             if (p[u] < 0) continue;
-            double jc[12], jp[6], rx, ry;
-            observe<true>(t, X[u][0], X[u][1], X[u][2], 0.0, 0.0, K, rx, ry, jc, jp);
             if (ROUND) {
+                double jc[12], jp[6], rx, ry;
+                observe<true>(t, X[u][0], X[u][1], X[u][2], 0.0, 0.0, K, rx, ry, jc, jp);
 #pragma unroll
                 for (int q = 0; q < 3; ++q) { jc[q] = (double)(float)jc[q]; jc[6 + q] = (double)(float)jc[6 + q]; }
 #pragma unroll
                 for (int q = 0; q < 6; ++q) jp[q] = (double)(float)jp[q];
 #pragma unroll
                 for (int q = 0; q < 3; ++q) { jc[3 + q] = -jp[q]; jc[9 + q] = -jp[3 + q]; }
-            }
-            double u0 = -(jp[0] * z[u][0] + jp[1] * z[u][1] + jp[2] * z[u][2]);
-            double u1 = -(jp[3] * z[u][0] + jp[4] * z[u][1] + jp[5] * z[u][2]);
-            if (MODE == 0) {
+                double u0 = -(jp[0] * z[u][0] + jp[1] * z[u][1] + jp[2] * z[u][2]);
+                double u1 = -(jp[3] * z[u][0] + jp[4] * z[u][1] + jp[5] * z[u][2]);
+                if (MODE == 0) {
 #pragma unroll
-                for (int q = 0; q < 6; ++q) { u0 += jc[q] * vc[q]; u1 += jc[6 + q] * vc[q]; }
-            }
+                    for (int q = 0; q < 6; ++q) { u0 += jc[q] * vc[q]; u1 += jc[6 + q] * vc[q]; }
+                }
 #pragma unroll
-            for (int q = 0; q < 6; ++q) a[q] += jc[q] * u0 + jc[6 + q] * u1;
+                for (int q = 0; q < 6; ++q) a[q] += jc[q] * u0 + jc[6 + q] * u1;
+            } else {
+                const double vx = X[u][0] - t[9], vy = X[u][1] - t[10], vz = X[u][2] - t[11];
+                const double qx = t[0] * vx + t[1] * vy + t[2] * vz;
+                const double qy = t[3] * vx + t[4] * vy + t[5] * vz;
+                const double qz = t[6] * vx + t[7] * vy + t[8] * vz;
+                const double px = K.k[0] * qx + K.k[1] * qy + K.k[2] * qz;
+                const double py = K.k[3] * qx + K.k[4] * qy + K.k[5] * qz;
+                const double pz = K.k[6] * qx + K.k[7] * qy + K.k[8] * qz;
+                const double iz = 1.0 / pz;
+                double h0 = z[u][0], h1 = z[u][1], h2 = z[u][2];
+                if (MODE == 0) {
+                    h0 += vy * ap[2] - vz * ap[1] + vc[3];
+                    h1 += vz * ap[0] - vx * ap[2] + vc[4];
+                    h2 += vx * ap[1] - vy * ap[0] + vc[5];
+                }
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0;             // q = sum_k u_k j_k
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const double pk = (k == 0 ? px : py) * iz;
+                    const double b0 = (K.k[3 * k + 0] - pk * K.k[6]) * iz;
+                    const double b1 = (K.k[3 * k + 1] - pk * K.k[7]) * iz;
+                    const double b2 = (K.k[3 * k + 2] - pk * K.k[8]) * iz;
+                    const double j0 = b0 * t[0] + b1 * t[3] + b2 * t[6];
+                    const double j1 = b0 * t[1] + b1 * t[4] + b2 * t[7];
+                    const double j2 = b0 * t[2] + b1 * t[5] + b2 * t[8];
+                    const double uk = -(j0 * h0 + j1 * h1 + j2 * h2);
+                    s0 += uk * j0; s1 += uk * j1; s2 += uk * j2;
+                }
+                a[0] += s1 * vz - s2 * vy; a[1] += s2 * vx - s0 * vz; a[2] += s0 * vy - s1 * vx;       // q x v
+                a[3] += s0; a[4] += s1; a[5] += s2;
+            }
         }
     }
     const double s = cam_block_total<6>(a, red);
+    double out = s;
+    if (!ROUND) {                                        // rotation Jacobian applied to the summed M (see above)
+        __shared__ double tot[6];
+        if (threadIdx.x < 6) tot[threadIdx.x] = s;
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            const double wx = t[12], wy = t[13], wz = t[14];
+            const double m0 = tot[0], m1 = tot[1], m2 = tot[2];
+            const double c0 = m1 * wz - m2 * wy, c1 = m2 * wx - m0 * wz, c2 = m0 * wy - m1 * wx;          // M x w
+            const double d0 = c1 * wz - c2 * wy, d1 = c2 * wx - c0 * wz, d2 = c0 * wy - c1 * wx;          // (M x w) x w
+            const double r0 = -(m0 - t[15] * c0 + t[16] * d0), r1 = -(m1 - t[15] * c1 + t[16] * d1),
+                         r2 = -(m2 - t[15] * c2 + t[16] * d2);
+            out = threadIdx.x == 0 ? r0 : (threadIdx.x == 1 ? r1 : r2);
+        } else if (threadIdx.x < 6) {
+            out = -tot[threadIdx.x];
+        }
+    }
     if (threadIdx.x < 6) {
-        if (ch.w == 1) acc[(size_t)threadIdx.x * C + ch.x] = s;
-        else partial[(size_t)blockIdx.x * 6 + threadIdx.x] = s;
+        if (ch.w == 1) acc[(size_t)threadIdx.x * C + ch.x] = out;
+        else partial[(size_t)blockIdx.x * 6 + threadIdx.x] = out;
     }
 }
 

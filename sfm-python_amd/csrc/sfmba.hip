@@ -594,17 +594,19 @@ int launch_cam_combine(sfmba_handle* h, int ncols, double* out, int cs, int ks, 
 template <bool F32>
 int launch_normal_blocks_v(sfmba_handle* h, const double* x, const double* tab, const double* rec) {
     const double* pts = x + 6 * h->C;
-    constexpr int wpb = kPointBlockThreads / 64;
-    const int grid = (h->n_ranges + wpb - 1) / wpb;
+    const int grid = (int)((h->P + kPointBlockThreads - 1) / kPointBlockThreads);
     const size_t lds = (size_t)h->C * kCamRT * sizeof(double);
-    if (lds <= 48 * 1024 && h->dbg.tab_lds != 0) {
-        hipLaunchKernelGGL((k_point_blocks<true, F32>), dim3(grid), dim3(kPointBlockThreads), lds, h->stream, step_table(h),
-                           h->cam_idx.as<int>(), h->pt_idx.as<int>(), h->uv.as<double>(), tab, pts, (int)h->C, h->K,
-                           h->V.as<double>(), h->gp.as<double>(), h->skip);
+    if (lds <= kLdsDynMax && h->dbg.tab_lds != 0) {
+        auto kern = k_point_blocks<true, F32>;
+        CHK(set_lds(h, kern, lds));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kPointBlockThreads), lds, h->stream, (const int*)h->pt_ptr.as<int>(),
+                           (const int*)h->cam_idx.as<int>(), (const double*)h->uv.as<double>(), tab, pts, (int)h->P,
+                           (int)h->C, h->K, h->V.as<double>(), h->gp.as<double>(), h->skip);
     } else {
-        hipLaunchKernelGGL((k_point_blocks<false, F32>), dim3(grid), dim3(kPointBlockThreads), 0, h->stream, step_table(h),
-                           h->cam_idx.as<int>(), h->pt_idx.as<int>(), h->uv.as<double>(), tab, pts, (int)h->C, h->K,
-                           h->V.as<double>(), h->gp.as<double>(), h->skip);
+        hipLaunchKernelGGL((k_point_blocks<false, F32>), dim3(grid), dim3(kPointBlockThreads), 0, h->stream,
+                           (const int*)h->pt_ptr.as<int>(), (const int*)h->cam_idx.as<int>(),
+                           (const double*)h->uv.as<double>(), tab, pts, (int)h->P, (int)h->C, h->K, h->V.as<double>(),
+                           h->gp.as<double>(), h->skip);
     }
     LAUNCHED(h);
     hipLaunchKernelGGL((k_cam_blocks<F32>), dim3(h->n_chunks), dim3(kCamThreads), 0, h->stream, cam_major(h), tab, rec,
