@@ -1029,22 +1029,33 @@ __global__ void k_point_prep(const double* __restrict__ V, const double* __restr
 // reduced camera system; Dc = reg si_c^2 is also written out.  Camera-sized PCG vectors (Dc, Minv,
 // acc, x, r, p, s, u) are stored plane-major, element k of camera c at [k*C + c], so that the
 // one-thread-per-camera PCG kernels read and write them fully coalesced.
+// sd (optional, plane-major [21][C]): sum_i W_i Vinv W_i^T of the camera's own observations -- with it the block
+// is the true diagonal block of the reduced camera matrix S (Schur-diagonal preconditioner) and Dc is read, not
+// written (it was formed before the pass that produced sd).
 __device__ __forceinline__ void cam_prep_one(const double* __restrict__ Ugc, const double* __restrict__ sic,
                                              const double* __restrict__ dc_extra, int C, int c, double reg,
-                                             double* __restrict__ Dc, double* __restrict__ Minv) {
+                                             double* __restrict__ Dc, double* __restrict__ Minv,
+                                             const double* __restrict__ sd = nullptr) {
     double A[6][6];
     {
         int n = 0;
 #pragma unroll
         for (int a = 0; a < 6; ++a)
 #pragma unroll
-            for (int b = a; b < 6; ++b) { A[a][b] = Ugc[(size_t)c * 27 + n]; A[b][a] = A[a][b]; ++n; }
+            for (int b = a; b < 6; ++b) {
+                A[a][b] = Ugc[(size_t)c * 27 + n] - (sd ? sd[(size_t)n * C + c] : 0.0);
+                A[b][a] = A[a][b];
+                ++n;
+            }
     }
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
-        const double d = dc_extra ? dc_extra[6 * (size_t)c + a]
-                                  : reg * sic[6 * (size_t)c + a] * sic[6 * (size_t)c + a];
-        Dc[(size_t)a * C + c] = d;                      // plane-major over cameras (coalesced in the PCG)
+        double d;
+        if (sd) d = Dc[(size_t)a * C + c];
+        else {
+            d = dc_extra ? dc_extra[6 * (size_t)c + a] : reg * sic[6 * (size_t)c + a] * sic[6 * (size_t)c + a];
+            Dc[(size_t)a * C + c] = d;                  // plane-major over cameras (coalesced in the PCG)
+        }
         A[a][a] += d;
     }
     double Lm[6][6];
@@ -1097,6 +1108,15 @@ __global__ void k_cam_prep(const double* __restrict__ Ugc, const double* __restr
     cam_prep_one(Ugc, sic, dc_extra, C, c, reg, Dc, Minv);
 }
 
+// Schur-diagonal preconditioner: Minv = (U + Dc - sum_i W_i Vinv W_i^T)^-1 per camera, after the pass that summed
+// the last term (k_cam_schur MODE 1 with DIAG) and its all-reduce.
+__global__ __launch_bounds__(64) void k_cam_prep_schur(const double* __restrict__ Ugc, const double* __restrict__ sd, int C,
+                                                       double* __restrict__ Dc, double* __restrict__ Minv) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    cam_prep_one(Ugc, nullptr, nullptr, C, c, 0.0, Dc, Minv, sd);
+}
+
 // Everything between the Cauchy product and the reduced right-hand side in one launch: the
 // regularisation term from the exchange scalars (every thread evaluates the same few flops, block 0
 // publishes it in scalar slot 13), blocks [0, bc): one camera per thread (Dc, Minv),
@@ -1126,7 +1146,9 @@ __global__ __launch_bounds__(64) void k_prep(double* __restrict__ sc, double Del
     if ((int)blockIdx.x < bc) {
         const int c = blockIdx.x * blockDim.x + threadIdx.x;
         if (c >= C) return;
-        cam_prep_one(Ugc, si, nullptr, C, c, reg, Dc, Minv);
+        if (Minv != nullptr) { cam_prep_one(Ugc, si, nullptr, C, c, reg, Dc, Minv); return; }
+#pragma unroll                                        // Schur-diagonal preconditioner: only Dc here, Minv by k_cam_prep_schur
+        for (int a = 0; a < 6; ++a) Dc[(size_t)a * C + c] = reg * si[6 * (size_t)c + a] * si[6 * (size_t)c + a];
         return;
     }
     const int p = (blockIdx.x - bc) * blockDim.x + threadIdx.x;
@@ -1694,6 +1716,80 @@ __global__ __launch_bounds__(kCamThreads) void k_cam_schur(CamMajor cm, const do
     if (threadIdx.x < 6) {
         if (ch.w == 1) acc[(size_t)threadIdx.x * C + ch.x] = out;
         else partial[(size_t)blockIdx.x * 6 + threadIdx.x] = out;
+    }
+}
+
+// Reduced right-hand side WITH the diagonal blocks of W Vinv W^T (Schur-diagonal preconditioner): one camera-major
+// pass yields, per camera,  out[0..5] = -sum_i W_i e_p  (what k_cam_schur MODE 1 computes) and
+// out[6..26] = sum_i W_i Vinv_p W_i^T  (packed upper triangle), W_i = Jc_i^T Jp_i.  Every W_i is formed anyway for the
+// first sum; the second costs one more gathered row per observation (Vinv_p, 48 bytes) and no pass of its own.
+// Output plane-major [27][C] (acc | sd: one contiguous vector for the all-reduce) or partial[chunk][27].
+template <bool ROUND>
+__global__ __launch_bounds__(kCamThreads) void k_cam_rhs_diag(CamMajor cm, const double* __restrict__ camtab,
+                                                              const double* __restrict__ rec,
+                                                              const double* __restrict__ Vinv, KMat K, int C,
+                                                              double* __restrict__ out, double* __restrict__ partial) {
+    __shared__ double red[kCamWaves][27];
+    const int4 ch = cm.chunks[blockIdx.x];
+    double t[kCamTab];
+#pragma unroll
+    for (int k = 0; k < kCamTab; ++k) t[k] = camtab[(size_t)ch.x * kCamTab + k];      // wave-uniform: scalar loads
+    double a[27];
+#pragma unroll
+    for (int q = 0; q < 27; ++q) a[q] = 0.0;
+    constexpr int kU = 2;                          // 27 accumulators: two observations in flight per lane
+    for (int k0 = ch.y + (int)threadIdx.x; k0 < ch.z; k0 += kCamThreads * kU) {
+        int p[kU];
+        double X[kU][3], e[kU][3], vi[kU][6];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int k = k0 + u * kCamThreads;
+            p[u] = k < ch.z ? cm.pt[k] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const size_t pp = (size_t)(p[u] < 0 ? 0 : p[u]);
+            const double2* __restrict__ rp = reinterpret_cast<const double2*>(rec + kRec * pp);
+            const double2* __restrict__ vp = reinterpret_cast<const double2*>(Vinv + 6 * pp);
+            const double2 r0 = rp[0], r1 = rp[1], r2 = rp[2], v0 = vp[0], v1 = vp[1], v2 = vp[2];
+            X[u][0] = r0.x; X[u][1] = r0.y; X[u][2] = r1.x;
+            e[u][0] = r1.y; e[u][1] = r2.x; e[u][2] = r2.y;
+            vi[u][0] = v0.x; vi[u][1] = v0.y; vi[u][2] = v1.x; vi[u][3] = v1.y; vi[u][4] = v2.x; vi[u][5] = v2.y;
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            if (p[u] < 0) continue;
+            double jc[12], jp[6], rx, ry;
+            observe<true>(t, X[u][0], X[u][1], X[u][2], 0.0, 0.0, K, rx, ry, jc, jp);
+            if (ROUND) {                           // as stored in fp32 (see k_cam_schur)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) { jc[q] = (double)(float)jc[q]; jc[6 + q] = (double)(float)jc[6 + q]; }
+#pragma unroll
+                for (int q = 0; q < 6; ++q) jp[q] = (double)(float)jp[q];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) { jc[3 + q] = -jp[q]; jc[9 + q] = -jp[3 + q]; }
+            }
+            double W[6][3], Y[6][3];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) W[i][j] = jc[i] * jp[j] + jc[6 + i] * jp[3 + j];
+                Y[i][0] = W[i][0] * vi[u][0] + W[i][1] * vi[u][1] + W[i][2] * vi[u][2];      // W Vinv (Vinv packed upper)
+                Y[i][1] = W[i][0] * vi[u][1] + W[i][1] * vi[u][3] + W[i][2] * vi[u][4];
+                Y[i][2] = W[i][0] * vi[u][2] + W[i][1] * vi[u][4] + W[i][2] * vi[u][5];
+                a[i] -= W[i][0] * e[u][0] + W[i][1] * e[u][1] + W[i][2] * e[u][2];
+            }
+            int n = 6;
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = i; j < 6; ++j) a[n++] += Y[i][0] * W[j][0] + Y[i][1] * W[j][1] + Y[i][2] * W[j][2];
+        }
+    }
+    const double s = cam_block_total<27>(a, red);
+    if (threadIdx.x < 27) {
+        if (ch.w == 1) out[(size_t)threadIdx.x * C + ch.x] = s;
+        else partial[(size_t)blockIdx.x * 27 + threadIdx.x] = s;
     }
 }
 

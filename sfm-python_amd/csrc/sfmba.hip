@@ -226,6 +226,7 @@ struct sfmba_handle {
         int tab_lds = -1, vec_lds = -1;      // 0: camera table / camera vector read from L2 although LDS would fit
         int sweep_rc = -1;                   // 0: pass A reads the stored Jacobian although the recomputing form would fit
         int dense = -1;                      // 0: PCG although the dense reduced-camera path would apply
+        int precond = -1;                    // 0: block-Jacobi preconditioner from U + Dc instead of the Schur diagonal
         int cam_chunk = 0;                   // > 0: chunk length of the camera-major kernels
         int pcg_guess_bias = 0;              // added to the number of speculatively enqueued PCG iterations
         int trace_pcg = 0, trace_stalls = 0, trace_timing = 0;   // stderr diagnostics
@@ -246,7 +247,7 @@ struct sfmba_handle {
     DevBuf Dc, Minv, vecs, vtmp, vcm;               // camera-sized, plane-major [k][C]; vecs = 2 sets x (x r p s u)
     DevBuf part, ctrl;
     DevBuf arena_own;
-    double* arena = nullptr;                 // [acc 6C | spare 12C | Ugc 27C | 32 scalars]
+    double* arena = nullptr;                 // [acc 6C | sd 21C | Ugc 27C | 32 scalars]; acc | sd are plane-major [27][C]
     int64_t arena_doubles = 0;
     sfmba_allreduce_fn ar_fn = nullptr;
     void* ar_ctx = nullptr;
@@ -300,8 +301,9 @@ struct sfmba_handle {
     double* rec_new = nullptr;
 
     double* acc() const { return arena; }    // product of the implicit Schur complement / reduced rhs term (6C)
-    double* Ugc() const { return arena + 18 * C; }
-    double* scal() const { return arena + 45 * C; }
+    double* sd() const { return arena + 6 * C; }       // diagonal blocks of W Vinv W^T (Schur-diagonal preconditioner)
+    double* Ugc() const { return arena + 27 * C; }
+    double* scal() const { return arena + 54 * C; }
     int pcg_L = 0;                           // launches (sweep+update pairs) since pcg_start
     int red_bc = 1, red_grid = 2;            // block split of k_update_scale's reduction (cameras | points)
     double* partB() const { return part.as<double>() + (size_t)kPartRows * kNQ; }
@@ -692,6 +694,32 @@ int launch_cam_schur(sfmba_handle* h, const double* vin, const PcgCtrl* ctrl_don
     return launch_cam_combine(h, 6, h->acc(), 1, (int)h->C, nullptr, ctrl_done ? &ctrl_done->done : nullptr);
 }
 
+// Reduced right-hand side term -> acc and, with the Schur-diagonal preconditioner, the diagonal blocks of
+// W Vinv W^T -> sd in the same pass; all-reduce; block inverses.  (k_prep has written e into the records and, for
+// the block-Jacobi-of-U form, Minv itself.)
+int launch_rhs_and_preconditioner(sfmba_handle* h) {
+    const int64_t C = h->C;
+    if (h->dbg.precond == 0) {
+        CHK(launch_cam_schur<1>(h, nullptr, nullptr, 0));
+        return exchange(h, h->acc(), 6 * C, 0);
+    }
+    if (h->f32 && !h->sweep_rc)
+        hipLaunchKernelGGL((k_cam_rhs_diag<true>), dim3(h->n_chunks), dim3(kCamThreads), 0, h->stream, cam_major(h),
+                           (const double*)h->tab, (const double*)h->rec, (const double*)h->Vinv.as<double>(), h->K, (int)C,
+                           h->acc(), h->cam_partial.as<double>());
+    else
+        hipLaunchKernelGGL((k_cam_rhs_diag<false>), dim3(h->n_chunks), dim3(kCamThreads), 0, h->stream, cam_major(h),
+                           (const double*)h->tab, (const double*)h->rec, (const double*)h->Vinv.as<double>(), h->K, (int)C,
+                           h->acc(), h->cam_partial.as<double>());
+    LAUNCHED(h);
+    CHK(launch_cam_combine(h, 27, h->acc(), 1, (int)C, nullptr, nullptr));
+    CHK(exchange(h, h->acc(), 27 * C, 0));                  // acc | sd: one contiguous plane-major vector
+    hipLaunchKernelGGL(k_cam_prep_schur, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, h->stream, (const double*)h->Ugc(),
+                       (const double*)h->sd(), (int)C, h->Dc.as<double>(), h->Minv.as<double>());
+    LAUNCHED(h);
+    return 0;
+}
+
 // Dense reduced-camera path: form the block pairs of W V^-1 W^T, factorise S = U + Dc - (...) in one workgroup and
 // leave the camera step where the PCG would have left it (x of vector set 0, control block "converged").
 // acc must hold the reduced right-hand-side term (pass B, MODE 1).
@@ -1061,6 +1089,7 @@ int sfmba_debug_option(sfmba_handle* h, const char* name, int64_t value) {
     if (n == "pcg_fused") h->dbg.pcg_fused = v;
     else if (n == "sweep_rc") h->dbg.sweep_rc = v;
     else if (n == "dense") h->dbg.dense = v;
+    else if (n == "precond") h->dbg.precond = v;
     else if (n == "tab_lds") h->dbg.tab_lds = v;
     else if (n == "vec_lds") h->dbg.vec_lds = v;
     else if (n == "cam_chunk") h->dbg.cam_chunk = v;
@@ -1082,7 +1111,7 @@ int sfmba_set_precision(sfmba_handle* h, int32_t storage_bits) {
     return 0;
 }
 
-int64_t sfmba_exchange_doubles(int64_t n_cameras) { return 45 * n_cameras + kScalSlots; }   // kScalSlots = 32
+int64_t sfmba_exchange_doubles(int64_t n_cameras) { return 54 * n_cameras + kScalSlots; }   // kScalSlots = 32
 
 int sfmba_set_exchange(sfmba_handle* h, void* arena, int64_t arena_doubles, sfmba_allreduce_fn fn,
                        void* ctx, int64_t n_obs_total) {
@@ -1975,13 +2004,14 @@ static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt
             const int bc = (int)((C + 63) / 64), bp = (int)((P + 63) / 64);
             hipLaunchKernelGGL(k_prep, dim3(bc + bp), dim3(64), 0, h->stream, sc, Delta, opt.reg_min, h->Ugc(),
                                h->V.as<double>(), h->gp.as<double>(), h->si.as<double>(), (int)C, (int)P, bc,
-                               h->Dc.as<double>(), h->Minv.as<double>(), h->Vinv.as<double>(),
-                               h->rec + 3, one_rank ? (const double*)h->partB() : (const double*)nullptr, np);
+                               h->Dc.as<double>(), (h->dbg.precond == 0 ? h->Minv.as<double>() : (double*)nullptr),
+                               h->Vinv.as<double>(), h->rec + 3,
+                               one_rank ? (const double*)h->partB() : (const double*)nullptr, np);
             LAUNCHED(h);
         }
-        CHK(launch_cam_schur<1>(h, nullptr, nullptr, 0));                          // reduced rhs term -> acc
-        CHK(exchange(h, h->acc(), 6 * C, 0));
         const bool dense = h->dense && one_rank;               // (sharded: the block pairs would need their own all-reduce)
+        if (dense) CHK(launch_cam_schur<1>(h, nullptr, nullptr, 0));               // reduced rhs term -> acc
+        else CHK(launch_rhs_and_preconditioner(h));             // ... and the preconditioner blocks
         if (!dense) CHK(pcg_start(h, opt));                     // replaces lsmr, trf.py:477-480
         PcgCtrl hc{};
         if (dense) {

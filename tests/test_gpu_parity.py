@@ -220,7 +220,7 @@ def dbg():
             b.debug_option(name, value)
             touched.append((b, name))
     yield set_
-    defaults = dict(pcg_fused=-1, tab_lds=-1, vec_lds=-1, cam_chunk=0, pcg_guess_bias=0, sweep_rc=-1, dense=-1)
+    defaults = dict(pcg_fused=-1, tab_lds=-1, vec_lds=-1, cam_chunk=0, pcg_guess_bias=0, sweep_rc=-1, dense=-1, precond=-1)
     for b, name in touched:
         b.debug_option(name, defaults[name])
 
@@ -272,7 +272,7 @@ def test_results_are_bitwise_reproducible(be):
 def _oracle_kwargs(dense):
     """The reduced camera system is solved exactly (formed and factorised) when 6 C <= 128, by block-Jacobi PCG to
     1e-3 otherwise or when the debug option `dense` is 0: the oracle restates both."""
-    return dict(linear="dense") if dense else dict(linear="pcg", pcg_tol=1e-3)
+    return dict(linear="dense") if dense else dict(linear="pcg", pcg_tol=1e-3, precond="schur")
 
 
 def test_solve_matches_scipy_on_tiny_problems(orc, dbg):
@@ -420,7 +420,7 @@ def test_full_solves_with_many_cameras_vs_oracle(orc):
     import sfmba
     for C, P, N in ((1300, 4000, 40000), (1800, 3000, 30000)):
         pb = sfmba.make_problem(C, P, N, seed=21)
-        o = orc.trf_schur(pb.x0, *pb.args, ftol=1e-10, linear="pcg", pcg_tol=1e-3)
+        o = orc.trf_schur(pb.x0, *pb.args, ftol=1e-10, **_oracle_kwargs(False))
         res = sfmba.least_squares(sfmba.compute_residuals, pb.x0, x_scale="jac", ftol=1e-10, method="trf",
                                   args=pb.args)
         assert res.status == o.status and (res.nfev, res.njev) == (o.nfev, o.njev)
@@ -434,7 +434,7 @@ def test_cfg3_full_loop_vs_oracle(orc):
     GPU against the oracle's."""
     import sfmba
     pb = sfmba.make_config("cfg3")
-    o = orc.trf_schur(pb.x0, *pb.args, ftol=1e-10, linear="pcg", pcg_tol=1e-3)
+    o = orc.trf_schur(pb.x0, *pb.args, ftol=1e-10, **_oracle_kwargs(False))
     res = sfmba.least_squares(sfmba.compute_residuals, pb.x0, x_scale="jac", ftol=1e-10, method="trf",
                               args=pb.args)
     assert res.status == o.status and (res.nfev, res.njev) == (o.nfev, o.njev)
