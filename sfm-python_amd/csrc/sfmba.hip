@@ -596,16 +596,18 @@ int launch_cam_combine(sfmba_handle* h, int ncols, double* out, int cs, int ks, 
 template <bool F32>
 int launch_normal_blocks_v(sfmba_handle* h, const double* x, const double* tab, const double* rec) {
     const double* pts = x + 6 * h->C;
-    const int grid = (int)((h->P + kPointBlockThreads - 1) / kPointBlockThreads);
+    // one lane per point; workgroups of 64 ... 512 threads, sized so that a small cloud still covers the chip
+    const int threads = (int)std::min<int64_t>(kPointBlockThreads, std::max<int64_t>(64, (h->P / h->n_cu + 63) / 64 * 64));
+    const int grid = (int)((h->P + threads - 1) / threads);
     const size_t lds = (size_t)h->C * kCamRT * sizeof(double);
     if (lds <= kLdsDynMax && h->dbg.tab_lds != 0) {
         auto kern = k_point_blocks<true, F32>;
         CHK(set_lds(h, kern, lds));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kPointBlockThreads), lds, h->stream, (const int*)h->pt_ptr.as<int>(),
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, h->stream, (const int*)h->pt_ptr.as<int>(),
                            (const int*)h->cam_idx.as<int>(), (const double*)h->uv.as<double>(), tab, pts, (int)h->P,
                            (int)h->C, h->K, h->V.as<double>(), h->gp.as<double>(), h->skip);
     } else {
-        hipLaunchKernelGGL((k_point_blocks<false, F32>), dim3(grid), dim3(kPointBlockThreads), 0, h->stream,
+        hipLaunchKernelGGL((k_point_blocks<false, F32>), dim3(grid), dim3(threads), 0, h->stream,
                            (const int*)h->pt_ptr.as<int>(), (const int*)h->cam_idx.as<int>(),
                            (const double*)h->uv.as<double>(), tab, pts, (int)h->P, (int)h->C, h->K, h->V.as<double>(),
                            h->gp.as<double>(), h->skip);

@@ -814,3 +814,81 @@ def test_dense_reduced_camera_matrix_and_cholesky(be, orc):
         yref = np.linalg.solve(Sref, rhs)
         assert np.abs(y - yref).max() <= 1e-8 * np.abs(yref).max(), (C, np.abs(y - yref).max(), np.abs(yref).max())
         assert np.abs(S @ y - rhs).max() <= 1e-9 * max(1.0, np.abs(rhs).max()) * np.linalg.cond(Sref) ** 0.5
+
+
+def _late_rank_worker(rank, world, port, q):
+    import time
+    import torch
+    import torch.distributed as td
+    import sfmba
+    from sfmba import dist as sdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pb = sfmba.make_problem(30, 600, 5000, seed=2)
+        shards = sdist.partition_points(pb.point_indices, pb.n_points, world)
+        loc = sdist.shard_problem(pb, shards[rank])
+        be = sfmba.Backend(0)
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            be.set_stream(stream.cuda_stream)
+            be.set_problem(*loc.args)
+            ex = sdist.Exchange(be, n_obs_local=loc.n_obs, device="cuda")
+            link = sdist.DirectLink(be)
+            assert link.active
+            opt = be.default_options()
+            opt.ftol = 1e-10
+            x_ok, res_ok, _, _ = be.solve(loc.x0, opt)             # a healthy solve first
+            td.barrier()
+            be.debug_option("p2p_timeout_ms", 300)                 # both time-outs of the direct all-reduce
+            if rank == 1:
+                be.debug_option("p2p_delay_ms", 1500)              # this rank enters its solve 1.5 s late
+            t0 = time.perf_counter()
+            err = None
+            try:
+                be.solve(loc.x0, opt)
+            except sfmba.BackendError as exc:
+                err = str(exc)
+            dt = time.perf_counter() - t0
+            be.debug_option("p2p_timeout_ms", 0)
+            be.debug_option("p2p_delay_ms", 0)
+            td.barrier()
+            # the direct link is gone after the failure; the callback transport registered before it still serves
+            x_again, res_again, _, _ = be.solve(loc.x0, opt)
+            torch.cuda.synchronize()
+        calls_after = ex.n_calls
+        q.put(dict(rank=rank, err=err, seconds=dt, cost_ok=float(res_ok.cost), cost_again=float(res_again.cost),
+                   same=bool(np.array_equal(x_ok[:180], x_again[:180])), callback_calls=calls_after))
+        td.barrier()
+        be.close()
+    finally:
+        td.destroy_process_group()
+
+
+def test_direct_allreduce_peer_late_beyond_timeout_fails_promptly_and_cleanly():
+    """a rank that enters a collective after its peers gave up must not make the others optimise on
+    stale sums until max_nfev.  With the time-out of the direct all-reduce at 0.3 s and rank 1 entering its solve
+    1.5 s late, BOTH ranks get error -5 (rank 0 from the hand-off that follows the timed-out collective, rank 1 once
+    it finds its peer gone), within seconds, without hanging or aborting; the handle then falls back to the
+    transport registered before the direct link and solves again with the same result."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_late_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = sorted((q.get(timeout=300) for _ in range(2)), key=lambda o: o["rank"])
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    for o in outs:
+        assert o["err"] is not None and "-5" in o["err"] and "timed out" in o["err"], o
+        assert o["seconds"] < 10.0, o
+        assert o["callback_calls"] > 10                      # the fallback transport carried the last solve
+        assert abs(o["cost_again"] - o["cost_ok"]) <= 1e-12 * o["cost_ok"] and o["same"]

@@ -6,7 +6,11 @@ import sfmba
 cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg4"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 bits = int(sys.argv[3]) if len(sys.argv) > 3 else 64
-pb = sfmba.make_config(cfg)
+if "," in cfg:                       # custom size "C,P,N" (e.g. one rank's share of a sharded problem)
+    C_, P_, N_ = (int(v) for v in cfg.split(","))
+    pb = sfmba.make_problem(C_, P_, N_, seed=0)
+else:
+    pb = sfmba.make_config(cfg)
 be = sfmba.Backend(0)
 be.set_precision(bits)
 be.set_problem(*pb.args)
