@@ -1191,7 +1191,15 @@ struct PcgFused {
     PcgCtrl* __restrict__ ctrl2;
     double tol;
     int max_iters;
+    // LOCAL form (one rank, every camera a single chunk): pass B's workgroup owns its camera, so the per-camera
+    // bookkeeping of the iteration (w = acc + Dc u, s, p, x, r, m = Minv s and the partial dot products
+    // w.u, s.u, s.m, r.u) runs THERE, once per camera, and the prologue of pass A only needs, for all cameras,
+    //     u_new = u - alpha m            (12 doubles per camera instead of 51, no 6x6 products)
+    // with alpha from the summed partials and gamma_new = gamma - 2 alpha (s.u) + alpha^2 (s.m), gamma = sum r.u
+    // being the TRUE value of the previous iterate (one recurrence step from an exact anchor: no drift).
+    double* __restrict__ part;           // [4][C] partial dot products of the cameras (null: not the local form)
 };
+constexpr int kPcgM = kPcgUcm;           // the local form keeps m = Minv s where the two-kernel form keeps its copy of u
 
 // The PCG update in the prologue of a fused pass-A launch (see PcgFused): returns false when the launch has
 // nothing more to do (the solve had finished or finishes here; grid-uniform).  Otherwise uu = the new u of
@@ -1222,6 +1230,68 @@ __device__ __forceinline__ bool pcg_fused_update(const PcgFused& pf, const doubl
             if (writer) *cout = ci;
             return false;
         }
+    }
+    if (pf.part != nullptr && L != 0) {
+        // ---- local form: iteration i = L - 1; its product and camera-side bookkeeping were done by pass B(L-1) ----
+        __shared__ double red4[16][4];
+        double q4[4] = {0.0, 0.0, 0.0, 0.0};
+        double ue[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, me[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        if (has) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q4[k] = pf.part[(size_t)k * C + cam];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const size_t e = (size_t)k * C + cam;
+                ue[k] = vold[kPcgU * n6 + e];
+                me[k] = pf.vecs[kPcgM * n6 + e];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q4[k] = wave_sum(q4[k]);
+        if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) red4[threadIdx.x >> 6][k] = q4[k];
+        }
+        __syncthreads();
+        double tot[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tot[k] += red4[w][k];
+        }
+        const double delta = tot[0], su = tot[1], sm = tot[2], gamma = tot[3];     // w.u, s.u, s.m, r.u (true gamma_i)
+        const double beta = ci.iters == 0 ? 0.0 : ci.rz / ci.rz_prev;             // the beta pass B built s and p with
+        const double den = delta - (ci.iters == 0 ? 0.0 : beta * gamma / ci.alpha_prev);
+        const double alpha = gamma / den;
+        if (!(den > 0.0) || !isfinite(alpha)) {                // S not SPD / NaN: x stays the last good iterate
+            if (writer) { PcgCtrl co = ci; co.done = 3; *cout = co; }
+            return false;
+        }
+        const double rz = gamma - 2.0 * alpha * su + alpha * alpha * sm;          // gamma_{i+1}
+        int done = 0;
+        if (!(rz > ci.tol2 * ci.rz0)) done = 1;               // also catches NaN and a cancelled-out (<= 0) value
+        else if (ci.iters + 1 >= ci.max_iters) done = 2;
+        if (writer) {
+            PcgCtrl co = ci;
+            co.rz_prev = gamma; co.alpha_prev = alpha; co.rz = rz; co.iters = ci.iters + 1; co.done = done;
+            *cout = co;
+        }
+        if (has) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) uu[k] = ue[k] - alpha * me[k];
+            if (own) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const size_t e = (size_t)k * C + cam;
+                    vnew[kPcgU * n6 + e] = uu[k];
+                    if (done != 0) {                          // the deferred x += alpha p of the last iteration (x is kept
+                        const double xk = pf.vecs[kPcgX * n6 + e] + alpha * pf.vecs[kPcgP * n6 + e];     // in both sets)
+                        pf.vecs[kPcgX * n6 + e] = xk;
+                        pf.vecs[(size_t)kPcgVecs * n6 + kPcgX * n6 + e] = xk;
+                    }
+                }
+            }
+        }
+        return done == 0;                                     // grid-uniform
     }
     if (has) {
 #pragma unroll
@@ -1594,18 +1664,45 @@ __global__ __launch_bounds__(kSweepThreads) void k_point_sweep_rc(
 //   ctrl_done: PCG control block whose `done` voids this launch (null: unconditional)
 //   set:       vector set holding u; < 0: take it from ctrl_done->iters (two-kernel PCG); vin then is the base of
 //              the sets.  ctrl_done == null: vin is the plane-major vector itself.
+// Local form of the fused PCG (PcgFused::part): what the workgroup of camera c does with its finished product.
+struct PcgLocal {
+    const double* __restrict__ Dc;
+    const double* __restrict__ Minv;
+    double* __restrict__ vecs;
+    double* __restrict__ part;           // null: not the local form
+};
+
 template <int MODE, bool ROUND>
 __global__ __launch_bounds__(kCamThreads) void k_cam_schur(CamMajor cm, const double* __restrict__ camtab,
                                                            const double* __restrict__ rec, KMat K,
                                                            const double* __restrict__ vin, int C,
                                                            double* __restrict__ acc, double* __restrict__ partial,
-                                                           const PcgCtrl* __restrict__ ctrl_done, int set) {
+                                                           const PcgCtrl* __restrict__ ctrl_done, int set, PcgLocal pl) {
     __shared__ double red[kCamWaves][6];
     if (ctrl_done != nullptr) {
         if (ctrl_done->done != 0) return;                       // grid-uniform
         if (MODE == 0) vin += (size_t)((set < 0 ? (ctrl_done->iters & 1) : set) * kPcgVecs + kPcgU) * 6 * C;
     }
     const int4 ch = cm.chunks[blockIdx.x];
+    // local form: the camera's own state, requested now by the six threads that will need it after the sweep
+    const bool local = MODE == 0 && pl.part != nullptr;
+    const size_t n6l = 6 * (size_t)C;
+    double l_u = 0.0, l_dc = 0.0, l_s = 0.0, l_p = 0.0, l_x = 0.0, l_r = 0.0, l_m[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    double l_rz = 0.0, l_rzp = 1.0, l_ap = 0.0;
+    int l_it = 0;
+    if (local && threadIdx.x < 6) {
+        const int k = threadIdx.x;
+        const size_t e = (size_t)k * C + ch.x;
+        l_u = vin[e]; l_dc = pl.Dc[e];
+        l_s = pl.vecs[kPcgS * n6l + e]; l_p = pl.vecs[kPcgP * n6l + e];
+        l_x = pl.vecs[kPcgX * n6l + e]; l_r = pl.vecs[kPcgR * n6l + e];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int a = k < j ? k : j, b = k < j ? j : k;
+            l_m[j] = pl.Minv[(size_t)(a * 6 - a * (a - 1) / 2 + (b - a)) * C + ch.x];     // row k of the packed upper triangle
+        }
+        l_rz = ctrl_done->rz; l_rzp = ctrl_done->rz_prev; l_ap = ctrl_done->alpha_prev; l_it = ctrl_done->iters;
+    }
     double t[kCamTab];
 #pragma unroll
     for (int k = 0; k < kCamTab; ++k) t[k] = camtab[(size_t)ch.x * kCamTab + k];      // wave-uniform: scalar loads
@@ -1716,6 +1813,38 @@ __global__ __launch_bounds__(kCamThreads) void k_cam_schur(CamMajor cm, const do
     if (threadIdx.x < 6) {
         if (ch.w == 1) acc[(size_t)threadIdx.x * C + ch.x] = out;
         else partial[(size_t)blockIdx.x * 6 + threadIdx.x] = out;
+    }
+    if (local) {                                            // (every camera is a single chunk in this form)
+        __shared__ double ts[6];
+        const int k = threadIdx.x;
+        double w = 0.0, sk = 0.0;
+        if (k < 6) {
+            const double beta = l_it == 0 ? 0.0 : l_rz / l_rzp;
+            w = out + l_dc * l_u;                           // (S u)_k
+            l_x += l_ap * l_p;                              // the deferred updates of the previous iteration
+            l_r -= l_ap * l_s;
+            sk = w + beta * l_s;
+            l_p = l_u + beta * l_p;
+            ts[k] = sk;
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {                             // wave 0: lanes 0..5 carry the camera, the others zeros
+            double mk = 0.0;
+            if (k < 6) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) mk += l_m[j] * ts[j];
+            }
+            const double d0 = wave_sum(k < 6 ? w * l_u : 0.0), d1 = wave_sum(k < 6 ? sk * l_u : 0.0);
+            const double d2 = wave_sum(k < 6 ? sk * mk : 0.0), d3 = wave_sum(k < 6 ? l_r * l_u : 0.0);
+            if (k < 6) {
+                const size_t e = (size_t)k * C + ch.x;
+                pl.vecs[kPcgS * n6l + e] = sk; pl.vecs[kPcgP * n6l + e] = l_p; pl.vecs[kPcgR * n6l + e] = l_r;
+                pl.vecs[kPcgM * n6l + e] = mk;
+                pl.vecs[kPcgX * n6l + e] = l_x;
+                pl.vecs[(size_t)kPcgVecs * n6l + kPcgX * n6l + e] = l_x;        // x lives in both sets (k_backsub)
+            }
+            if (k < 4) pl.part[(size_t)k * C + ch.x] = k == 0 ? d0 : (k == 1 ? d1 : (k == 2 ? d2 : d3));
+        }
     }
 }
 

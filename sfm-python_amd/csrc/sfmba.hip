@@ -227,6 +227,7 @@ struct sfmba_handle {
         int sweep_rc = -1;                   // 0: pass A reads the stored Jacobian although the recomputing form would fit
         int dense = -1;                      // 0: PCG although the dense reduced-camera path would apply
         int precond = -1;                    // 0: block-Jacobi preconditioner from U + Dc instead of the Schur diagonal
+        int pcg_local = -1;                  // 0: the fused PCG keeps its whole update in pass A's prologue
         int cam_chunk = 0;                   // > 0: chunk length of the camera-major kernels
         int pcg_guess_bias = 0;              // added to the number of speculatively enqueued PCG iterations
         int trace_pcg = 0, trace_stalls = 0, trace_timing = 0;   // stderr diagnostics
@@ -288,6 +289,8 @@ struct sfmba_handle {
     const double* skip = nullptr;         // device flag gating speculative trial launches (sfmba_solve); else null
     double pcg_tol = 0.0; int pcg_cap = 0; // options of the running PCG (fused launch 0 writes the control block)
     bool pcg_fused = false;               // PCG update fused into the launch of pass A (v in LDS, C <= 1024)
+    bool pcg_local = false;               // ... with the per-camera bookkeeping in pass B (one rank, single-chunk cameras)
+    DevBuf pcg_part;                      // [4][C] partial dot products of the local form
     int pcg_hint = 0;                     // largest PCG iteration count a solve on this handle has needed
     bool solved = false;
     std::vector<const void*> lds_ready;      // kernels already opted in to 160 KiB dynamic LDS
@@ -657,7 +660,7 @@ int launch_point_sweep(sfmba_handle* h, const double* vin, const PcgCtrl* ctrl2,
 int launch_pcg_fused(sfmba_handle* h, int L) {
     const int grid = (h->n_ranges + kWavesPerSweepBlock - 1) / kWavesPerSweepBlock;
     PcgFused pf{h->Dc.as<double>(), h->Minv.as<double>(), h->Ugc(), h->vecs.as<double>(), h->ctrl.as<PcgCtrl>(),
-                h->pcg_tol, h->pcg_cap};
+                h->pcg_tol, h->pcg_cap, h->pcg_local ? h->pcg_part.as<double>() : (double*)nullptr};
     if (h->sweep_rc) {
         const size_t lds_rc = sizeof(double) * kRcRow * (size_t)h->C;
         auto kern_rc = k_point_sweep_rc<true>;
@@ -683,15 +686,17 @@ int launch_pcg_fused(sfmba_handle* h, int L) {
 // Pass B (camera-major): MODE 0  acc = sum Jc^T (Jc v - Jp z) with z from pass A; MODE 1  acc = -sum Jc^T Jp e.
 // ctrl_done / set: see k_cam_schur.
 template <int MODE>
-int launch_cam_schur(sfmba_handle* h, const double* vin, const PcgCtrl* ctrl_done, int set) {
+int launch_cam_schur(sfmba_handle* h, const double* vin, const PcgCtrl* ctrl_done, int set, bool local = false) {
+    const PcgLocal pl{h->Dc.as<double>(), h->Minv.as<double>(), h->vecs.as<double>(),
+                      local ? h->pcg_part.as<double>() : (double*)nullptr};
     if (h->f32 && !h->sweep_rc)           // pass A applies the stored fp32 blocks: pass B rounds its own the same way
         hipLaunchKernelGGL((k_cam_schur<MODE, true>), dim3(h->n_chunks), dim3(kCamThreads), 0, h->stream, cam_major(h),
                            (const double*)h->tab, (const double*)h->rec, h->K, vin, (int)h->C, h->acc(),
-                           h->cam_partial.as<double>(), ctrl_done, set);
+                           h->cam_partial.as<double>(), ctrl_done, set, pl);
     else
         hipLaunchKernelGGL((k_cam_schur<MODE, false>), dim3(h->n_chunks), dim3(kCamThreads), 0, h->stream, cam_major(h),
                            (const double*)h->tab, (const double*)h->rec, h->K, vin, (int)h->C, h->acc(),
-                           h->cam_partial.as<double>(), ctrl_done, set);
+                           h->cam_partial.as<double>(), ctrl_done, set, pl);
     LAUNCHED(h);
     return launch_cam_combine(h, 6, h->acc(), 1, (int)h->C, nullptr, ctrl_done ? &ctrl_done->done : nullptr);
 }
@@ -917,6 +922,7 @@ int pcg_max_iters(const sfmba_handle* h, const sfmba_options& opt) {
 // x = 0, r = rhs, u = Minv r (acc holds the reduced right-hand side term of pass B, MODE 1)
 int pcg_start(sfmba_handle* h, const sfmba_options& opt) {
     h->pcg_L = 0;
+    h->pcg_local = h->pcg_fused && !multi_rank(h) && !h->cam_multi && h->dbg.pcg_local != 0;
     if (h->pcg_fused) {                   // launch 0 of the fused form initialises the solve itself
         h->pcg_tol = opt.pcg_tol;
         h->pcg_cap = pcg_max_iters(h, opt);
@@ -940,7 +946,7 @@ int pcg_enqueue(sfmba_handle* h, int count) {
             // a launch that found the solve finished (or finished it) produced no z: its control block (written
             // to slot (L+1)&1) says so, and pass B and the collective behind it are void as well
             const PcgCtrl* cd = ctrl2 + ((L + 1) & 1);
-            CHK(launch_cam_schur<0>(h, h->vecs.as<double>(), cd, L & 1));
+            CHK(launch_cam_schur<0>(h, h->vecs.as<double>(), cd, L & 1, h->pcg_local));
             CHK(exchange(h, h->acc(), 6 * h->C, 0, &cd->done));
             h->pcg_L = L + 1;
             continue;
@@ -1092,6 +1098,7 @@ int sfmba_debug_option(sfmba_handle* h, const char* name, int64_t value) {
     else if (n == "sweep_rc") h->dbg.sweep_rc = v;
     else if (n == "dense") h->dbg.dense = v;
     else if (n == "precond") h->dbg.precond = v;
+    else if (n == "pcg_local") h->dbg.pcg_local = v;
     else if (n == "tab_lds") h->dbg.tab_lds = v;
     else if (n == "vec_lds") h->dbg.vec_lds = v;
     else if (n == "cam_chunk") h->dbg.cam_chunk = v;
@@ -1605,6 +1612,7 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     h->red_grid = h->red_bc + grid_1d(3 * P, 256, 992);   // <= 1024 partial rows, summed by k_jdot's rider workgroup
     HIPCHK(h, h->part.ensure(sizeof(double) * (size_t)(2 * kPartRows * kNQ)));
     HIPCHK(h, h->ctrl.ensure(2 * sizeof(PcgCtrl)));
+    HIPCHK(h, h->pcg_part.ensure(sizeof(double) * 4 * C));
     HIPCHK(h, h->arena_own.ensure(sizeof(double) * (size_t)sfmba_exchange_doubles(C)));
     h->arena = h->arena_own.as<double>();
     h->ar_fn = nullptr; h->ar_ctx = nullptr;
