@@ -578,7 +578,7 @@ constexpr int kCamWaves = kCamThreads / 64;
 constexpr int kCamUnroll = 4;
 
 // sums of one workgroup: NV values per lane -> out[col] (thread col < NV holds the total afterwards)
-template <int NV>
+template <int NV, int NW = kCamWaves>
 __device__ __forceinline__ double cam_block_total(double (&a)[NV], double (*red)[NV]) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
@@ -591,7 +591,7 @@ __device__ __forceinline__ double cam_block_total(double (&a)[NV], double (*red)
     double s = 0.0;
     if ((int)threadIdx.x < NV) {
 #pragma unroll
-        for (int k = 0; k < kCamWaves; ++k) s += red[k][threadIdx.x];      // fixed order
+        for (int k = 0; k < NW; ++k) s += red[k][threadIdx.x];            // fixed order
     }
     return s;
 }
@@ -613,27 +613,29 @@ __global__ __launch_bounds__(kCamThreads) void k_cam_blocks(CamMajor cm, const d
     double a[27];
 #pragma unroll
     for (int q = 0; q < 27; ++q) a[q] = 0.0;
-    // kCamUnroll observations per lane and trip, all index loads first, then all gathers: a camera of ~1000
-    // observations is one trip, whose latency is one index round trip plus one gather round trip
-    for (int k0 = ch.y + (int)threadIdx.x; k0 < ch.z; k0 += kCamThreads * kCamUnroll) {
-        int p[kCamUnroll];
-        double2 uv[kCamUnroll];
-        double X[kCamUnroll][3];
+    // kU observations per lane and trip, all index loads first, then all gathers (kU = 2 here: with 27 sums in
+    // registers a deeper unroll pushes the kernel past 128 VGPRs, i.e. below four workgroups per CU, and 1000
+    // camera workgroups then take two rounds)
+    constexpr int kU = 2;
+    for (int k0 = ch.y + (int)threadIdx.x; k0 < ch.z; k0 += kCamThreads * kU) {
+        int p[kU];
+        double2 uv[kU];
+        double X[kU][3];
 #pragma unroll
-        for (int u = 0; u < kCamUnroll; ++u) {
+        for (int u = 0; u < kU; ++u) {
             const int k = k0 + u * kCamThreads;
             p[u] = -1;
             uv[u] = make_double2(0.0, 0.0);
             if (k < ch.z) { p[u] = cm.pt[k]; uv[u] = load_pair(cm.uv, F32, k); }
         }
 #pragma unroll
-        for (int u = 0; u < kCamUnroll; ++u) {            // two 16-byte loads of the point's record: X Y | Z .
+        for (int u = 0; u < kU; ++u) {                    // two 16-byte loads of the point's record: X Y | Z .
             const double2* __restrict__ rp = reinterpret_cast<const double2*>(rec + (size_t)kRec * (p[u] < 0 ? 0 : p[u]));
             const double2 xy = rp[0], zz = rp[1];
             X[u][0] = xy.x; X[u][1] = xy.y; X[u][2] = zz.x;
         }
 #pragma unroll
-        for (int u = 0; u < kCamUnroll; ++u) {
+        for (int u = 0; u < kU; ++u) {
             if (p[u] < 0) continue;
             double jc[12], jp[6], rx, ry;
             observe<true>(t, X[u][0], X[u][1], X[u][2], uv[u].x, uv[u].y, K, rx, ry, jc, jp);
@@ -1684,25 +1686,8 @@ __global__ __launch_bounds__(kCamThreads) void k_cam_schur(CamMajor cm, const do
         if (MODE == 0) vin += (size_t)((set < 0 ? (ctrl_done->iters & 1) : set) * kPcgVecs + kPcgU) * 6 * C;
     }
     const int4 ch = cm.chunks[blockIdx.x];
-    // local form: the camera's own state, requested now by the six threads that will need it after the sweep
-    const bool local = MODE == 0 && pl.part != nullptr;
+    const bool local = MODE == 0 && pl.part != nullptr;     // local form of the fused PCG (see PcgLocal)
     const size_t n6l = 6 * (size_t)C;
-    double l_u = 0.0, l_dc = 0.0, l_s = 0.0, l_p = 0.0, l_x = 0.0, l_r = 0.0, l_m[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    double l_rz = 0.0, l_rzp = 1.0, l_ap = 0.0;
-    int l_it = 0;
-    if (local && threadIdx.x < 6) {
-        const int k = threadIdx.x;
-        const size_t e = (size_t)k * C + ch.x;
-        l_u = vin[e]; l_dc = pl.Dc[e];
-        l_s = pl.vecs[kPcgS * n6l + e]; l_p = pl.vecs[kPcgP * n6l + e];
-        l_x = pl.vecs[kPcgX * n6l + e]; l_r = pl.vecs[kPcgR * n6l + e];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const int a = k < j ? k : j, b = k < j ? j : k;
-            l_m[j] = pl.Minv[(size_t)(a * 6 - a * (a - 1) / 2 + (b - a)) * C + ch.x];     // row k of the packed upper triangle
-        }
-        l_rz = ctrl_done->rz; l_rzp = ctrl_done->rz_prev; l_ap = ctrl_done->alpha_prev; l_it = ctrl_done->iters;
-    }
     double t[kCamTab];
 #pragma unroll
     for (int k = 0; k < kCamTab; ++k) t[k] = camtab[(size_t)ch.x * kCamTab + k];      // wave-uniform: scalar loads
@@ -1792,6 +1777,24 @@ __global__ __launch_bounds__(kCamThreads) void k_cam_schur(CamMajor cm, const do
             }
         }
     }
+    // local form: the camera's own state, requested by the six threads that need it behind the reduction (after
+    // the sweep, so that it does not occupy registers across it: the kernel has to stay at four workgroups per CU)
+    double l_u = 0.0, l_dc = 0.0, l_s = 0.0, l_p = 0.0, l_x = 0.0, l_r = 0.0, l_m[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    double l_rz = 0.0, l_rzp = 1.0, l_ap = 0.0;
+    int l_it = 0;
+    if (local && threadIdx.x < 6) {
+        const int k = threadIdx.x;
+        const size_t e = (size_t)k * C + ch.x;
+        l_u = vin[e]; l_dc = pl.Dc[e];
+        l_s = pl.vecs[kPcgS * n6l + e]; l_p = pl.vecs[kPcgP * n6l + e];
+        l_x = pl.vecs[kPcgX * n6l + e]; l_r = pl.vecs[kPcgR * n6l + e];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int a_ = k < j ? k : j, b_ = k < j ? j : k;
+            l_m[j] = pl.Minv[(size_t)(a_ * 6 - a_ * (a_ - 1) / 2 + (b_ - a_)) * C + ch.x];     // row k of the packed upper triangle
+        }
+        l_rz = ctrl_done->rz; l_rzp = ctrl_done->rz_prev; l_ap = ctrl_done->alpha_prev; l_it = ctrl_done->iters;
+    }
     const double s = cam_block_total<6>(a, red);
     double out = s;
     if (!ROUND) {                                        // rotation Jacobian applied to the summed M (see above)
@@ -1853,12 +1856,15 @@ __global__ __launch_bounds__(kCamThreads) void k_cam_schur(CamMajor cm, const do
 // out[6..26] = sum_i W_i Vinv_p W_i^T  (packed upper triangle), W_i = Jc_i^T Jp_i.  Every W_i is formed anyway for the
 // first sum; the second costs one more gathered row per observation (Vinv_p, 48 bytes) and no pass of its own.
 // Output plane-major [27][C] (acc | sd: one contiguous vector for the all-reduce) or partial[chunk][27].
+// 192-thread workgroups: the kernel needs ~150 VGPRs (three waves per SIMD), and four 3-wave workgroups per CU keep
+// 1024 camera workgroups resident at once where three 4-wave ones would take a 1000-camera problem in two rounds.
+constexpr int kRhsThreads = 192;
 template <bool ROUND>
-__global__ __launch_bounds__(kCamThreads) void k_cam_rhs_diag(CamMajor cm, const double* __restrict__ camtab,
+__global__ __launch_bounds__(kRhsThreads) void k_cam_rhs_diag(CamMajor cm, const double* __restrict__ camtab,
                                                               const double* __restrict__ rec,
                                                               const double* __restrict__ Vinv, KMat K, int C,
                                                               double* __restrict__ out, double* __restrict__ partial) {
-    __shared__ double red[kCamWaves][27];
+    __shared__ double red[kRhsThreads / 64][27];
     const int4 ch = cm.chunks[blockIdx.x];
     double t[kCamTab];
 #pragma unroll
@@ -1866,13 +1872,13 @@ __global__ __launch_bounds__(kCamThreads) void k_cam_rhs_diag(CamMajor cm, const
     double a[27];
 #pragma unroll
     for (int q = 0; q < 27; ++q) a[q] = 0.0;
-    constexpr int kU = 2;                          // 27 accumulators: two observations in flight per lane
-    for (int k0 = ch.y + (int)threadIdx.x; k0 < ch.z; k0 += kCamThreads * kU) {
+    constexpr int kU = 1;                          // 27 sums + a 6x3 block pair per observation: no room to unroll
+    for (int k0 = ch.y + (int)threadIdx.x; k0 < ch.z; k0 += kRhsThreads * kU) {
         int p[kU];
         double X[kU][3], e[kU][3], vi[kU][6];
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
-            const int k = k0 + u * kCamThreads;
+            const int k = k0 + u * kRhsThreads;
             p[u] = k < ch.z ? cm.pt[k] : -1;
         }
 #pragma unroll
@@ -1915,7 +1921,7 @@ __global__ __launch_bounds__(kCamThreads) void k_cam_rhs_diag(CamMajor cm, const
                 for (int j = i; j < 6; ++j) a[n++] += Y[i][0] * W[j][0] + Y[i][1] * W[j][1] + Y[i][2] * W[j][2];
         }
     }
-    const double s = cam_block_total<27>(a, red);
+    const double s = cam_block_total<27, kRhsThreads / 64>(a, red);
     if (threadIdx.x < 27) {
         if (ch.w == 1) out[(size_t)threadIdx.x * C + ch.x] = s;
         else partial[(size_t)blockIdx.x * 27 + threadIdx.x] = s;

@@ -711,11 +711,11 @@ int launch_rhs_and_preconditioner(sfmba_handle* h) {
         return exchange(h, h->acc(), 6 * C, 0);
     }
     if (h->f32 && !h->sweep_rc)
-        hipLaunchKernelGGL((k_cam_rhs_diag<true>), dim3(h->n_chunks), dim3(kCamThreads), 0, h->stream, cam_major(h),
+        hipLaunchKernelGGL((k_cam_rhs_diag<true>), dim3(h->n_chunks), dim3(kRhsThreads), 0, h->stream, cam_major(h),
                            (const double*)h->tab, (const double*)h->rec, (const double*)h->Vinv.as<double>(), h->K, (int)C,
                            h->acc(), h->cam_partial.as<double>());
     else
-        hipLaunchKernelGGL((k_cam_rhs_diag<false>), dim3(h->n_chunks), dim3(kCamThreads), 0, h->stream, cam_major(h),
+        hipLaunchKernelGGL((k_cam_rhs_diag<false>), dim3(h->n_chunks), dim3(kRhsThreads), 0, h->stream, cam_major(h),
                            (const double*)h->tab, (const double*)h->rec, (const double*)h->Vinv.as<double>(), h->K, (int)C,
                            h->acc(), h->cam_partial.as<double>());
     LAUNCHED(h);
