@@ -701,14 +701,21 @@ struct StepTable {
 
 // K2: V_p = sum Jp^T Jp (6, packed upper triangle), g_p = sum Jp^T r (3), recomputed from the camera table
 // and the point like K1 does (20 B per observation of indices and pixels instead of 64 B of stored blocks,
-// and exact fp64 in fp32-storage mode too).  One LANE per point: the lane walks its point's run and keeps the
-// nine sums in registers, so there is no cross-lane reduction at all (the wave-segmented form spent most of its
-// time in the DPP / v_readlane reduction of nine doubles per step).  The trip count of a wave is its longest run;
-// runs longer than kLongRun are left out of the per-lane walk and summed by the whole wave afterwards.
-// d r / d X and r need R and T only: the compact view of the camera table (rows of 96 bytes, 16-byte aligned),
-// staged in LDS when it fits (LDS_TAB), gathered with six 16-byte loads otherwise.
-constexpr int kPointBlockThreads = 512;
-constexpr int kLongRun = 64;
+// and exact fp64 in fp32-storage mode too).  FOUR LANES per point: the quad walks its point's run four
+// observations at a time (64 contiguous bytes of pixels per quad and trip) and keeps the nine sums in registers;
+// the only cross-lane work is two quad-permute steps at the end (the wave-segmented form spent two thirds of its
+// time in the DPP / v_readlane reduction of nine doubles per step; one lane per point halved that but thrashed
+// the L1 with 64 strided walks per wave).  The trip count of a wave is its longest run / 4; runs longer than
+// kLongRun are left out of the quad walk and summed by the whole wave afterwards.  Persistent workgroups stage
+// the compact R | T view of the camera table (rows of 96 bytes) in LDS once and loop over groups of 128 points;
+// when the table does not fit (LDS_TAB = false) its rows are gathered with six 16-byte loads.
+constexpr int kPointBlockThreads = 1024;
+constexpr int kLongRun = 256;
+__device__ __forceinline__ double quad_sum(double v) {        // sum over the four lanes of a quad, on every lane
+    v += dpp_double<0xB1>(v);                                  // quad_perm [1,0,3,2]
+    v += dpp_double<0x4E>(v);                                  // quad_perm [2,3,0,1]
+    return v;
+}
 template <bool LDS_TAB, bool F32>
 __global__ __launch_bounds__(kPointBlockThreads) void k_point_blocks(
     const int* __restrict__ pt_ptr, const int* __restrict__ cam_idx, const double* __restrict__ uv,
@@ -716,17 +723,10 @@ __global__ __launch_bounds__(kPointBlockThreads) void k_point_blocks(
     double* __restrict__ V, double* __restrict__ gp, const double* __restrict__ skip) {
     extern __shared__ __align__(16) double smem[];
     if (skip != nullptr && *skip != 0.0) return;   // speculative launch cancelled by k_tr_step
-    const int lane = threadIdx.x & 63;
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    int b = 0, e = 0;
-    double X = 0.0, Y = 0.0, Z = 0.0;
-    if (p < P) {
-        b = pt_ptr[p]; e = pt_ptr[p + 1];
-        const double* __restrict__ Xp = pts + 3 * (size_t)p;
-        X = Xp[0]; Y = Xp[1]; Z = Xp[2];
-    }
+    const int lane = threadIdx.x & 63, sub = threadIdx.x & 3;
+    const int per_block = blockDim.x >> 2;                      // points per workgroup and trip
     const double* __restrict__ rt = camtab + cam_rt_offset(C);
-    if (LDS_TAB) {                               // stage the table while those loads fly
+    if (LDS_TAB) {
         const int n2 = (C * kCamRT) >> 1;
         const double2* __restrict__ src = reinterpret_cast<const double2*>(rt);
         double2* __restrict__ dst = reinterpret_cast<double2*>(smem);
@@ -748,49 +748,60 @@ __global__ __launch_bounds__(kPointBlockThreads) void k_point_blocks(
         v[4] += jp[1] * jp[2] + jp[4] * jp[5]; v[5] += jp[2] * jp[2] + jp[5] * jp[5];
         v[6] += jp[0] * rx + jp[3] * ry; v[7] += jp[1] * rx + jp[4] * ry; v[8] += jp[2] * rx + jp[5] * ry;
     };
-    const int len = e - b;
-    const bool is_long = len > kLongRun;
-    double v[9];
+    for (int base = blockIdx.x * per_block; base < P; base += gridDim.x * per_block) {
+        const int p = base + ((int)threadIdx.x >> 2);
+        int b = 0, e = 0;
+        double X = 0.0, Y = 0.0, Z = 0.0;
+        if (p < P) {
+            b = pt_ptr[p]; e = pt_ptr[p + 1];
+            const double* __restrict__ Xp = pts + 3 * (size_t)p;
+            X = Xp[0]; Y = Xp[1]; Z = Xp[2];
+        }
+        const bool is_long = e - b > kLongRun;
+        double v[9];
 #pragma unroll
-    for (int q = 0; q < 9; ++q) v[q] = 0.0;
-    // the next observation's index and pixel are requested while this one computes
-    int i = b;
-    bool on = !is_long && i < e;
-    int c = 0;
-    double2 px = make_double2(0.0, 0.0);
-    if (on) { c = cam_idx[i]; px = load_pair(uv, F32, i); }
-    while (__ballot(on) != 0ull) {
-        const int in_ = i + 1;
-        const bool on_n = on && in_ < e;
-        int cn = 0;
-        double2 pxn = make_double2(0.0, 0.0);
-        if (on_n) { cn = cam_idx[in_]; pxn = load_pair(uv, F32, in_); }
-        if (on) add_terms(c, X, Y, Z, px, v);
-        i = in_; on = on_n; c = cn; px = pxn;
-    }
-    if (p < P && !is_long) {                      // a point without observations gets its zeros here
+        for (int q = 0; q < 9; ++q) v[q] = 0.0;
+        // the next observation's index and pixel are requested while this one computes
+        int i = b + sub;
+        bool on = !is_long && i < e;
+        int c = 0;
+        double2 px = make_double2(0.0, 0.0);
+        if (on) { c = cam_idx[i]; px = load_pair(uv, F32, i); }
+        while (__ballot(on) != 0ull) {
+            const int in_ = i + 4;
+            const bool on_n = on && in_ < e;
+            int cn = 0;
+            double2 pxn = make_double2(0.0, 0.0);
+            if (on_n) { cn = cam_idx[in_]; pxn = load_pair(uv, F32, in_); }
+            if (on) add_terms(c, X, Y, Z, px, v);
+            i = in_; on = on_n; c = cn; px = pxn;
+        }
 #pragma unroll
-        for (int q = 0; q < 6; ++q) V[(size_t)p * 6 + q] = v[q];
+        for (int q = 0; q < 9; ++q) v[q] = quad_sum(v[q]);
+        if (p < P && !is_long && sub == 0) {          // a point without observations gets its zeros here
 #pragma unroll
-        for (int q = 0; q < 3; ++q) gp[(size_t)p * 3 + q] = v[6 + q];
-    }
-    unsigned long long todo = __ballot(is_long);  // long runs: the whole wave sums one point at a time
-    while (todo != 0ull) {
-        const int l = __ffsll((long long)todo) - 1;
-        todo &= todo - 1ull;
-        const int pp = __shfl(p, l), bb = __shfl(b, l), ee = __shfl(e, l);
-        const double xl = __shfl(X, l), yl = __shfl(Y, l), zl = __shfl(Z, l);
-        double w[9];
+            for (int q = 0; q < 6; ++q) V[(size_t)p * 6 + q] = v[q];
 #pragma unroll
-        for (int q = 0; q < 9; ++q) w[q] = 0.0;
-        for (int j = bb + lane; j < ee; j += 64) add_terms(cam_idx[j], xl, yl, zl, load_pair(uv, F32, j), w);
+            for (int q = 0; q < 3; ++q) gp[(size_t)p * 3 + q] = v[6 + q];
+        }
+        unsigned long long todo = __ballot(is_long && sub == 0);   // long runs: the whole wave sums one point at a time
+        while (todo != 0ull) {
+            const int l = __ffsll((long long)todo) - 1;
+            todo &= todo - 1ull;
+            const int pp = __shfl(p, l), bb = __shfl(b, l), ee = __shfl(e, l);
+            const double xl = __shfl(X, l), yl = __shfl(Y, l), zl = __shfl(Z, l);
+            double w[9];
 #pragma unroll
-        for (int q = 0; q < 9; ++q) w[q] = wave_sum(w[q]);
-        if (lane == 0) {
+            for (int q = 0; q < 9; ++q) w[q] = 0.0;
+            for (int j = bb + lane; j < ee; j += 64) add_terms(cam_idx[j], xl, yl, zl, load_pair(uv, F32, j), w);
 #pragma unroll
-            for (int q = 0; q < 6; ++q) V[(size_t)pp * 6 + q] = w[q];
+            for (int q = 0; q < 9; ++q) w[q] = wave_sum(w[q]);
+            if (lane == 0) {
 #pragma unroll
-            for (int q = 0; q < 3; ++q) gp[(size_t)pp * 3 + q] = w[6 + q];
+                for (int q = 0; q < 6; ++q) V[(size_t)pp * 6 + q] = w[q];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) gp[(size_t)pp * 3 + q] = w[6 + q];
+            }
         }
     }
 }

@@ -599,11 +599,14 @@ int launch_cam_combine(sfmba_handle* h, int ncols, double* out, int cs, int ks, 
 template <bool F32>
 int launch_normal_blocks_v(sfmba_handle* h, const double* x, const double* tab, const double* rec) {
     const double* pts = x + 6 * h->C;
-    // one lane per point; workgroups of 64 ... 512 threads, sized so that a small cloud still covers the chip
-    const int threads = (int)std::min<int64_t>(kPointBlockThreads, std::max<int64_t>(64, (h->P / h->n_cu + 63) / 64 * 64));
-    const int grid = (int)((h->P + threads - 1) / threads);
+    // four lanes per point; persistent workgroups of 64 ... 512 threads (16 ... 128 points per trip), at most one
+    // per CU (each stages the compact camera table once), sized so that a small cloud still covers the chip
+    const int64_t lanes = 4 * h->P;
+    const int threads = (int)std::min<int64_t>(kPointBlockThreads, std::max<int64_t>(64, (lanes / h->n_cu + 63) / 64 * 64));
     const size_t lds = (size_t)h->C * kCamRT * sizeof(double);
-    if (lds <= kLdsDynMax && h->dbg.tab_lds != 0) {
+    const bool tab_in_lds = lds <= kLdsDynMax && h->dbg.tab_lds != 0;
+    const int grid = (int)std::min<int64_t>((tab_in_lds ? 1 : 4) * (int64_t)h->n_cu, (lanes + threads - 1) / threads);
+    if (tab_in_lds) {
         auto kern = k_point_blocks<true, F32>;
         CHK(set_lds(h, kern, lds));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, h->stream, (const int*)h->pt_ptr.as<int>(),
