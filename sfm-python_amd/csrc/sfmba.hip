@@ -292,6 +292,10 @@ struct sfmba_handle {
     bool pcg_local = false;               // ... with the per-camera bookkeeping in pass B (one rank, single-chunk cameras)
     DevBuf pcg_part;                      // [4][C] partial dot products of the local form
     int pcg_hint = 0;                     // largest PCG iteration count a solve on this handle has needed
+    std::vector<int> pcg_hist;            // PCG iterations of outer iteration k in the previous solve on this handle: the
+                                          // reference solves a slightly grown problem from a nearby start call after
+                                          // call (sfm.py:59-71), and the counts repeat; with a record the speculative
+                                          // batch is that count (+1 launch for the fused update), without the spare
     bool solved = false;
     std::vector<const void*> lds_ready;      // kernels already opted in to 160 KiB dynamic LDS
     int last_pcg_iters = 0;
@@ -1970,6 +1974,9 @@ static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt
     double step_norm = 0.0, actual_reduction = 0.0, g_norm = 0.0, reg_term = 0.0;
     bool have_red = false;
     int pcg_guess = h->pcg_hint;                                // iterations to enqueue without reading back
+    std::vector<int> pcg_hist_new;
+    bool guess_exact = false;                                   // pcg_guess comes from the record: no spare launch
+    if (!h->pcg_hist.empty() && h->pcg_hist[0] > 0) { pcg_guess = h->pcg_hist[0]; guess_exact = true; }
     int64_t pcg_breakdowns = 0;
     bool nb_valid = true;                                       // V, g_p, [U|g_c] (and, single-buffered, J and r) belong to h->x
     // Single-buffered Jacobian: the trial point is evaluated into the SAME J / r buffers the sweeps of
@@ -2032,7 +2039,7 @@ static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt
         } else if (pcg_guess > 0) {
             // speculative: no read-back; surplus launches are no-ops.  Fused launches apply the update of
             // iteration k in launch k + 1, so k iterations need k + 1 launches; one spare either way.
-            CHK(pcg_enqueue(h, pcg_guess + (h->pcg_fused ? 2 : 1)));
+            CHK(pcg_enqueue(h, pcg_guess + (h->pcg_fused ? 1 : 0) + (guess_exact ? 0 : 1)));
         } else {
             CHK(pcg_finish_polling(h, opt, &hc));
         }
@@ -2104,6 +2111,7 @@ static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt
             return 0;
         };
         const bool speculated = pcg_guess > 0 || dense;         // dense: the control block always says "finished"
+        const int pcg_enqueued = pcg_guess > 0 ? pcg_guess + (h->pcg_fused ? 1 : 0) + (guess_exact ? 0 : 1) : 0;
         bool missed = false;
         for (bool speculative = speculated;;) {
             hipLaunchKernelGGL(k_tr_step, dim3(1), dim3(one_rank ? 1024 : 64), 0, h->stream, sc, Delta,
@@ -2146,11 +2154,16 @@ static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt
         pcg_total += hc.iters;
         if (pcg_debug)
             fprintf(stderr, "sfmba: iteration %lld: PCG enqueued %d, needed %d%s\n", (long long)iteration,
-                    speculated ? pcg_guess + (h->pcg_fused ? 2 : 1) : 0, hc.iters, missed ? " (miss)" : "");
+                    pcg_enqueued, hc.iters, missed ? " (miss)" : "");
         // Next guess: the largest recent count, forgotten by one iteration per outer iteration.  A surplus
         // iteration costs two empty launches (~10 us); a miss costs a hand-off per polled batch.
         h->pcg_hint = std::max(hc.iters, h->pcg_hint - 1);
-        pcg_guess = std::max(1, h->pcg_hint + pcg_bias);
+        pcg_hist_new.push_back(hc.iters);
+        {
+            const int rec = (iteration + 1 < (int64_t)h->pcg_hist.size()) ? h->pcg_hist[iteration + 1] : 0;
+            guess_exact = rec > 0 && pcg_bias == 0;
+            pcg_guess = std::max(1, (guess_exact ? rec : h->pcg_hint) + pcg_bias);
+        }
         reg_term = h->h_scal[kRegSlot];
 
         const double x_norm = std::sqrt(qsum(h, 3));
@@ -2239,6 +2252,7 @@ static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt
         out->resjac_avg_us = 1e3 * tot / (double)evs.size();
         out->resjac_launches = (int64_t)evs.size();
     }
+    h->pcg_hist.swap(pcg_hist_new);
     out->cost = cost;
     out->optimality = g_norm;
     out->rmse = std::sqrt(2.0 * cost / m_total);
