@@ -48,11 +48,11 @@ typedef struct sfmba_options {
     int32_t verbose;       /* 0 silent, 1 summary (printed by the host shim), 2 iteration table  */
     int32_t max_iter;      /* <=0: unlimited; otherwise stop after this many outer iterations    */
     double  pcg_tol;       /* forcing term of the inexact step: the Schur PCG stops when the
-                              preconditioned residual norm has dropped by this factor (default 1e-3;
+                              preconditioned residual norm has dropped by this factor (default 1e-2;
                               see DESIGN.md section 3 for how this compares with scipy's LSMR)        */
     int32_t pcg_max_iter;  /* <=0: 2 * 6 * n_cameras                                             */
     int32_t pcg_check_every; /* host polls the device-side convergence flag every k iterations   */
-    double  reg_min;       /* floor of the Levenberg-Marquardt term (1e-10), see DESIGN.md        */
+    double  reg_min;       /* floor of the Levenberg-Marquardt term (1e-6), see DESIGN.md         */
     int32_t profile;       /* 1: bracket every residual+Jacobian launch with HIP events          */
     int32_t reserved;
 } sfmba_options;

@@ -401,7 +401,7 @@ class TRFResult:
 
 def trf_schur(x0, n_cameras, n_points, camera_indices, point_indices, points_2d, K,
               ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None, linear="dense",
-              pcg_tol=1e-10, precond="block_u", reg_min=1e-10, verbose=0, comm=None):
+              pcg_tol=1e-10, precond="block_u", reg_min=1e-6, verbose=0, comm=None):
     """Restatement of trf_no_bounds(tr_solver='lsmr', x_scale='jac', loss='linear').
 
     Line references are to SCIPY/optimize/_lsq/trf.py.  Difference from scipy: gn_h of trf.py:480

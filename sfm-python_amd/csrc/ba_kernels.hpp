@@ -218,6 +218,40 @@ __device__ __forceinline__ void seg_reduce(double (&v)[NV], int key, int lane) {
     }
 }
 
+// The same reduction value by value (all seven steps of v[0], then v[1], ...) with the lane masks computed once:
+// a kernel that carries a software pipeline across the reduction cannot afford the registers of NV interleaved
+// chains (k_resjac spilled 100 dwords per lane with seg_reduce<9>).
+template <int NV>
+__device__ __forceinline__ void seg_reduce_serial(double (&v)[NV], int key, int lane) {
+    constexpr int kRowShl = 0x100;
+    const int col = lane & 15, row = lane >> 4;
+    // (the cross-lane reads first and unconditionally: inside the short-circuit of `&&` they would run under a
+    // partial EXEC mask, and a DPP read of a disabled lane returns 0)
+    const int n1 = dpp_int<kRowShl + 1>(key), n2 = dpp_int<kRowShl + 2>(key);
+    const int n4 = dpp_int<kRowShl + 4>(key), n8 = dpp_int<kRowShl + 8>(key);
+    const int f48 = __builtin_amdgcn_readlane(key, 48), f32 = __builtin_amdgcn_readlane(key, 32);
+    const int f16 = __builtin_amdgcn_readlane(key, 16);
+    // the masks as factors 1.0 / 0.0: "add when the key matches" is then one FMA per step instead of an add and two
+    // selects (a non-finite neighbour would leak through 0 * inf; a non-finite block fails the evaluation anyway)
+    const double m1 = ((col + 1 < 16) & (n1 == key)) ? 1.0 : 0.0, m2 = ((col + 2 < 16) & (n2 == key)) ? 1.0 : 0.0;
+    const double m4 = ((col + 4 < 16) & (n4 == key)) ? 1.0 : 0.0, m8 = ((col + 8 < 16) & (n8 == key)) ? 1.0 : 0.0;
+    const double r2 = ((row == 2) & (key == f48)) ? 1.0 : 0.0, r1 = ((row == 1) & (key == f32)) ? 1.0 : 0.0;
+    const double r0 = ((row == 0) & (key == f16)) ? 1.0 : 0.0;
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+        double x = v[n];
+        x = fma(dpp_double<kRowShl + 1>(x), m1, x);
+        x = fma(dpp_double<kRowShl + 2>(x), m2, x);
+        x = fma(dpp_double<kRowShl + 4>(x), m4, x);
+        x = fma(dpp_double<kRowShl + 8>(x), m8, x);
+        x = fma(readlane_double(x, 48), r2, x);
+        x = fma(readlane_double(x, 32), r1, x);
+        x = fma(readlane_double(x, 16), r0, x);
+        v[n] = x;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // fp32-STORAGE mode (BASELINE config 5): uv, r, t1 and the compact Jacobian are kept as floats, all
 // arithmetic and every accumulation stays fp64.  The Jacobian tile of 64 observations is then three
 // float4 planes: (w0 w1 w2 w0') (w1' w2' X0 X1) (X2 X0' X1' X2')  -- 48 B per observation.
@@ -419,16 +453,34 @@ __device__ __forceinline__ void st16(double* __restrict__ p, double a, double b)
     *reinterpret_cast<double2*>(p) = make_double2(a, b);
 }
 
+// Point blocks ride along (pb.V != null): V_p = sum Jp^T Jp (6, packed upper triangle) and g_p = sum Jp^T r (3) are
+// sums over the point's run of observations, and the lanes of a wave hold 64 consecutive observations of the
+// point-major order with Jp and r in registers.  The nine products are reduced over the runs inside the wave
+// (seg_reduce; the kernel is HBM-write bound, the VALU has the time) and the first lane of every run that lies
+// inside the tile stores the point's row.  A run cut by a tile boundary leaves its pieces in edge[tile][0] (the
+// run that continues from the previous tile) and edge[tile][1] (the run that continues into the next one);
+// point_edge_fixup, riding with the camera pass that follows, adds the pieces in tile order.  No atomics; a
+// separate kernel (round 2: k_point_blocks, 19 us at 1M observations) re-read the indices and pixels and
+// recomputed every block.  Points without observations keep the zeros set_problem wrote.
+constexpr int kEdgeRow = 10;                     // 9 sums, padded to a multiple of 16 bytes
+struct PointBlocksOut {
+    double* __restrict__ V;                      // [P][6]; null: no block sums
+    double* __restrict__ gp;                     // [P][3]
+    double* __restrict__ edge;                   // [tiles][2][kEdgeRow]
+};
+
 template <bool LDS_TAB, bool JAC, bool STORE_R, bool F32>
 __global__ __launch_bounds__(kSweepThreads) void k_resjac(
     const double* __restrict__ camtab, const double* __restrict__ pts, const int* __restrict__ cam_idx,
     const int* __restrict__ pt_idx, const double* __restrict__ uv, double* __restrict__ r,
     double* __restrict__ J, int N, int64_t ld, int C, KMat K,
-    double* __restrict__ cost_part, const double* __restrict__ skip) {
+    double* __restrict__ cost_part, const double* __restrict__ skip, PointBlocksOut pb) {
     extern __shared__ __align__(16) double smem[];
     __shared__ double red[kWavesPerSweepBlock];
     if (skip != nullptr && *skip != 0.0) return;   // speculative launch cancelled by k_tr_step
     const int stride = gridDim.x * blockDim.x;
+    const int lane = threadIdx.x & 63;
+    const bool blocks = JAC && pb.V != nullptr;    // grid-uniform
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     // pipeline registers: batch i (uv, X ready), batch i+stride (indices ready)
     int c0 = 0, p0 = 0, c1 = 0, p1 = 0;
@@ -447,7 +499,8 @@ __global__ __launch_bounds__(kSweepThreads) void k_resjac(
     }
     const double* __restrict__ tab = LDS_TAB ? smem : camtab;
     double acc = 0.0;
-    while (i < N) {
+    while (i - lane < N) {                       // wave-uniform: the segmented reduction needs all 64 lanes
+        const bool on = i < N;
         // issue the next batch's loads first
         const int in = i + stride, in2 = in + stride;
         int c2 = 0, p2 = 0;
@@ -459,25 +512,66 @@ __global__ __launch_bounds__(kSweepThreads) void k_resjac(
             const double* __restrict__ Xp = pts + 3 * (size_t)p1;
             X1 = Xp[0]; Y1 = Xp[1]; Z1 = Xp[2];
         }
+        // the points either side of the tile (wave-uniform addresses): does a run continue across its boundaries?
+        const int ib = i - lane;
+        int pprev = -1, pnext = -2;
+        if (blocks) {
+            if (ib > 0) pprev = pt_idx[ib - 1];
+            if (ib + 64 < N) pnext = pt_idx[ib + 64];
+        }
         double jc[12], jp[6], rx, ry;
         observe<JAC>(tab + c0 * kCamTab, X0, Y0, Z0, uv0.x, uv0.y, K, rx, ry, jc, jp);
-        acc += rx * rx + ry * ry;
-        if (STORE_R) {
-            if (F32) store_pair(r, 1, i, rx, ry); else st16(r + 2 * (size_t)i, rx, ry);
-        }
-        if (JAC) {
-            // compact form: d r/d w (jc[0..2], jc[6..8]) and d r/d X (jp); d r/d T = -jp is not stored
-            if (F32) {
-                float4* __restrict__ Jf = reinterpret_cast<float4*>(J);
-                Jf[jaddr_f32(i, 0)] = make_float4((float)jc[0], (float)jc[1], (float)jc[2], (float)jc[6]);
-                Jf[jaddr_f32(i, 1)] = make_float4((float)jc[7], (float)jc[8], (float)jp[0], (float)jp[1]);
-                Jf[jaddr_f32(i, 2)] = make_float4((float)jp[2], (float)jp[3], (float)jp[4], (float)jp[5]);
-            } else {
-                st16(J + jaddr(ld, i, 0), jc[0], jc[1]);
-                st16(J + jaddr(ld, i, 1), jc[2], jc[6]);
-                st16(J + jaddr(ld, i, 2), jc[7], jc[8]);
+        if (on) {
+            acc += rx * rx + ry * ry;
+            if (STORE_R) {
+                if (F32) store_pair(r, 1, i, rx, ry); else st16(r + 2 * (size_t)i, rx, ry);
+            }
+            if (JAC) {
+                // compact form: d r/d w (jc[0..2], jc[6..8]) and d r/d X (jp); d r/d T = -jp is not stored
+                if (F32) {
+                    float4* __restrict__ Jf = reinterpret_cast<float4*>(J);
+                    Jf[jaddr_f32(i, 0)] = make_float4((float)jc[0], (float)jc[1], (float)jc[2], (float)jc[6]);
+                    Jf[jaddr_f32(i, 1)] = make_float4((float)jc[7], (float)jc[8], (float)jp[0], (float)jp[1]);
+                    Jf[jaddr_f32(i, 2)] = make_float4((float)jp[2], (float)jp[3], (float)jp[4], (float)jp[5]);
+                } else {
+                    st16(J + jaddr(ld, i, 0), jc[0], jc[1]);
+                    st16(J + jaddr(ld, i, 1), jc[2], jc[6]);
+                    st16(J + jaddr(ld, i, 2), jc[7], jc[8]);
 #pragma unroll
-                for (int m = 0; m < 3; ++m) st16(J + jaddr(ld, i, 3 + m), jp[2 * m], jp[2 * m + 1]);
+                    for (int m = 0; m < 3; ++m) st16(J + jaddr(ld, i, 3 + m), jp[2 * m], jp[2 * m + 1]);
+                }
+            }
+        }
+        if (blocks) {
+            double v[9];
+            v[0] = jp[0] * jp[0] + jp[3] * jp[3]; v[1] = jp[0] * jp[1] + jp[3] * jp[4];
+            v[2] = jp[0] * jp[2] + jp[3] * jp[5]; v[3] = jp[1] * jp[1] + jp[4] * jp[4];
+            v[4] = jp[1] * jp[2] + jp[4] * jp[5]; v[5] = jp[2] * jp[2] + jp[5] * jp[5];
+            v[6] = jp[0] * rx + jp[3] * ry; v[7] = jp[1] * rx + jp[4] * ry; v[8] = jp[2] * rx + jp[5] * ry;
+            const int key = on ? p0 : -1;
+            if (!on) {
+#pragma unroll
+                for (int q = 0; q < 9; ++q) v[q] = 0.0;
+            }
+            seg_reduce_serial<9>(v, key, lane);                  // first lane of every run: the run's sums
+            int kp = dpp_int<0x111>(key);                        // row_shr:1: the key one lane down
+            const int k15 = __builtin_amdgcn_readlane(key, 15), k31 = __builtin_amdgcn_readlane(key, 31);
+            const int k47 = __builtin_amdgcn_readlane(key, 47), k63 = __builtin_amdgcn_readlane(key, 63);
+            kp = lane == 16 ? k15 : (lane == 32 ? k31 : (lane == 48 ? k47 : kp));
+            const bool first = on && (lane == 0 || key != kp);
+            const bool head = lane == 0 && key == pprev;         // continues a run of the previous tile
+            const bool tail = key == k63 && k63 == pnext;        // continues into the next tile
+            if (first) {
+                if (!head && !tail) {
+                    double* __restrict__ vr = pb.V + 6 * (size_t)key;
+                    st16(vr, v[0], v[1]); st16(vr + 2, v[2], v[3]); st16(vr + 4, v[4], v[5]);
+                    double* __restrict__ gr = pb.gp + 3 * (size_t)key;
+                    gr[0] = v[6]; gr[1] = v[7]; gr[2] = v[8];
+                } else {
+                    double* __restrict__ e = pb.edge + ((size_t)(ib >> 6) * 2 + (head ? 0 : 1)) * kEdgeRow;
+                    st16(e, v[0], v[1]); st16(e + 2, v[2], v[3]); st16(e + 4, v[4], v[5]); st16(e + 6, v[6], v[7]);
+                    e[8] = v[8];
+                }
             }
         }
         i = in;
@@ -492,6 +586,33 @@ __global__ __launch_bounds__(kSweepThreads) void k_resjac(
         for (int k = 0; k < (int)(blockDim.x >> 6); ++k) s += red[k];
         cost_part[blockIdx.x] = s;
     }
+}
+
+// The pieces of the point rows that k_resjac left in `edge` (see there): one thread per tile boundary.  The tile in
+// which a cut run STARTS owns it: its piece (slot 1), then slot 0 of every following tile the run reaches, in tile
+// order.
+__device__ __forceinline__ void point_edge_fixup(int t, const int* __restrict__ pt_idx, int N,
+                                                 const PointBlocksOut& pb) {
+    const int e0 = 64 * (t + 1);                           // first observation of the next tile
+    if (e0 >= N) return;
+    const int key = pt_idx[e0 - 1];
+    if (key != pt_idx[e0]) return;                         // no run crosses this boundary
+    if (t > 0 && pt_idx[64 * t] == key && pt_idx[64 * t - 1] == key) return;      // started earlier: not the owner
+    double s[9];
+    const double* __restrict__ a = pb.edge + ((size_t)t * 2 + 1) * kEdgeRow;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) s[q] = a[q];
+    for (int u = t + 1;; ++u) {
+        const double* __restrict__ b = pb.edge + (size_t)u * 2 * kEdgeRow;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) s[q] += b[q];
+        const int n0 = 64 * (u + 1);
+        if (!(n0 < N && pt_idx[n0 - 1] == key && pt_idx[n0] == key)) break;       // the run ends inside tile u
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) pb.V[6 * (size_t)key + q] = s[q];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) pb.gp[3 * (size_t)key + q] = s[6 + q];
 }
 
 // Unpack the Jacobian pair-planes into the row-major (N,2,6)/(N,2,3) blocks of the C-ABI (test entry).
@@ -603,9 +724,14 @@ template <bool F32>
 __global__ __launch_bounds__(kCamThreads) void k_cam_blocks(CamMajor cm, const double* __restrict__ camtab,
                                                             const double* __restrict__ rec, KMat K,
                                                             double* __restrict__ Ugc, double* __restrict__ partial,
-                                                            const double* __restrict__ skip) {
+                                                            const double* __restrict__ skip, int n_chunks,
+                                                            const int* __restrict__ pt_idx, int N, PointBlocksOut pb) {
     __shared__ double red[kCamWaves][27];
     if (skip != nullptr && *skip != 0.0) return;   // speculative launch cancelled by k_tr_step
+    if ((int)blockIdx.x >= n_chunks) {             // riders: the point rows K1's tiles cut (see k_resjac)
+        point_edge_fixup(((int)blockIdx.x - n_chunks) * kCamThreads + (int)threadIdx.x, pt_idx, N, pb);
+        return;
+    }
     const int4 ch = cm.chunks[blockIdx.x];
     double t[kCamTab];
 #pragma unroll
@@ -698,113 +824,6 @@ struct StepTable {
     const int2* __restrict__ steps;
     int n_waves;
 };
-
-// K2: V_p = sum Jp^T Jp (6, packed upper triangle), g_p = sum Jp^T r (3), recomputed from the camera table
-// and the point like K1 does (20 B per observation of indices and pixels instead of 64 B of stored blocks,
-// and exact fp64 in fp32-storage mode too).  FOUR LANES per point: the quad walks its point's run four
-// observations at a time (64 contiguous bytes of pixels per quad and trip) and keeps the nine sums in registers;
-// the only cross-lane work is two quad-permute steps at the end (the wave-segmented form spent two thirds of its
-// time in the DPP / v_readlane reduction of nine doubles per step; one lane per point halved that but thrashed
-// the L1 with 64 strided walks per wave).  The trip count of a wave is its longest run / 4; runs longer than
-// kLongRun are left out of the quad walk and summed by the whole wave afterwards.  Persistent workgroups stage
-// the compact R | T view of the camera table (rows of 96 bytes) in LDS once and loop over groups of 128 points;
-// when the table does not fit (LDS_TAB = false) its rows are gathered with six 16-byte loads.
-constexpr int kPointBlockThreads = 1024;
-constexpr int kLongRun = 256;
-__device__ __forceinline__ double quad_sum(double v) {        // sum over the four lanes of a quad, on every lane
-    v += dpp_double<0xB1>(v);                                  // quad_perm [1,0,3,2]
-    v += dpp_double<0x4E>(v);                                  // quad_perm [2,3,0,1]
-    return v;
-}
-template <bool LDS_TAB, bool F32>
-__global__ __launch_bounds__(kPointBlockThreads) void k_point_blocks(
-    const int* __restrict__ pt_ptr, const int* __restrict__ cam_idx, const double* __restrict__ uv,
-    const double* __restrict__ camtab, const double* __restrict__ pts, int P, int C, KMat K,
-    double* __restrict__ V, double* __restrict__ gp, const double* __restrict__ skip) {
-    extern __shared__ __align__(16) double smem[];
-    if (skip != nullptr && *skip != 0.0) return;   // speculative launch cancelled by k_tr_step
-    const int lane = threadIdx.x & 63, sub = threadIdx.x & 3;
-    const int per_block = blockDim.x >> 2;                      // points per workgroup and trip
-    const double* __restrict__ rt = camtab + cam_rt_offset(C);
-    if (LDS_TAB) {
-        const int n2 = (C * kCamRT) >> 1;
-        const double2* __restrict__ src = reinterpret_cast<const double2*>(rt);
-        double2* __restrict__ dst = reinterpret_cast<double2*>(smem);
-        for (int k = threadIdx.x; k < n2; k += blockDim.x) dst[k] = src[k];
-        __syncthreads();
-    }
-    const double* __restrict__ tab = LDS_TAB ? smem : rt;
-    auto add_terms = [&](int cc, double x_, double y_, double z_, double2 px, double* v) {
-        double jc[12], jp[6], rx, ry;
-        double t[kCamTab];
-        const double2* __restrict__ row = reinterpret_cast<const double2*>(tab + (size_t)cc * kCamRT);
-#pragma unroll
-        for (int k = 0; k < kCamRT / 2; ++k) { const double2 q = row[k]; t[2 * k] = q.x; t[2 * k + 1] = q.y; }
-#pragma unroll
-        for (int k = kCamRT; k < kCamTab; ++k) t[k] = 0.0;       // the rotation part of the camera block is not used here
-        observe<true>(t, x_, y_, z_, px.x, px.y, K, rx, ry, jc, jp);
-        v[0] += jp[0] * jp[0] + jp[3] * jp[3]; v[1] += jp[0] * jp[1] + jp[3] * jp[4];
-        v[2] += jp[0] * jp[2] + jp[3] * jp[5]; v[3] += jp[1] * jp[1] + jp[4] * jp[4];
-        v[4] += jp[1] * jp[2] + jp[4] * jp[5]; v[5] += jp[2] * jp[2] + jp[5] * jp[5];
-        v[6] += jp[0] * rx + jp[3] * ry; v[7] += jp[1] * rx + jp[4] * ry; v[8] += jp[2] * rx + jp[5] * ry;
-    };
-    for (int base = blockIdx.x * per_block; base < P; base += gridDim.x * per_block) {
-        const int p = base + ((int)threadIdx.x >> 2);
-        int b = 0, e = 0;
-        double X = 0.0, Y = 0.0, Z = 0.0;
-        if (p < P) {
-            b = pt_ptr[p]; e = pt_ptr[p + 1];
-            const double* __restrict__ Xp = pts + 3 * (size_t)p;
-            X = Xp[0]; Y = Xp[1]; Z = Xp[2];
-        }
-        const bool is_long = e - b > kLongRun;
-        double v[9];
-#pragma unroll
-        for (int q = 0; q < 9; ++q) v[q] = 0.0;
-        // the next observation's index and pixel are requested while this one computes
-        int i = b + sub;
-        bool on = !is_long && i < e;
-        int c = 0;
-        double2 px = make_double2(0.0, 0.0);
-        if (on) { c = cam_idx[i]; px = load_pair(uv, F32, i); }
-        while (__ballot(on) != 0ull) {
-            const int in_ = i + 4;
-            const bool on_n = on && in_ < e;
-            int cn = 0;
-            double2 pxn = make_double2(0.0, 0.0);
-            if (on_n) { cn = cam_idx[in_]; pxn = load_pair(uv, F32, in_); }
-            if (on) add_terms(c, X, Y, Z, px, v);
-            i = in_; on = on_n; c = cn; px = pxn;
-        }
-#pragma unroll
-        for (int q = 0; q < 9; ++q) v[q] = quad_sum(v[q]);
-        if (p < P && !is_long && sub == 0) {          // a point without observations gets its zeros here
-#pragma unroll
-            for (int q = 0; q < 6; ++q) V[(size_t)p * 6 + q] = v[q];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) gp[(size_t)p * 3 + q] = v[6 + q];
-        }
-        unsigned long long todo = __ballot(is_long && sub == 0);   // long runs: the whole wave sums one point at a time
-        while (todo != 0ull) {
-            const int l = __ffsll((long long)todo) - 1;
-            todo &= todo - 1ull;
-            const int pp = __shfl(p, l), bb = __shfl(b, l), ee = __shfl(e, l);
-            const double xl = __shfl(X, l), yl = __shfl(Y, l), zl = __shfl(Z, l);
-            double w[9];
-#pragma unroll
-            for (int q = 0; q < 9; ++q) w[q] = 0.0;
-            for (int j = bb + lane; j < ee; j += 64) add_terms(cam_idx[j], xl, yl, zl, load_pair(uv, F32, j), w);
-#pragma unroll
-            for (int q = 0; q < 9; ++q) w[q] = wave_sum(w[q]);
-            if (lane == 0) {
-#pragma unroll
-                for (int q = 0; q < 6; ++q) V[(size_t)pp * 6 + q] = w[q];
-#pragma unroll
-                for (int q = 0; q < 3; ++q) gp[(size_t)pp * 3 + q] = w[6 + q];
-            }
-        }
-    }
-}
 
 // Reductions over the parameter vector are taken separately over the camera slice [0, 6C) (replicated
 // on every rank) and the point slice [6C, n) (local to the shard, summed over ranks): blocks
@@ -1955,7 +1974,7 @@ constexpr int kDenseTile = 16;
 // the Levenberg-Marquardt term, which scipy's rule lets fall to 1e-10 of the diagonal: the last pivots are then
 // rounding noise.  An unknown whose pivot does not exceed this fraction of its original diagonal entry is dropped
 // from the solve (its step is 0, its column decoupled): a basic solution of the consistent singular system.
-constexpr double kDensePivotTol = 1e-12;
+constexpr double kDensePivotTol = 1e-14;
 
 __host__ __device__ constexpr int dense_block_index(int a, int b, int C) {      // a <= b, row-major upper triangle
     return a * C - a * (a - 1) / 2 + (b - a);

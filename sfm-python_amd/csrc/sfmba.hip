@@ -244,6 +244,7 @@ struct sfmba_handle {
     bool cam_multi = false;                  // some camera has more than one chunk: k_cam_combine runs
     DevBuf xa, xb, tabA, tabB, r, J, t1;     // ONE Jacobian / residual buffer set
     DevBuf V, Vinv, gp, e, recA, recB;       // rec: point records X Y Z | z (k_fill_rec), one per parameter vector
+    DevBuf edge;                             // pieces of the point rows cut by K1's tiles (PointBlocksOut)
     DevBuf g, si, sg, p;                     // n-vectors; p = [dc | dp]
     DevBuf Dc, Minv, vecs, vtmp, vcm;               // camera-sized, plane-major [k][C]; vecs = 2 sets x (x r p s u)
     DevBuf part, ctrl;
@@ -515,38 +516,45 @@ int launch_cam_table(sfmba_handle* h, const double* x, double* tab, double* rec)
 // sum r^2 partials in `part` and returns the number of partials.  With ev0/ev1 the dispatch itself
 // is bracketed (hipExtLaunchKernelGGL: start/stop taken from the kernel's own dispatch, as rocprofv3
 // does), so the measured duration is the kernel's and not host launch latency.
+PointBlocksOut point_blocks_out(sfmba_handle* h) {
+    return PointBlocksOut{h->V.as<double>(), h->gp.as<double>(), h->edge.as<double>()};
+}
+
 template <bool LDS, bool JAC, bool STORE_R, bool F32>
 int launch_resjac_v(sfmba_handle* h, const double* x, const double* tab, int grid, size_t lds,
-                    hipEvent_t ev0, hipEvent_t ev1) {
+                    hipEvent_t ev0, hipEvent_t ev1, bool blocks) {
     const double* pts = x + 6 * h->C;
+    const PointBlocksOut pb = blocks ? point_blocks_out(h) : PointBlocksOut{nullptr, nullptr, nullptr};
     auto kern = k_resjac<LDS, JAC, STORE_R, F32>;
     CHK(set_lds(h, kern, lds));
     if (ev0) {
         hipExtLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), (uint32_t)lds, h->stream, ev0, ev1, 0u, tab, pts,
                               (const int*)h->cam_idx.as<int>(), (const int*)h->pt_idx.as<int>(),
                               (const double*)h->uv.as<double>(), h->r.as<double>(), h->J.as<double>(),
-                              (int)h->N, h->ld, (int)h->C, h->K, h->part.as<double>(), h->skip);
+                              (int)h->N, h->ld, (int)h->C, h->K, h->part.as<double>(), h->skip, pb);
     } else {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), lds, h->stream, tab, pts,
                            h->cam_idx.as<int>(), h->pt_idx.as<int>(), h->uv.as<double>(),
                            h->r.as<double>(), h->J.as<double>(), (int)h->N,
-                           h->ld, (int)h->C, h->K, h->part.as<double>(), h->skip);
+                           h->ld, (int)h->C, h->K, h->part.as<double>(), h->skip, pb);
     }
     LAUNCHED(h);
     return 0;
 }
 
+// `blocks`: the Jacobian launch also leaves V_p, g_p of x (the point half of the normal equations; the camera half
+// and the pieces of runs cut by tile boundaries follow in launch_normal_blocks)
 template <bool JAC, bool STORE_R>
 int launch_resjac(sfmba_handle* h, const double* x, const double* tab, int* nparts,
-                  hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
+                  hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, bool blocks = JAC) {
     const int grid = grid_1d(h->N, kSweepThreads, h->n_cu);
     *nparts = grid;
     const size_t lds = (size_t)h->C * kCamTab * sizeof(double);
     if (h->lds_tab)
-        return h->f32 ? launch_resjac_v<true, JAC, STORE_R, true>(h, x, tab, grid, lds, ev0, ev1)
-                      : launch_resjac_v<true, JAC, STORE_R, false>(h, x, tab, grid, lds, ev0, ev1);
-    return h->f32 ? launch_resjac_v<false, JAC, STORE_R, true>(h, x, tab, grid, 0, ev0, ev1)
-                  : launch_resjac_v<false, JAC, STORE_R, false>(h, x, tab, grid, 0, ev0, ev1);
+        return h->f32 ? launch_resjac_v<true, JAC, STORE_R, true>(h, x, tab, grid, lds, ev0, ev1, blocks)
+                      : launch_resjac_v<true, JAC, STORE_R, false>(h, x, tab, grid, lds, ev0, ev1, blocks);
+    return h->f32 ? launch_resjac_v<false, JAC, STORE_R, true>(h, x, tab, grid, 0, ev0, ev1, blocks)
+                  : launch_resjac_v<false, JAC, STORE_R, false>(h, x, tab, grid, 0, ev0, ev1, blocks);
 }
 
 // sum of `nparts` partial rows of width nq into the exchange scalars starting at slot `slot`
@@ -598,33 +606,17 @@ int launch_cam_combine(sfmba_handle* h, int ncols, double* out, int cs, int ks, 
     return 0;
 }
 
-// K2 + K3 at (x, tab): V_p, g_p over the point-major order, [U_c | g_c] over the camera-major order; both
-// recompute the blocks from the camera table and the point (no stored Jacobian is read)
+// K3 at (x, tab): [U_c | g_c] over the camera-major order, blocks recomputed from the camera table and the point
+// records.  V_p, g_p were left by the residual+Jacobian launch at the same x (launch_resjac with `blocks`), except
+// for the runs its 64-observation tiles cut: their pieces are added by a few extra workgroups of this launch.
 template <bool F32>
 int launch_normal_blocks_v(sfmba_handle* h, const double* x, const double* tab, const double* rec) {
-    const double* pts = x + 6 * h->C;
-    // four lanes per point; persistent workgroups of 64 ... 512 threads (16 ... 128 points per trip), at most one
-    // per CU (each stages the compact camera table once), sized so that a small cloud still covers the chip
-    const int64_t lanes = 4 * h->P;
-    const int threads = (int)std::min<int64_t>(kPointBlockThreads, std::max<int64_t>(64, (lanes / h->n_cu + 63) / 64 * 64));
-    const size_t lds = (size_t)h->C * kCamRT * sizeof(double);
-    const bool tab_in_lds = lds <= kLdsDynMax && h->dbg.tab_lds != 0;
-    const int grid = (int)std::min<int64_t>((tab_in_lds ? 1 : 4) * (int64_t)h->n_cu, (lanes + threads - 1) / threads);
-    if (tab_in_lds) {
-        auto kern = k_point_blocks<true, F32>;
-        CHK(set_lds(h, kern, lds));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, h->stream, (const int*)h->pt_ptr.as<int>(),
-                           (const int*)h->cam_idx.as<int>(), (const double*)h->uv.as<double>(), tab, pts, (int)h->P,
-                           (int)h->C, h->K, h->V.as<double>(), h->gp.as<double>(), h->skip);
-    } else {
-        hipLaunchKernelGGL((k_point_blocks<false, F32>), dim3(grid), dim3(threads), 0, h->stream,
-                           (const int*)h->pt_ptr.as<int>(), (const int*)h->cam_idx.as<int>(),
-                           (const double*)h->uv.as<double>(), tab, pts, (int)h->P, (int)h->C, h->K, h->V.as<double>(),
-                           h->gp.as<double>(), h->skip);
-    }
-    LAUNCHED(h);
-    hipLaunchKernelGGL((k_cam_blocks<F32>), dim3(h->n_chunks), dim3(kCamThreads), 0, h->stream, cam_major(h), tab, rec,
-                       h->K, h->Ugc(), h->cam_partial.as<double>(), h->skip);
+    (void)x;
+    const int tiles = (int)((h->N + 63) / 64);
+    const int riders = (tiles + kCamThreads - 1) / kCamThreads;
+    hipLaunchKernelGGL((k_cam_blocks<F32>), dim3(h->n_chunks + riders), dim3(kCamThreads), 0, h->stream, cam_major(h), tab,
+                       rec, h->K, h->Ugc(), h->cam_partial.as<double>(), h->skip, (int)h->n_chunks,
+                       (const int*)h->pt_idx.as<int>(), (int)h->N, point_blocks_out(h));
     LAUNCHED(h);
     return launch_cam_combine(h, 27, h->Ugc(), 27, 1, h->skip, nullptr);
 }
@@ -1037,8 +1029,8 @@ void sfmba_default_options(sfmba_options* o) {
     memset(o, 0, sizeof *o);
     o->ftol = 1e-8; o->xtol = 1e-8; o->gtol = 1e-8;
     o->max_nfev = 0; o->verbose = 0; o->max_iter = 0;
-    o->pcg_tol = 1e-3; o->pcg_max_iter = 0; o->pcg_check_every = 2;
-    o->reg_min = 1e-10; o->profile = 0;
+    o->pcg_tol = 1e-2; o->pcg_max_iter = 0; o->pcg_check_every = 2;
+    o->reg_min = 1e-6; o->profile = 0;
 }
 
 int sfmba_create(sfmba_handle** out, int device_id) {
@@ -1605,6 +1597,7 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     HIPCHK(h, h->V.ensure(sizeof(double) * 6 * P));
     HIPCHK(h, h->Vinv.ensure(sizeof(double) * 6 * P));
     HIPCHK(h, h->gp.ensure(sizeof(double) * 3 * P));
+    HIPCHK(h, h->edge.ensure(sizeof(double) * 2 * kEdgeRow * (size_t)((N + 63) / 64)));
     HIPCHK(h, h->e.ensure(sizeof(double) * 3 * P));
     HIPCHK(h, h->g.ensure(sizeof(double) * h->n));
     HIPCHK(h, h->si.ensure(sizeof(double) * h->n));
@@ -1693,7 +1686,7 @@ int sfmba_residual_jacobian(sfmba_handle* h, const double* x, double* r_out, dou
     CHK(upload_x(h, x));
     CHK(launch_cam_table(h, h->x, h->tab, h->rec));
     int np = 0;
-    CHK((launch_resjac<true, true>(h, h->x, h->tab, &np)));
+    CHK((launch_resjac<true, true>(h, h->x, h->tab, &np, nullptr, nullptr, /*blocks=*/false)));
     DevBuf jc_rm, jp_rm;
     HIPCHK(h, jc_rm.ensure(sizeof(double) * 12 * h->N));
     HIPCHK(h, jp_rm.ensure(sizeof(double) * 6 * h->N));
@@ -2152,7 +2145,10 @@ static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt
         if (opt.verbose >= 2) print_iter(h, iteration, nfev, cost, have_red, actual_reduction, step_norm, g_norm);
         if (status != -1 || nfev >= max_nfev || (opt.max_iter > 0 && iteration >= opt.max_iter)) break;
         pcg_total += hc.iters;
-        if (pcg_debug)
+        if (pcg_debug && dense)
+            fprintf(stderr, "sfmba: iteration %lld: dense solve, %d unknowns dropped, reg %.3e\n", (long long)iteration,
+                    hc.max_iters, h->h_scal[kRegSlot]);
+        else if (pcg_debug)
             fprintf(stderr, "sfmba: iteration %lld: PCG enqueued %d, needed %d%s\n", (long long)iteration,
                     pcg_enqueued, hc.iters, missed ? " (miss)" : "");
         // Next guess: the largest recent count, forgotten by one iteration per outer iteration.  A surplus

@@ -40,7 +40,7 @@ for case in range(n_cases):
     r_true = orc.compute_residuals(xt, C, P, ci, pi, np.zeros((N, 2)), base.K)
     uv = np.trunc(r_true.reshape(N, 2) + rng.normal(0, 0.5, (N, 2))).astype(np.int64)
     args = (C, P, ci, pi, uv, base.K)
-    o = orc.trf_schur(base.x0, *args, ftol=1e-10, linear="pcg", pcg_tol=1e-3, max_nfev=60)
+    o = orc.trf_schur(base.x0, *args, ftol=1e-10, linear="pcg", pcg_tol=1e-2, max_nfev=60)
     res = sfmba.least_squares(sfmba.compute_residuals, base.x0, x_scale="jac", ftol=1e-10, method="trf", args=args,
                               max_nfev=60)
     ok = (res.status == o.status and (res.nfev, res.njev) == (o.nfev, o.njev)
