@@ -38,20 +38,22 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI35
 
 
 def k1_bytes_f32(C, P, N):
-    """fp32-storage mode: idx 8 + uv 8 read, r 8 + Jacobian 48 written per observation."""
-    return 72 * N + 24 * P + 48 * C
+    """fp32-storage mode: idx 8 + uv 8 read, r 8 + Jacobian 48 written per observation; point rows as k1_bytes."""
+    return 72 * N + 96 * P + 48 * C
 
 
 def k1_bytes(C, P, N):
     """Algorithmic bytes of one residual+Jacobian launch: per observation read
     cam_idx 4 + pt_idx 4 + uv 16, write r 16 + d r/d w 48 + d r/d X 48 = 136 B; once per point 24 B, per
-    camera 48 B.  SURVEY.md section 8d counts 184 B because it also writes d r/d T, which is -d r/d X and is
-    not stored (see k1_bytes_survey for that accounting)."""
-    return 136 * N + 24 * P + 48 * C
+    camera 48 B.  Since round 3 the launch also leaves the point half of the normal equations, V_p (48 B) and g_p
+    (24 B) per point, summed from the blocks it holds in registers: 96 B per point in all.  SURVEY.md section 8d
+    counts 184 B per observation because it also writes d r/d T, which is -d r/d X and is not stored (see
+    k1_bytes_survey for that accounting)."""
+    return 136 * N + 96 * P + 48 * C
 
 
 def k1_bytes_survey(C, P, N):
-    return 184 * N + 24 * P + 48 * C
+    return 184 * N + 96 * P + 48 * C
 
 
 def cpu_baseline(workload_dims, seconds_budget=25.0):
@@ -326,12 +328,12 @@ def main():
             # time until the RMSE is final = wall time of a solve that ran to its ftol termination
             "time_to_final_rmse_ms": (round(1e3 * sorted(r[7] for r in full)[len(full) // 2], 3)
                                       if any(r[6] != 0 for r in results) else None),
-            "roofline": {"kernel": "k_resjac (residual + 2x6/2x3 Jacobian sweep)", "bound": "hbm",
+            "roofline": {"kernel": "k_resjac (residual + 2x6/2x3 Jacobian sweep + point blocks V_p, g_p)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                          "traffic": traffic, "avg_launch_us": k1_us,
                          "algorithmic_bytes_per_launch": kb(Cl, Pl, Nl),
-                         "note": "bytes = 136 N + 24 P + 48 C of the rank's shard: the 2x3 block d r/d T = -d r/d X is "
+                         "note": "bytes = 136 N + 96 P + 48 C of the rank's shard: the 2x3 block d r/d T = -d r/d X is "
                                  "not stored; SURVEY 8d's 184 N figure writes it a second time",
                          "achieved_if_counted_as_survey_184B": (k1_bytes_survey(Cl, Pl, Nl) / (k1_us * 1e-6) / 1e9)
                                                                 if k1_us > 0 else None,

@@ -318,11 +318,24 @@ def schur_solve(nb: NormalBlocks, Dc, Dp, camera_indices, point_indices, rhs_c, 
     else:
         if precond == "block_u":
             Minv = np.linalg.inv(Ud)
-        else:  # true diagonal blocks of S
-            Sd = Ud.copy()
+        elif precond == "schur":  # diagonal blocks of S, one term per observation (what the camera-major pass of
+            Sd = Ud.copy()        # the HIP path sums along with the reduced right-hand side)
             WV = np.einsum("nij,njk->nik", nb.W, Vinv[pi])
             np.add.at(Sd, ci, -np.einsum("nik,njk->nij", WV, nb.W))
             Minv = np.linalg.inv(Sd)
+        elif precond == "schur_exact":  # the diagonal blocks of the FORMED S (few-camera path of the HIP code): the
+            # same, except that several observations of one (camera, point) pair -- random test problems have
+            # them, a reconstruction does not -- contribute (sum W)(Vinv)(sum W)^T, cross terms included
+            key = ci.astype(np.int64) * P + pi
+            uniq, inv = np.unique(key, return_inverse=True)
+            Wsum = np.zeros((len(uniq), 6, 3))
+            np.add.at(Wsum, inv, nb.W)
+            cu, pu = uniq // P, uniq % P
+            Sd = Ud.copy()
+            np.add.at(Sd, cu, -np.einsum("nik,nkl,njl->nij", Wsum, Vinv[pu], Wsum))
+            Minv = np.linalg.inv(Sd)
+        else:
+            raise ValueError(f"unknown preconditioner {precond!r}")
         bvec = red.reshape(-1)
         xk = np.zeros_like(bvec)
         rk = bvec.copy()

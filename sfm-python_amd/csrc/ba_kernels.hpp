@@ -96,6 +96,11 @@ __device__ __forceinline__ double wave_sum(double v) {
     v += dpp_double<0x108>(v);
     return ((readlane_double(v, 0) + readlane_double(v, 16)) + readlane_double(v, 32)) + readlane_double(v, 48);
 }
+__device__ __forceinline__ double quad_sum(double v) {        // sum over the four lanes of a quad, on every lane
+    v += dpp_double<0xB1>(v);                                  // quad_perm [1,0,3,2]
+    v += dpp_double<0x4E>(v);                                  // quad_perm [2,3,0,1]
+    return v;
+}
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
@@ -1057,39 +1062,8 @@ __global__ void k_point_prep(const double* __restrict__ V, const double* __restr
     point_prep_one(V, gp, sip, dp_extra, p, reg, Vinv, e);
 }
 
-// Per camera: Minv = (U + diag(Dc))^-1 (6x6, Cholesky), the block-Jacobi preconditioner of the
-// reduced camera system; Dc = reg si_c^2 is also written out.  Camera-sized PCG vectors (Dc, Minv,
-// acc, x, r, p, s, u) are stored plane-major, element k of camera c at [k*C + c], so that the
-// one-thread-per-camera PCG kernels read and write them fully coalesced.
-// sd (optional, plane-major [21][C]): sum_i W_i Vinv W_i^T of the camera's own observations -- with it the block
-// is the true diagonal block of the reduced camera matrix S (Schur-diagonal preconditioner) and Dc is read, not
-// written (it was formed before the pass that produced sd).
-__device__ __forceinline__ void cam_prep_one(const double* __restrict__ Ugc, const double* __restrict__ sic,
-                                             const double* __restrict__ dc_extra, int C, int c, double reg,
-                                             double* __restrict__ Dc, double* __restrict__ Minv,
-                                             const double* __restrict__ sd = nullptr) {
-    double A[6][6];
-    {
-        int n = 0;
-#pragma unroll
-        for (int a = 0; a < 6; ++a)
-#pragma unroll
-            for (int b = a; b < 6; ++b) {
-                A[a][b] = Ugc[(size_t)c * 27 + n] - (sd ? sd[(size_t)n * C + c] : 0.0);
-                A[b][a] = A[a][b];
-                ++n;
-            }
-    }
-#pragma unroll
-    for (int a = 0; a < 6; ++a) {
-        double d;
-        if (sd) d = Dc[(size_t)a * C + c];
-        else {
-            d = dc_extra ? dc_extra[6 * (size_t)c + a] : reg * sic[6 * (size_t)c + a] * sic[6 * (size_t)c + a];
-            Dc[(size_t)a * C + c] = d;                  // plane-major over cameras (coalesced in the PCG)
-        }
-        A[a][a] += d;
-    }
+// out = packed upper triangle of A^-1 for a symmetric positive definite 6x6 A (Cholesky, inverse of the factor)
+__device__ __forceinline__ void spd6_inverse(const double (&A)[6][6], double (&out)[21]) {
     double Lm[6][6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -1123,13 +1097,51 @@ __device__ __forceinline__ void cam_prep_one(const double* __restrict__ Ugc, con
 #pragma unroll
     for (int a = 0; a < 6; ++a)
 #pragma unroll
-        for (int b = a; b < 6; ++b) {                    // packed upper triangle, plane n = [C]
+        for (int b = a; b < 6; ++b) {
             double t = 0.0;
 #pragma unroll
             for (int k = b; k < 6; ++k) t += M[k][a] * M[k][b];
-            Minv[(size_t)n * C + c] = t;
-            ++n;
+            out[n++] = t;
         }
+}
+
+// Per camera: Minv = (U + diag(Dc))^-1 (6x6, Cholesky), the block-Jacobi preconditioner of the
+// reduced camera system; Dc = reg si_c^2 is also written out.  Camera-sized PCG vectors (Dc, Minv,
+// acc, x, r, p, s, u) are stored plane-major, element k of camera c at [k*C + c], so that the
+// one-thread-per-camera PCG kernels read and write them fully coalesced.
+// sd (optional, plane-major [21][C]): sum_i W_i Vinv W_i^T of the camera's own observations -- with it the block
+// is the true diagonal block of the reduced camera matrix S (Schur-diagonal preconditioner) and Dc is read, not
+// written (it was formed before the pass that produced sd).
+__device__ __forceinline__ void cam_prep_one(const double* __restrict__ Ugc, const double* __restrict__ sic,
+                                             const double* __restrict__ dc_extra, int C, int c, double reg,
+                                             double* __restrict__ Dc, double* __restrict__ Minv,
+                                             const double* __restrict__ sd = nullptr) {
+    double A[6][6];
+    {
+        int n = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = a; b < 6; ++b) {
+                A[a][b] = Ugc[(size_t)c * 27 + n] - (sd ? sd[(size_t)n * C + c] : 0.0);
+                A[b][a] = A[a][b];
+                ++n;
+            }
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        double d;
+        if (sd) d = Dc[(size_t)a * C + c];
+        else {
+            d = dc_extra ? dc_extra[6 * (size_t)c + a] : reg * sic[6 * (size_t)c + a] * sic[6 * (size_t)c + a];
+            Dc[(size_t)a * C + c] = d;                  // plane-major over cameras (coalesced in the PCG)
+        }
+        A[a][a] += d;
+    }
+    double out[21];
+    spd6_inverse(A, out);
+#pragma unroll
+    for (int n = 0; n < 21; ++n) Minv[(size_t)n * C + c] = out[n];          // packed upper triangle, plane n = [C]
 }
 
 __global__ void k_cam_prep(const double* __restrict__ Ugc, const double* __restrict__ sic,
@@ -1959,23 +1971,20 @@ __global__ __launch_bounds__(kRhsThreads) void k_cam_rhs_diag(CamMajor cm, const
 }
 
 // ---------------------------------------------------------------------------------------------
-// Dense reduced-camera path (6 C <= kDenseMaxN): the size the reference itself produces -- SceauxCastle has 11
-// cameras (BASELINE.json configs[0-1]).  There the iterative solve is all launch latency (46 PCG iterations of
-// two launches each per solve at 11 cameras), while the reduced camera matrix S = U + Dc - W V^-1 W^T is 66 x 66.
-// So S is FORMED -- one wave per 6x6 block pair (a <= b) over the list of points both cameras see, built once
-// per problem; blocks recomputed from the camera rows and the gathered point; no atomics -- and factorised by
-// one workgroup in LDS: blocked Cholesky with 16 x 16 tiles, the trailing updates on the matrix cores
-// (v_mfma_f64_16x16x4_f64), the right-hand side carried along as an extra row, then one back substitution.
-// The Gauss-Newton step is then exact instead of PCG-to-1e-3.
+// Few cameras (6 C <= kDenseMaxN): the size the reference itself produces -- SceauxCastle has 11 cameras
+// (BASELINE.json configs[0-1]).  There the implicit product is all launch latency (two launches per PCG iteration,
+// ~10 iterations per outer iteration), while the reduced camera matrix S = U + Dc - W V^-1 W^T is 66 x 66.
+// So S is FORMED -- one workgroup per 6x6 block pair (a <= b) over the list of points both cameras see, built once
+// per problem; blocks recomputed from the camera rows and the gathered point; no atomics -- and the SAME
+// preconditioned conjugate gradients run inside one workgroup with S in LDS: an iteration is a 66 x 66
+// matrix-vector product by 256 threads and two block reductions, a few hundred cycles instead of two launches.
+// The preconditioner is the inverse of the diagonal 6x6 blocks of S, i.e. exactly the Schur-diagonal
+// preconditioner of the implicit path: both paths walk through the same iterates up to rounding.
+// (Round 2 factorised S instead: blocked Cholesky with the trailing updates on v_mfma_f64_16x16x4_f64.  33 us at
+// 66 unknowns -- the 16-step diagonal tiles and panel substitutions are serial code for one wavefront -- and its
+// exact steps carried rounding noise along the seven gauge directions that no camera being fixed leaves open.)
 // ---------------------------------------------------------------------------------------------
 constexpr int kDenseMaxN = 128;                  // 6 C <= 128: C <= 21
-constexpr int kDenseTile = 16;
-// No camera is held fixed (bundle_adjustment.py:6, sfm.py:264), so S is singular along the 7 gauge directions up to
-// the Levenberg-Marquardt term, which scipy's rule lets fall to 1e-10 of the diagonal: the last pivots are then
-// rounding noise.  An unknown whose pivot does not exceed this fraction of its original diagonal entry is dropped
-// from the solve (its step is 0, its column decoupled): a basic solution of the consistent singular system.
-constexpr double kDensePivotTol = 1e-14;
-
 __host__ __device__ constexpr int dense_block_index(int a, int b, int C) {      // a <= b, row-major upper triangle
     return a * C - a * (a - 1) / 2 + (b - a);
 }
@@ -2030,171 +2039,183 @@ __global__ __launch_bounds__(kCamThreads) void k_schur_blocks(const int* __restr
     if (threadIdx.x < 36) Sblk[(size_t)blockIdx.x * 36 + threadIdx.x] = tot;
 }
 
-typedef double dense_acc_t __attribute__((ext_vector_type(4)));
-
-// Solve (U + Dc - blk) dc = -g_c - acc for the camera step.  One workgroup of 256 threads; the matrix lives in LDS
-// as (T + 1) x T tiles of 16 x 16 (lower triangle used; tile row T carries the right-hand side in its first row),
-// leading dimension npad + 1.  The step goes to x of PCG vector set 0 and the control block says "converged, 0
-// iterations, set 0", which is what the back substitution and the host read; a non-positive pivot reports a
-// breakdown (done = 3) with a zero step, like the PCG does.
-__global__ __launch_bounds__(256) void k_dense_schur_solve(const double* __restrict__ Sblk, const double* __restrict__ Ugc,
-                                                           const double* __restrict__ Dc, const double* __restrict__ acc,
-                                                           int C, double* __restrict__ vecs, PcgCtrl* __restrict__ ctrl2) {
+// Solve (U + Dc - blk) dc = -g_c - acc by block-preconditioned CG in LDS (see above).  One workgroup of 512
+// threads; S full and symmetric, leading dimension n | 1; four lanes per row of the matrix-vector product, the
+// first of them owns x, r, p, s of its unknown in registers.  The recurrences are those of the implicit PCG below
+// (single reduction per iteration, Chronopoulos-Gear):
+//     u = M^-1 r;  w = S u;  gamma = r.u;  delta = w.u;  beta = gamma / gamma_prev;
+//     alpha = gamma / (delta - beta gamma / alpha_prev);  p = u + beta p;  s = w + beta s;  x += alpha p;  r -= alpha s
+// so an iteration is three barriers and four LDS round trips; the lane's 32 entries of S stay in registers.
+// (Measured with s_memtime at 66 unknowns: the first version -- textbook CG, 256 threads, S read from LDS in a
+// 9-trip loop -- spent 5600 cycles per iteration, all of it exposed LDS latency.)  The step goes to x of both PCG vector sets and the control block reports
+// iterations and outcome like the implicit PCG does (1 converged, 2 iteration cap, 3 breakdown: x is the last good
+// iterate).  Every sum has a fixed order: same input, same bits.
+constexpr int kDenseThreads = 512, kDenseLanes = 4;      // (1024 x 8: 128 registers per lane, spills; 256 x 2: slower)
+__device__ __forceinline__ double dense_rcp(double d) {         // v_rcp_f64 + one Newton step
+    const double y = __builtin_amdgcn_rcp(d);
+    return fma(fma(-d, y, 1.0), y, y);
+}
+__global__ __launch_bounds__(kDenseThreads) void k_dense_pcg(const double* __restrict__ Sblk, const double* __restrict__ Ugc,
+                                                             const double* __restrict__ Dc, const double* __restrict__ acc,
+                                                             int C, double tol, int max_iters, double* __restrict__ vecs,
+                                                             PcgCtrl* __restrict__ ctrl2) {
     extern __shared__ __align__(16) double A[];
-    __shared__ double sv[kDenseTile];
-    __shared__ int s_bad;
-    const int n = 6 * C, T = (n + kDenseTile - 1) / kDenseTile, npad = T * kDenseTile, ld = npad + 1;
-    // behind the matrix in the dynamic region (the static part of a kernel that asks for the full 160 KiB has to
-    // stay small): solution, diagonal of S before elimination, unknowns dropped from the solve (kDensePivotTol)
-    double* xv = A + (size_t)(npad + kDenseTile) * ld;
-    double* dg = xv + kDenseMaxN;
-    double* rdg = dg + kDenseMaxN;              // 1 / L_jj (0 for a dropped unknown)
-    double* bsum = rdg + kDenseMaxN;            // [16][16] partial sums of the back substitution
-    int* skipf = reinterpret_cast<int*>(bsum + kDenseTile * kDenseTile);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int kWaves = kDenseThreads / 64;
+    const int n = 6 * C, ld = n | 1;
+    double* rv = A + (size_t)n * ld;            // behind the matrix: r, u, the 6x6 inverses, reduction slots
+    double* uv = rv + kDenseMaxN;
+    double* mi = uv + kDenseMaxN;               // [C][21] packed upper triangles, padded to a multiple of 16 bytes
+    double* red = mi + ((21 * kDenseMaxN / 6 + 1) & ~1);      // [2 rounds][waves][gamma, delta]
+    const int tid = threadIdx.x;
+    const int row = tid / kDenseLanes, sub = tid & (kDenseLanes - 1);
+    const bool owner = sub == 0 && row < n;
     auto at = [&](int r, int c) -> double& { return A[(size_t)r * ld + c]; };
-    if (tid == 0) s_bad = 0;
-    for (int e = tid; e < (npad + kDenseTile) * ld; e += blockDim.x) A[e] = 0.0;
-    __syncthreads();
-    // lower triangle from the blocks: entry (6b+v, 6a+u), a <= b, is -blk[a][b][u][v] (+ U, Dc on the diagonal blocks)
-    const int nblk = C * (C + 1) / 2;
-    for (int e = tid; e < nblk * 36; e += blockDim.x) {
-        const int blk = e / 36, uv = e - blk * 36, u = uv / 6, v = uv - 6 * u;
-        int a = 0, rem = blk;
-        while (rem >= C - a) { rem -= C - a; ++a; }                 // blk = dense_block_index(a, b): small C
-        const int b = a + rem;
-        double val = -Sblk[e];
-        if (a == b) {
-            if (u > v) continue;                                     // diagonal block: take (u <= v), store at row v, col u
-            val += Ugc[(size_t)a * 27 + (u * 6 - u * (u - 1) / 2 + (v - u))];
-            if (u == v) val += Dc[(size_t)u * C + a];
-        }
-        at(6 * b + v, 6 * a + u) = val;
+    // entry e of the block list -> (a, b, u, v) without a table: blk = a C - a (a - 1) / 2 + (b - a), a <= b
+    auto decode = [&](int e, int& a_, int& b_, int& u, int& v) {
+        const int blk = e / 36, uvi = e - blk * 36;
+        u = uvi / 6; v = uvi - 6 * u;
+        const float t = (float)(2 * C + 1);
+        int a = (int)((t - sqrtf(t * t - 8.0f * (float)blk)) * 0.5f);
+        while (a > 0 && dense_block_index(a, a, C) > blk) --a;
+        while (a + 1 < C && dense_block_index(a + 1, a + 1, C) <= blk) ++a;
+        a_ = a; b_ = a + (blk - dense_block_index(a, a, C));
+    };
+    double x = 0.0, r = 0.0, pp = 0.0, ss = 0.0;
+    if (owner) {                                                         // right-hand side
+        const int c = row / 6, k = row - 6 * c;
+        r = -Ugc[(size_t)c * 27 + 21 + k] - acc[(size_t)k * C + c];
+        rv[row] = r;
     }
-    for (int e = n + tid; e < npad; e += blockDim.x) at(e, e) = 1.0;  // padding: identity
-    __syncthreads();
-    for (int e = tid; e < npad; e += blockDim.x) { dg[e] = at(e, e); skipf[e] = 0; }
-    for (int e = tid; e < n; e += blockDim.x) {                       // right-hand side row
-        const int c = e / 6, k = e - 6 * c;
-        at(npad, e) = -Ugc[(size_t)c * 27 + 21 + k] - acc[(size_t)k * C + c];
-    }
-    __syncthreads();
-    for (int k = 0; k < T; ++k) {
-        const int o = k * kDenseTile;
-        if (wave == 0) {                          // diagonal tile: lanes 0..15 hold one row each (registers + v_readlane)
-            const int row = lane & 15;
-            double a[kDenseTile];
+    {   // S from the blocks: entries (6a+u, 6b+v) and (6b+v, 6a+u), a <= b, are -blk[a][b][u][v] (+ U, Dc on the
+        // diagonal blocks, whose half u <= v is mirrored); six entries per thread and trip with all their global
+        // loads in flight together (the block list was written by the previous launch on other XCDs: every dependent
+        // round trip costs a microsecond)
+        const int nent = C * (C + 1) / 2 * 36;
+        constexpr int kB = 6;
+        for (int e0 = tid; e0 < nent; e0 += kB * kDenseThreads) {
+            double val[kB], add[kB];
+            int rr[kB], cc[kB];
 #pragma unroll
-            for (int c = 0; c < kDenseTile; ++c) a[c] = at(o + row, o + c);
-            bool bad = false;
-#pragma unroll
-            for (int j = 0; j < kDenseTile; ++j) {
-                double s = a[j];
-#pragma unroll
-                for (int q = 0; q < j; ++q) s -= a[q] * readlane_double(a[q], j);
-                const double d = readlane_double(s, j);
-                if (!isfinite(d)) bad = true;
-                const bool sk = !(d > kDensePivotTol * dg[o + j]);            // wave-uniform
-                const double rpiv = sk ? 1.0 : rsqrt(d);                      // one reciprocal square root instead of
-                const double piv = sk ? 1.0 : d * rpiv;                       // a square root and a division per column
-                a[j] = (row == j) ? piv : (sk ? 0.0 : s * rpiv);
-                if (lane == 0) { skipf[o + j] = sk ? 1 : 0; rdg[o + j] = sk ? 0.0 : rpiv; }
-            }
-            if (lane < kDenseTile) {
-#pragma unroll
-                for (int c = 0; c < kDenseTile; ++c) at(o + row, o + c) = (c <= row) ? a[c] : 0.0;
-                if (bad && lane == 0) s_bad = 1;
-            }
-        }
-        __syncthreads();
-        {   // panel below the diagonal tile (and the right-hand-side row): x L_kk^T = a, one row per thread
-            const int r = o + kDenseTile + tid;
-            if (r < npad + 1) {
-                double x[kDenseTile];
-#pragma unroll
-                for (int c = 0; c < kDenseTile; ++c) x[c] = at(r, o + c);
-#pragma unroll
-                for (int j = 0; j < kDenseTile; ++j) {
-                    double s = x[j];
-#pragma unroll
-                    for (int q = 0; q < j; ++q) s -= x[q] * at(o + j, o + q);
-                    x[j] = s * rdg[o + j];                            // 1 / L_jj, 0 for a dropped unknown
+            for (int q = 0; q < kB; ++q) {
+                const int e = e0 + q * kDenseThreads;
+                val[q] = 0.0; add[q] = 0.0; rr[q] = -1; cc[q] = 0;
+                if (e < nent) {
+                    int a, b, u, v;
+                    decode(e, a, b, u, v);
+                    if (a == b && u > v) continue;
+                    val[q] = Sblk[e];
+                    if (a == b) {
+                        add[q] = Ugc[(size_t)a * 27 + (u * 6 - u * (u - 1) / 2 + (v - u))];
+                        if (u == v) add[q] += Dc[(size_t)u * C + a];
+                    }
+                    rr[q] = 6 * a + u; cc[q] = 6 * b + v;
                 }
+            }
 #pragma unroll
-                for (int c = 0; c < kDenseTile; ++c) at(r, o + c) = x[c];
+            for (int q = 0; q < kB; ++q) {
+                if (rr[q] < 0) continue;
+                const double sv = add[q] - val[q];
+                at(rr[q], cc[q]) = sv;
+                at(cc[q], rr[q]) = sv;
             }
         }
+    }
+    __syncthreads();
+    if (tid < C) {                               // preconditioner: thread c inverts the diagonal block of camera c
+        double B[6][6], out[21];                 // (from LDS: gathered from global memory, its 63 strided loads per
+#pragma unroll                                   // lane cost the texture addresser more than the whole fill)
+        for (int u = 0; u < 6; ++u)
+#pragma unroll
+            for (int v = 0; v < 6; ++v) B[u][v] = at(6 * tid + u, 6 * tid + v);
+        spd6_inverse(B, out);
+#pragma unroll
+        for (int k = 0; k < 21; ++k) mi[21 * tid + k] = out[k];
+    }
+    // this lane's part of its row of S stays in registers for the whole solve
+    double sv[kDenseMaxN / kDenseLanes];
+#pragma unroll
+    for (int q = 0; q < kDenseMaxN / kDenseLanes; ++q) {
+        const int j = sub + q * kDenseLanes;
+        sv[q] = (row < n && j < n) ? at(row, j) : 0.0;
+    }
+    __syncthreads();
+    const double tol2 = tol * tol;
+    double gamma = 0.0, gamma0 = 0.0, inv_gamma_prev = 1.0, inv_alpha_prev = 1.0;
+    int it = 0, done = 0;
+    const int cam = row / 6, kk = row - 6 * cam;
+    for (;;) {
+        // u = M^-1 r (r of the camera's six unknowns from LDS), published for the product
+        double u = 0.0;
+        if (owner) {
+            u = minv_row(mi + 21 * cam, rv + 6 * cam, kk);
+            uv[row] = u;
+        }
         __syncthreads();
-        // trailing update on the matrix cores: tile (i, j), k < j <= i <= T: A_ij -= L_ik L_jk^T
+        // w = S u: four lanes per row, up to 32 independent products per lane (S from registers, u from LDS:
+        // lanes with the same `sub` read the same words), the lanes add up by DPP
+        double w = 0.0;
+        if (row < n) {
+            double s4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < kDenseMaxN / kDenseLanes; ++q) {
+                const int j = sub + q * kDenseLanes;
+                if (q * kDenseLanes < n) s4[q & 3] = fma(sv[q], uv[j < n ? j : 0], s4[q & 3]);      // (wave-uniform test)
+            }
+            w = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        }
+        static_assert(kDenseLanes == 4, "the lanes of a row are one quad");
+        w += dpp_double<0xB1>(w);                                        // quad_perm [1,0,3,2]
+        w += dpp_double<0x4E>(w);                                        // quad_perm [2,3,0,1]
+        // gamma = r.u, delta = w.u: waves in wave order
         {
-            const int m = T - k;                          // tile rows k+1 .. T  (T = the right-hand-side row block)
-            const int ntile = m * (m + 1) / 2 - (T > k ? 1 : 0);      // lower triangle of (m x m) without (T, T)
-            for (int t = wave; t < ntile; t += (int)(blockDim.x >> 6)) {
-                int ii = 0, rem = t;
-                while (rem > ii) { rem -= ii + 1; ++ii; }             // t -> (ii, jj) with jj <= ii, row-major lower
-                const int i = k + 1 + ii, j = k + 1 + rem;
-                const int ri = i * kDenseTile, rj = j * kDenseTile;
-                dense_acc_t c;
+            const double g = wave_sum(owner ? r * u : 0.0), d = wave_sum(owner ? w * u : 0.0);
+            double* __restrict__ slot = red + (size_t)(it & 1) * 2 * kWaves;
+            if ((tid & 63) == 0) { slot[2 * (tid >> 6)] = g; slot[2 * (tid >> 6) + 1] = d; }
+            __syncthreads();
+            double2 t2[4];                                               // four chains over the waves, fixed order
 #pragma unroll
-                for (int q = 0; q < 4; ++q) c[q] = at(ri + (lane >> 4) + 4 * q, rj + (lane & 15));
+            for (int k = 0; k < 4; ++k) t2[k] = reinterpret_cast<const double2*>(slot)[k];
 #pragma unroll
-                for (int mch = 0; mch < 4; ++mch) {
-                    const double av = -at(ri + (lane & 15), o + 4 * mch + (lane >> 4));
-                    const double bv = at(rj + (lane & 15), o + 4 * mch + (lane >> 4));
-                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, c, 0, 0, 0);
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) at(ri + (lane >> 4) + 4 * q, rj + (lane & 15)) = c[q];
+            for (int k = 4; k < kWaves; ++k) {
+                const double2 v = reinterpret_cast<const double2*>(slot)[k];
+                t2[k & 3].x += v.x; t2[k & 3].y += v.y;
             }
+            t2[0].x = (t2[0].x + t2[1].x) + (t2[2].x + t2[3].x);
+            t2[0].y = (t2[0].y + t2[1].y) + (t2[2].y + t2[3].y);
+            const double ds = t2[0].y;
+            gamma = t2[0].x;
+            if (it == 0) {
+                gamma0 = gamma;
+                if (!(gamma0 > 0.0)) { done = gamma0 == 0.0 ? 1 : 3; break; }        // zero right-hand side: x = 0
+            } else if (!(gamma > tol2 * gamma0)) { done = 1; break; }                // also catches NaN
+            if (it >= max_iters) { done = 2; break; }
+            // (reciprocals by v_rcp_f64 + one Newton step: three divisions were a quarter of the iteration)
+            const double beta = it == 0 ? 0.0 : gamma * inv_gamma_prev;
+            const double den = ds - (it == 0 ? 0.0 : beta * gamma * inv_alpha_prev);
+            const double inv_den = dense_rcp(den);
+            const double alpha = gamma * inv_den;
+            if (!(den > 0.0) || !isfinite(alpha)) { done = 3; break; }               // S not positive definite / NaN
+            if (owner) {
+                pp = fma(beta, pp, u);
+                ss = fma(beta, ss, w);
+                x = fma(alpha, pp, x);
+                r = fma(-alpha, ss, r);
+                rv[row] = r;
+            }
+            inv_gamma_prev = dense_rcp(gamma); inv_alpha_prev = den * inv_gamma_prev;
+            ++it;
         }
         __syncthreads();
     }
-    // back substitution L^T x = y (y = the right-hand-side row after the forward sweep)
-    for (int k = T - 1; k >= 0; --k) {
-        const int o = k * kDenseTile;
-        {   // s_t = y_t - sum_{r below the tile} L[r][t] x_r : 16 columns x 16 row groups, then the groups in order
-            const int t = tid & 15, g = tid >> 4;
-            double s = 0.0;
-            for (int r = o + kDenseTile + g; r < npad; r += 16) s += at(r, o + t) * xv[r];
-            bsum[g * kDenseTile + t] = s;
-        }
-        __syncthreads();
-        if (tid < kDenseTile) {
-            double s = at(npad, o + tid);
-#pragma unroll
-            for (int g = 0; g < 16; ++g) s -= bsum[g * kDenseTile + tid];
-            sv[tid] = s;
-        }
-        __syncthreads();
-        if (wave == 0) {
-            const int t = lane & 15;
-            double cl[kDenseTile];
-#pragma unroll
-            for (int q = 0; q < kDenseTile; ++q) cl[q] = at(o + q, o + t);           // column t of L_kk
-            double s = sv[t], xres = 0.0;
-#pragma unroll
-            for (int j = kDenseTile - 1; j >= 0; --j) {
-                const double xj = readlane_double(s * rdg[o + j], j);            // rdg = 0 for a dropped unknown
-                s -= cl[j] * xj;
-                if (t == j) xres = xj;
-            }
-            if (lane < kDenseTile) xv[o + t] = xres;
-        }
-        __syncthreads();
-    }
-    const bool bad = s_bad != 0;
-    const size_t n6 = (size_t)n;
-    for (int e = tid; e < n; e += blockDim.x) {
-        const int c = e / 6, k = e - 6 * c;
-        const double x = xv[e];
-        vecs[kPcgX * n6 + (size_t)k * C + c] = (bad || !isfinite(x)) ? 0.0 : x;
+    if (owner) {
+        const double xo = isfinite(x) ? x : 0.0;
+        vecs[kPcgX * (size_t)n + (size_t)kk * C + cam] = xo;                         // both vector sets: the back
+        vecs[(kPcgVecs + kPcgX) * (size_t)n + (size_t)kk * C + cam] = xo;            // substitution picks one by count
     }
     if (tid == 0) {
         PcgCtrl c0;
-        c0.rz = 0.0; c0.rz0 = 0.0; c0.tol2 = 0.0; c0.rz_prev = 1.0; c0.alpha_prev = 1.0;
-        int nskip = 0;
-        for (int e = 0; e < n; ++e) nskip += skipf[e];
-        c0.iters = 0; c0.max_iters = nskip; c0.done = bad ? 3 : 1; c0.pad = 2;     // max_iters: unknowns dropped
+        c0.rz = gamma; c0.rz0 = gamma0; c0.tol2 = tol2; c0.rz_prev = 1.0 / inv_gamma_prev; c0.alpha_prev = 1.0 / inv_alpha_prev;
+        c0.iters = it; c0.max_iters = max_iters; c0.done = done; c0.pad = 2;
         ctrl2[0] = c0;
         ctrl2[1] = c0;
     }

@@ -726,22 +726,22 @@ int launch_rhs_and_preconditioner(sfmba_handle* h) {
     return 0;
 }
 
-// Dense reduced-camera path: form the block pairs of W V^-1 W^T, factorise S = U + Dc - (...) in one workgroup and
-// leave the camera step where the PCG would have left it (x of vector set 0, control block "converged").
+// Few cameras: form the block pairs of W V^-1 W^T, then run the PCG on S = U + Dc - (...) inside one workgroup with
+// S in LDS; the camera step and the control block are left where the implicit PCG leaves them (x of vector set 0).
 // acc must hold the reduced right-hand-side term (pass B, MODE 1).
-int launch_dense_solve(sfmba_handle* h) {
+constexpr double kDenseTolFactor = 0.1;
+int launch_dense_solve(sfmba_handle* h, double tol, int max_iters) {
     hipLaunchKernelGGL(k_schur_blocks, dim3(h->n_blk), dim3(kCamThreads), 0, h->stream, (const int*)h->cov_ptr.as<int>(),
                        (const int*)h->cov_pt.as<int>(), (const int2*)h->blk_ab.as<int2>(), (const double*)h->tab,
                        (const double*)(h->x + 6 * h->C), (const double*)h->Vinv.as<double>(), h->K, h->Sblk.as<double>());
     LAUNCHED(h);
-    const int n = 6 * (int)h->C, npad = (n + kDenseTile - 1) / kDenseTile * kDenseTile;
-    const size_t lds = sizeof(double) * ((size_t)(npad + kDenseTile) * (size_t)(npad + 1) + 3 * kDenseMaxN +
-                                         kDenseTile * kDenseTile) + sizeof(int) * kDenseMaxN;
-                                         // matrix | solution | diagonal | 1 / L_jj | partial sums | dropped flags
-    CHK(set_lds(h, k_dense_schur_solve, lds));
-    hipLaunchKernelGGL(k_dense_schur_solve, dim3(1), dim3(256), lds, h->stream, (const double*)h->Sblk.as<double>(),
-                       (const double*)h->Ugc(), (const double*)h->Dc.as<double>(), (const double*)h->acc(), (int)h->C,
-                       h->vecs.as<double>(), h->ctrl.as<PcgCtrl>());
+    const int n = 6 * (int)h->C;
+    const size_t lds = sizeof(double) * ((size_t)n * (size_t)(n | 1) + 2 * kDenseMaxN + ((21 * kDenseMaxN / 6 + 1) & ~1) +
+                                         4 * (kDenseThreads / 64));      // matrix | r u | 6x6 inverses | reduction slots
+    CHK(set_lds(h, k_dense_pcg, lds));
+    hipLaunchKernelGGL(k_dense_pcg, dim3(1), dim3(kDenseThreads), lds, h->stream, (const double*)h->Sblk.as<double>(),
+                       (const double*)h->Ugc(), (const double*)h->Dc.as<double>(),
+                       (const double*)h->acc(), (int)h->C, tol, max_iters, h->vecs.as<double>(), h->ctrl.as<PcgCtrl>());
     LAUNCHED(h);
     h->pcg_L = 0;
     return 0;
@@ -1787,7 +1787,7 @@ int sfmba_dense_schur(sfmba_handle* h, const double* x, const double* dc, const 
                        h->gp.as<double>(), (const double*)nullptr, h->e.as<double>(), (int)h->P, 0.0,
                        h->Vinv.as<double>(), (double*)nullptr);
     LAUNCHED(h);
-    CHK(launch_dense_solve(h));
+    CHK(launch_dense_solve(h, 1e-14, 40 * 6 * (int)C));      // (test entry: to the end, to be compared with a direct solve)
     std::vector<double> blk(36 * (size_t)h->n_blk), sol(6 * C);
     HIPCHK(h, hipMemcpyAsync(blk.data(), h->Sblk.p, sizeof(double) * blk.size(), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(sol.data(), h->vecs.p, sizeof(double) * 6 * C, hipMemcpyDeviceToHost, h->stream));
@@ -2028,7 +2028,9 @@ static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt
         if (!dense) CHK(pcg_start(h, opt));                     // replaces lsmr, trf.py:477-480
         PcgCtrl hc{};
         if (dense) {
-            CHK(launch_dense_solve(h));                         // exact solve of the reduced camera system
+            // the same PCG inside one workgroup; an iteration there costs a twentieth of the two launches of the
+            // implicit product, so the forcing term is a decade tighter (cfg2: 5 outer iterations instead of 7)
+            CHK(launch_dense_solve(h, kDenseTolFactor * opt.pcg_tol, pcg_max_iters(h, opt)));
         } else if (pcg_guess > 0) {
             // speculative: no read-back; surplus launches are no-ops.  Fused launches apply the update of
             // iteration k in launch k + 1, so k iterations need k + 1 launches; one spare either way.
@@ -2146,8 +2148,8 @@ static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt
         if (status != -1 || nfev >= max_nfev || (opt.max_iter > 0 && iteration >= opt.max_iter)) break;
         pcg_total += hc.iters;
         if (pcg_debug && dense)
-            fprintf(stderr, "sfmba: iteration %lld: dense solve, %d unknowns dropped, reg %.3e\n", (long long)iteration,
-                    hc.max_iters, h->h_scal[kRegSlot]);
+            fprintf(stderr, "sfmba: iteration %lld: PCG in LDS, %d iterations, outcome %d, reg %.3e\n", (long long)iteration,
+                    hc.iters, hc.done, h->h_scal[kRegSlot]);
         else if (pcg_debug)
             fprintf(stderr, "sfmba: iteration %lld: PCG enqueued %d, needed %d%s\n", (long long)iteration,
                     pcg_enqueued, hc.iters, missed ? " (miss)" : "");

@@ -93,7 +93,7 @@ def test_apply_bundle_adjustment_end_to_end(orc):
     assert (pn_cam, pn_pts, pcmap) == (n_cam, n_pts, cmap) and n_cam == 6
     assert np.array_equal(pci, ci) and np.array_equal(ppi, pi) and np.array_equal(puv, uv)
     assert np.abs(px0 - x0).max() < 1e-13
-    o = orc.trf_schur(x0, n_cam, n_pts, ci, pi, uv, K, ftol=1e-10, linear="dense")     # 6 cameras: dense path
+    o = orc.trf_schur(x0, n_cam, n_pts, ci, pi, uv, K, ftol=1e-10, linear="pcg", pcg_tol=1e-3, precond="schur_exact")     # 6 cameras: PCG in LDS
     H_ref, X_ref = orc.unpack_result(o.x, n_cam, n_pts, cmap, H0)
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):

@@ -270,9 +270,21 @@ def test_results_are_bitwise_reproducible(be):
 # ---- A5-A9: the solver -------------------------------------------------------------------------------
 
 def _oracle_kwargs(dense):
-    """The reduced camera system is solved exactly (formed and factorised) when 6 C <= 128, by block-Jacobi PCG to
-    1e-2 otherwise or when the debug option `dense` is 0: the oracle restates both."""
-    return dict(linear="dense") if dense else dict(linear="pcg", pcg_tol=1e-2, precond="schur")
+    """The reduced camera system is solved by PCG to 1e-2 with the Schur-diagonal block preconditioner: with the
+    implicit product (two launches per iteration), or, when 6 C <= 128 (`dense`), with S formed and the iterations
+    inside one workgroup.  Same algorithm, so one restatement in the oracle."""
+    if dense:         # in LDS: a decade tighter, and the preconditioner blocks are those of the formed matrix
+        return dict(linear="pcg", pcg_tol=1e-3, precond="schur_exact")
+    return dict(linear="pcg", pcg_tol=1e-2, precond="schur")
+
+
+def _ran_dense(be, calls):
+    """Which path ran: the in-LDS PCG needs ~15 launches per outer iteration whatever its iteration count, the
+    implicit one two more per PCG iteration."""
+    l0 = be.counters()[0]
+    out = calls()
+    launches = be.counters()[0] - l0
+    return out, launches < 17 * (out.nfev + 1) and out.pcg_iterations > 0
 
 
 def test_solve_matches_scipy_on_tiny_problems(orc, dbg):
@@ -287,9 +299,10 @@ def test_solve_matches_scipy_on_tiny_problems(orc, dbg):
         C, P, N = (int(v) for v in g[pre + "dims"])
         pb = sfmba.make_problem(C, P, N, seed=int(g[pre + "seed"]))
         status, nfev, njev, cost, rmse, opt = g[pre + "summary"]
-        res = sfmba.least_squares(sfmba.compute_residuals, pb.x0, jac_sparsity=None, verbose=0,
-                                  x_scale="jac", ftol=1e-10, method="trf", args=pb.args)
-        assert (res.pcg_iterations == 0) == dense
+        res, ran_dense = _ran_dense(sfmba.get_backend(0), lambda: sfmba.least_squares(
+            sfmba.compute_residuals, pb.x0, jac_sparsity=None, verbose=0, x_scale="jac", ftol=1e-10, method="trf",
+            args=pb.args))
+        assert ran_dense == dense
         assert res.success and res.status in (1, 2, 3, 4)
         my_rmse = float(np.sqrt(np.mean(res.fun ** 2)))
         assert abs(my_rmse - rmse) < 1e-6
@@ -299,10 +312,7 @@ def test_solve_matches_scipy_on_tiny_problems(orc, dbg):
         # and against the oracle's restatement of the same algorithm
         o = orc.trf_schur(pb.x0, *pb.args, ftol=1e-10, **_oracle_kwargs(dense))
         assert abs(res.cost - o.cost) <= 1e-8 * o.cost
-        if dense:      # exact steps carry rounding noise along the gauge directions (see the rejected-steps test): the
-            assert res.status in (2, 3, 4) and abs(res.nfev - o.nfev) <= 2      # last, tiny steps may split differently
-        else:
-            assert (res.status, res.nfev, res.njev) == (o.status, o.nfev, o.njev)
+        assert (res.status, res.nfev, res.njev) == (o.status, o.nfev, o.njev)
         # result.fun / result.grad are consistent with result.x
         r = orc.compute_residuals(res.x, *pb.args)
         assert np.abs(r - res.fun).max() < 1e-8
@@ -331,11 +341,7 @@ def test_rejected_steps_and_nfev_limit_follow_the_oracle(orc, dbg, dense):
     with a smaller radius, speculative normal blocks discarded) and the max_nfev exit must follow the
     oracle's restatement of trf_no_bounds.
 
-    With the exact (dense) step the comparison is made on what the problem determines.  No camera is held fixed
-    (bundle_adjustment.py:6), so the reduced camera matrix is singular along the 7 gauge directions up to the
-    damping term; the component of an exact step along them is rounding noise over that term and differs between
-    numpy's pivoted LU and the in-LDS Cholesky.  It moves x (and the step norm of the xtol test, so the final status
-    may read 2 where the oracle's reads 4) but neither cost nor residuals."""
+    Both forms of the PCG (implicit product / S in LDS) are held to the same standard."""
     import sfmba
     dbg((sfmba.get_backend(0),), "dense", -1 if dense else 0)
     saw_rejection = False
@@ -344,12 +350,8 @@ def test_rejected_steps_and_nfev_limit_follow_the_oracle(orc, dbg, dense):
         o = orc.trf_schur(pb.x0, *pb.args, ftol=1e-10, **_oracle_kwargs(dense))
         res = sfmba.least_squares(sfmba.compute_residuals, pb.x0, x_scale="jac", ftol=1e-10, method="trf",
                                   args=pb.args)
-        if dense:
-            assert res.status in (2, 3, 4) and o.status in (2, 3, 4)
-            assert abs(res.nfev - o.nfev) <= 1 and abs(res.njev - o.njev) <= 1
-        else:
-            assert res.status == o.status
-            assert (res.nfev, res.njev) == (o.nfev, o.njev)
+        assert res.status == o.status
+        assert (res.nfev, res.njev) == (o.nfev, o.njev)
         assert abs(res.cost - o.cost) <= 1e-8 * o.cost
         saw_rejection |= res.nfev > res.njev
     assert saw_rejection
@@ -359,11 +361,10 @@ def test_rejected_steps_and_nfev_limit_follow_the_oracle(orc, dbg, dense):
         res = sfmba.least_squares(sfmba.compute_residuals, pb.x0, x_scale="jac", ftol=1e-10, method="trf",
                                   args=pb.args, max_nfev=max_nfev)
         assert res.status == o.status == 0 and res.nfev == o.nfev == max_nfev
-        assert abs(res.cost - o.cost) <= 1e-8 * o.cost
-        if dense:
-            assert np.abs(res.fun - o.fun).max() <= 1e-5 * max(1.0, np.abs(o.fun).max())
-        else:
-            assert np.abs(res.x - o.x).max() <= 1e-6 * np.abs(o.x).max()
+        # unconverged iterates of a far start amplify last-bit differences (the in-LDS iterations use v_rcp-based
+        # reciprocals and other sum orders than the oracle): two more digits of slack there
+        assert abs(res.cost - o.cost) <= (1e-6 if dense else 1e-8) * o.cost
+        assert np.abs(res.x - o.x).max() <= (1e-4 if dense else 1e-6) * np.abs(o.x).max()
         r = orc.compute_residuals(res.x, *pb.args)
         assert np.abs(r - res.fun).max() < 1e-8            # result.fun belongs to result.x
 
@@ -482,10 +483,7 @@ def test_ring_scene_large_rotations(orc, dbg, dense):
                               args=pb.args)
     o = orc.trf_schur(pb.x0, *pb.args, ftol=1e-10, **_oracle_kwargs(dense))
     assert res.success and abs(res.rmse - rmse) < 1e-6 and res.cost <= cost * (1 + 1e-9)
-    if dense:          # gauge noise of the exact step (see the rejected-steps test)
-        assert res.status in (2, 3, 4) and abs(res.nfev - o.nfev) <= 2
-    else:
-        assert (res.status, res.nfev, res.njev) == (o.status, o.nfev, o.njev)
+    assert (res.status, res.nfev, res.njev) == (o.status, o.nfev, o.njev)
     assert abs(res.cost - o.cost) <= 1e-9 * o.cost
     assert np.abs(res.fun - g["ring_fun"]).max() < 5e-2
 
@@ -787,13 +785,12 @@ def test_two_rank_solve_on_one_gpu_gloo(dbg):
     assert np.abs(out["x"] - ref.x).max() <= 1e-6 * np.abs(ref.x).max()
 
 
-# ---- dense reduced-camera path (few cameras): S formed and factorised, MFMA f64 Cholesky ---------------------------
+# ---- few cameras: S formed, the PCG inside one workgroup with S in LDS ---------------------------------------------
 
-def test_dense_reduced_camera_matrix_and_cholesky(be, orc):
-    """6 C <= 128: the reduced camera matrix is formed block pair by block pair and factorised in LDS (blocked
-    Cholesky, trailing updates on v_mfma_f64_16x16x4_f64).  S against the oracle's explicit Schur complement, the
-    solve against numpy's, for sizes that exercise 1 ... 8 tiles of 16, padding, duplicated (camera, point) pairs,
-    an unobserved camera."""
+def test_dense_reduced_camera_matrix_and_in_lds_pcg(be, orc):
+    """6 C <= 128: the reduced camera matrix is formed block pair by block pair and the PCG runs inside one workgroup
+    with S in LDS.  S against the oracle's explicit Schur complement, the solve (run to the end through the test
+    entry) against numpy's, for 2 ... 21 cameras, duplicated (camera, point) pairs, an unobserved camera."""
     import sfmba
     rng = np.random.default_rng(7)
     for C, P, N, seed in ((2, 12, 40, 1), (3, 8, 20, 0), (5, 40, 200, 9), (11, 300, 2000, 2), (16, 200, 1500, 4),

@@ -10,7 +10,7 @@ pb = sfmba.make_config(cfg)
 be = sfmba.Backend(0)
 be.set_precision(bits)
 be.set_problem(*pb.args)
-for tol in (1e-3, 3e-3, 1e-2, 3e-2, 1e-1, 3e-1):
+for tol in (1e-8, 1e-6, 1e-4, 1e-3, 3e-3, 1e-2, 3e-2, 1e-1, 3e-1):
     opt = be.default_options()
     opt.ftol = 1e-10
     opt.pcg_tol = tol
