@@ -30,7 +30,8 @@
 
 namespace sfmba {
 
-constexpr int kCamTab = 17;          // doubles per camera-table row
+constexpr int kCamTab = 17;          // entries of a camera-table row: R (9) T (3) w (3) b c
+constexpr int kCamRow = 18;          // ... and its stride: rows are 16-byte aligned (nine 16-byte loads per row)
 constexpr int kRec = 6;              // doubles per point record X Y Z | z0 z1 z2 (see k_fill_rec)
 constexpr int kSweepThreads = 1024;  // one workgroup per CU, 16 waves sharing one LDS camera table
 constexpr int kWavesPerSweepBlock = kSweepThreads / 64;
@@ -285,11 +286,12 @@ __device__ __forceinline__ void store_pair(double* __restrict__ base, int f32, i
 // compact [C][12] = R | T that the recomputing Schur pass stages in LDS, and w, b, c plane-major [5][C] for its
 // one-thread-per-camera prologue.
 constexpr int kCamRT = 12, kCamWbc = 5;
-__host__ __device__ constexpr size_t cam_rt_offset(int C) { return ((size_t)C * kCamTab + 1) & ~(size_t)1; }   // 16-byte aligned
+__host__ __device__ constexpr size_t cam_rt_offset(int C) { return (size_t)C * kCamRow; }
 __host__ __device__ constexpr size_t cam_wbc_offset(int C) { return cam_rt_offset(C) + (size_t)C * kCamRT; }
 __host__ __device__ constexpr size_t cam_table_doubles(int C) { return cam_wbc_offset(C) + (size_t)C * kCamWbc; }
 __device__ __forceinline__ void cam_table_row(const double* __restrict__ prm, double* __restrict__ tab, int C, int c) {
-    double* __restrict__ t = tab + (size_t)c * kCamTab;
+    double* __restrict__ t = tab + (size_t)c * kCamRow;
+    t[kCamTab] = 0.0;
     const double wx = prm[0], wy = prm[1], wz = prm[2];
     const double th2 = wx * wx + wy * wy + wz * wz;
     const double th = sqrt(th2);
@@ -495,11 +497,10 @@ __global__ __launch_bounds__(kSweepThreads) void k_resjac(
     if (i + stride < N) { c1 = cam_idx[i + stride]; p1 = pt_idx[i + stride]; }
     if (i < N) { const double* __restrict__ Xp = pts + 3 * (size_t)p0; X0 = Xp[0]; Y0 = Xp[1]; Z0 = Xp[2]; }
     if (LDS_TAB) {                               // stage the camera table while those loads fly
-        const int n2 = (C * kCamTab) >> 1;
+        const int n2 = (C * kCamRow) >> 1;
         const double2* __restrict__ src = reinterpret_cast<const double2*>(camtab);
         double2* __restrict__ dst = reinterpret_cast<double2*>(smem);
         for (int k = threadIdx.x; k < n2; k += blockDim.x) dst[k] = src[k];
-        if (((C * kCamTab) & 1) && threadIdx.x == 0) smem[C * kCamTab - 1] = camtab[C * kCamTab - 1];
         __syncthreads();
     }
     const double* __restrict__ tab = LDS_TAB ? smem : camtab;
@@ -525,7 +526,13 @@ __global__ __launch_bounds__(kSweepThreads) void k_resjac(
             if (ib + 64 < N) pnext = pt_idx[ib + 64];
         }
         double jc[12], jp[6], rx, ry;
-        observe<JAC>(tab + c0 * kCamTab, X0, Y0, Z0, uv0.x, uv0.y, K, rx, ry, jc, jp);
+        double tl[kCamRow];                      // the camera row by nine 16-byte loads (LDS or, past 160 KiB, L2)
+        {
+            const double2* __restrict__ trow = reinterpret_cast<const double2*>(tab + (size_t)c0 * kCamRow);
+#pragma unroll
+            for (int k = 0; k < kCamRow / 2; ++k) { const double2 q = trow[k]; tl[2 * k] = q.x; tl[2 * k + 1] = q.y; }
+        }
+        observe<JAC>(tl, X0, Y0, Z0, uv0.x, uv0.y, K, rx, ry, jc, jp);
         if (on) {
             acc += rx * rx + ry * ry;
             if (STORE_R) {
@@ -740,7 +747,7 @@ __global__ __launch_bounds__(kCamThreads) void k_cam_blocks(CamMajor cm, const d
     const int4 ch = cm.chunks[blockIdx.x];
     double t[kCamTab];
 #pragma unroll
-    for (int k = 0; k < kCamTab; ++k) t[k] = camtab[(size_t)ch.x * kCamTab + k];      // wave-uniform: scalar loads
+    for (int k = 0; k < kCamTab; ++k) t[k] = camtab[(size_t)ch.x * kCamRow + k];      // wave-uniform: scalar loads
     double a[27];
 #pragma unroll
     for (int q = 0; q < 27; ++q) a[q] = 0.0;
@@ -1732,7 +1739,7 @@ __global__ __launch_bounds__(kCamThreads) void k_cam_schur(CamMajor cm, const do
     const size_t n6l = 6 * (size_t)C;
     double t[kCamTab];
 #pragma unroll
-    for (int k = 0; k < kCamTab; ++k) t[k] = camtab[(size_t)ch.x * kCamTab + k];      // wave-uniform: scalar loads
+    for (int k = 0; k < kCamTab; ++k) t[k] = camtab[(size_t)ch.x * kCamRow + k];      // wave-uniform: scalar loads
     double vc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     if (MODE == 0) {
 #pragma unroll
@@ -1910,7 +1917,7 @@ __global__ __launch_bounds__(kRhsThreads) void k_cam_rhs_diag(CamMajor cm, const
     const int4 ch = cm.chunks[blockIdx.x];
     double t[kCamTab];
 #pragma unroll
-    for (int k = 0; k < kCamTab; ++k) t[k] = camtab[(size_t)ch.x * kCamTab + k];      // wave-uniform: scalar loads
+    for (int k = 0; k < kCamTab; ++k) t[k] = camtab[(size_t)ch.x * kCamRow + k];      // wave-uniform: scalar loads
     double a[27];
 #pragma unroll
     for (int q = 0; q < 27; ++q) a[q] = 0.0;
@@ -1999,7 +2006,7 @@ __global__ __launch_bounds__(kCamThreads) void k_schur_blocks(const int* __restr
     const int2 ab = blk_ab[blockIdx.x];
     double ta[kCamTab], tb[kCamTab];
 #pragma unroll
-    for (int k = 0; k < kCamTab; ++k) { ta[k] = camtab[(size_t)ab.x * kCamTab + k]; tb[k] = camtab[(size_t)ab.y * kCamTab + k]; }
+    for (int k = 0; k < kCamTab; ++k) { ta[k] = camtab[(size_t)ab.x * kCamRow + k]; tb[k] = camtab[(size_t)ab.y * kCamRow + k]; }
     double s[36];
 #pragma unroll
     for (int q = 0; q < 36; ++q) s[q] = 0.0;

@@ -549,7 +549,7 @@ int launch_resjac(sfmba_handle* h, const double* x, const double* tab, int* npar
                   hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, bool blocks = JAC) {
     const int grid = grid_1d(h->N, kSweepThreads, h->n_cu);
     *nparts = grid;
-    const size_t lds = (size_t)h->C * kCamTab * sizeof(double);
+    const size_t lds = (size_t)h->C * kCamRow * sizeof(double);
     if (h->lds_tab)
         return h->f32 ? launch_resjac_v<true, JAC, STORE_R, true>(h, x, tab, grid, lds, ev0, ev1, blocks)
                       : launch_resjac_v<true, JAC, STORE_R, false>(h, x, tab, grid, lds, ev0, ev1, blocks);
@@ -1552,7 +1552,7 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
         }
     }
     tp2 = now_s();
-    h->lds_tab = (size_t)C * kCamTab * sizeof(double) <= kLdsDynMax;
+    h->lds_tab = (size_t)C * kCamRow * sizeof(double) <= kLdsDynMax;
     h->lds_vec = (size_t)C * 6 * sizeof(double) <= kLdsDynMax;
     if (h->dbg.tab_lds == 0) h->lds_tab = false;               // test hooks (sfmba_debug_option): force the L2 placements
     if (h->dbg.vec_lds == 0) h->lds_vec = false;
