@@ -45,7 +45,7 @@ def k1_bytes_f32(C, P, N):
 def k1_bytes(C, P, N):
     """Algorithmic bytes of one residual+Jacobian launch: per observation read
     cam_idx 4 + pt_idx 4 + uv 16, write r 16 + d r/d w 48 + d r/d X 48 = 136 B; once per point 24 B, per
-    camera 48 B.  Since round 3 the launch also leaves the point half of the normal equations, V_p (48 B) and g_p
+    camera 48 B.  The launch also leaves the point half of the normal equations, V_p (48 B) and g_p
     (24 B) per point, summed from the blocks it holds in registers: 96 B per point in all.  SURVEY.md section 8d
     counts 184 B per observation because it also writes d r/d T, which is -d r/d X and is not stored (see
     k1_bytes_survey for that accounting)."""
@@ -259,7 +259,7 @@ def main():
         # on purpose: its launches in a rocprofv3 trace of this command are then exactly the ones
         # inside solves, the population `roofline.avg_launch_us` averages over.
         primed = {name: be.time_kernel(pb.x0, which, 50) for which, name in
-                  ((2, "normal_blocks"), (3, "schur_sweep"))}
+                  ((2, "camera_blocks"), (3, "schur_sweep"))}
         # Settle: on these boxes a process sees one or two ~45 ms stalls of its GPU queue during the first
         # ~100 ms of activity (observed with SFMBA_DEBUG_STALLS=1; none later in 600-solve runs).  Untimed
         # back-to-back solves for half a second keep that start-up transient out of the W + K steps below.

@@ -49,7 +49,8 @@ typedef struct sfmba_options {
     int32_t max_iter;      /* <=0: unlimited; otherwise stop after this many outer iterations    */
     double  pcg_tol;       /* forcing term of the inexact step: the Schur PCG stops when the
                               preconditioned residual norm has dropped by this factor (default 1e-2;
-                              see DESIGN.md section 3 for how this compares with scipy's LSMR)        */
+                              a tenth of it when 6 n_cameras <= 128 and the iterations run inside one
+                              workgroup; DESIGN.md section 3 compares this with scipy's LSMR)        */
     int32_t pcg_max_iter;  /* <=0: 2 * 6 * n_cameras                                             */
     int32_t pcg_check_every; /* host polls the device-side convergence flag every k iterations   */
     double  reg_min;       /* floor of the Levenberg-Marquardt term (1e-6), see DESIGN.md         */
@@ -180,9 +181,11 @@ int  sfmba_get_fun_grad(sfmba_handle* h, double* fun_out, double* grad_out);
 
 /* ---- measurement / test entry points -------------------------------------------------------- */
 /* `reps` back-to-back launches of one kernel at x, bracketed by HIP events on the handle's stream.
- * which: 0 residual+Jacobian sweep, 1 residual-only sweep, 2 normal-equation blocks (point pass + camera pass),
+ * which: 0 residual+Jacobian sweep (with the point blocks V_p, g_p it leaves behind), 1 residual-only sweep,
+ *        2 the camera pass of the normal equations (U_c, g_c, and the point rows the sweep's tiles cut),
  *        3 one implicit Schur product (pass A + pass B), 4 pass A alone, 5 pass B alone, 6 the reduced
- *        right-hand-side pass, 10 a streaming-store fill of the Jacobian buffer (ceiling probe).
+ *        right-hand-side pass, 7 the residual+Jacobian sweep with its point-block sums switched off,
+ *        10 a streaming-store fill of the Jacobian buffer (ceiling probe).
  * avg_us: average duration of one repetition. */
 int  sfmba_time_kernel(sfmba_handle* h, const double* x, int32_t which, int32_t reps, double* avg_us);
 /* Normal-equation blocks at x: U (C,21 upper triangle row-major), V (P,6 upper), gc (C,6), gp (P,3). */
@@ -192,9 +195,9 @@ int  sfmba_normal_blocks(sfmba_handle* h, const double* x, double* U, double* V,
 int  sfmba_schur_matvec(sfmba_handle* h, const double* x, const double* dc, const double* dp,
                         const double* v, double* y);
 
-/* Dense reduced-camera path (6 n_cameras <= 128, the reference's own problem sizes): at x, with the diagonals dc
- * (6C) and dp (3P), form S = U + diag(dc) - W (V + diag(dp))^-1 W^T (S_out: (6C)^2 row-major, may be NULL) and
- * solve S y = rhs with the in-LDS blocked Cholesky (sol_out: 6C). */
+/* Few-camera path (6 n_cameras <= 128, the reference's own problem sizes): at x, with the diagonals dc (6C) and dp
+ * (3P), form S = U + diag(dc) - W (V + diag(dp))^-1 W^T (S_out: (6C)^2 row-major, may be NULL) and solve S y = rhs
+ * with the in-LDS PCG run to the end (relative tolerance 1e-14; sol_out: 6C). */
 int  sfmba_dense_schur(sfmba_handle* h, const double* x, const double* dc, const double* dp, const double* rhs,
                        double* S_out, double* sol_out);
 
@@ -203,8 +206,8 @@ int  sfmba_dense_schur(sfmba_handle* h, const double* x, const double* dc, const
  * lies inside the region, 0 for a boundary solution. */
 int  sfmba_tr2d_solve(const double* B3, const double* g2, double Delta, double* p2);
 /* Test / diagnostic hooks (nothing in the library reads the environment).  Placement options take effect at
- * the next sfmba_set_problem.  Names: "pcg_fused" (0: two-kernel PCG), "dense" (0: PCG although the dense reduced-camera path would
- * apply), "sweep_rc" (0: pass A of the Schur product reads the stored Jacobian), "tab_lds" / "vec_lds" (0: camera table /
+ * the next sfmba_set_problem.  Names: "pcg_fused" (0: two-kernel PCG), "dense" (0: implicit Schur product although the reduced camera matrix
+ * would be formed, 6 n_cameras <= 128), "sweep_rc" (0: pass A of the Schur product reads the stored Jacobian), "tab_lds" / "vec_lds" (0: camera table /
  * camera vector read from L2 although they would fit the LDS), "cam_chunk" (> 0: chunk length of the
  * camera-major kernels), "pcg_guess_bias" (added to the speculative PCG iteration count), "trace_pcg",
  * "trace_stalls", "trace_timing" (stderr diagnostics). */

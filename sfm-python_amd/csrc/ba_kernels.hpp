@@ -467,7 +467,7 @@ __device__ __forceinline__ void st16(double* __restrict__ p, double a, double b)
 // inside the tile stores the point's row.  A run cut by a tile boundary leaves its pieces in edge[tile][0] (the
 // run that continues from the previous tile) and edge[tile][1] (the run that continues into the next one);
 // point_edge_fixup, riding with the camera pass that follows, adds the pieces in tile order.  No atomics; a
-// separate kernel (round 2: k_point_blocks, 19 us at 1M observations) re-read the indices and pixels and
+// separate kernel (k_point_blocks until then, 19 us at 1M observations) re-read the indices and pixels and
 // recomputed every block.  Points without observations keep the zeros set_problem wrote.
 constexpr int kEdgeRow = 10;                     // 9 sums, padded to a multiple of 16 bytes
 struct PointBlocksOut {
@@ -1984,10 +1984,10 @@ __global__ __launch_bounds__(kRhsThreads) void k_cam_rhs_diag(CamMajor cm, const
 // So S is FORMED -- one workgroup per 6x6 block pair (a <= b) over the list of points both cameras see, built once
 // per problem; blocks recomputed from the camera rows and the gathered point; no atomics -- and the SAME
 // preconditioned conjugate gradients run inside one workgroup with S in LDS: an iteration is a 66 x 66
-// matrix-vector product by 256 threads and two block reductions, a few hundred cycles instead of two launches.
+// matrix-vector product by 512 threads and one block reduction, ~3000 cycles instead of two launches.
 // The preconditioner is the inverse of the diagonal 6x6 blocks of S, i.e. exactly the Schur-diagonal
 // preconditioner of the implicit path: both paths walk through the same iterates up to rounding.
-// (Round 2 factorised S instead: blocked Cholesky with the trailing updates on v_mfma_f64_16x16x4_f64.  33 us at
+// (An earlier version factorised S instead: blocked Cholesky with the trailing updates on v_mfma_f64_16x16x4_f64.  33 us at
 // 66 unknowns -- the 16-step diagonal tiles and panel substitutions are serial code for one wavefront -- and its
 // exact steps carried rounding noise along the seven gauge directions that no camera being fixed leaves open.)
 // ---------------------------------------------------------------------------------------------

@@ -1853,6 +1853,7 @@ int sfmba_time_kernel(sfmba_handle* h, const double* x, int32_t which, int32_t r
             case 4: CHK(launch_point_sweep(h, (h->lds_vec || h->sweep_rc) ? h->vtmp.as<double>() : h->vcm.as<double>(), nullptr, 0)); break;
             case 5: CHK(launch_cam_schur<0>(h, h->vtmp.as<double>(), nullptr, 0)); break;
             case 6: CHK(launch_cam_schur<1>(h, nullptr, nullptr, 0)); break;
+            case 7: CHK((launch_resjac<true, true>(h, h->x, h->tab, &np, nullptr, nullptr, /*blocks=*/false))); break;
             case 10:   // streaming-store ceiling: fill the Jacobian planes, 16 B per lane, one stream
                 hipLaunchKernelGGL(k_fill16, dim3(h->n_cu * 2), dim3(1024), 0, h->stream, h->J.as<double>(),
                                    (int64_t)((h->f32 ? 3 : 6) * h->ld), 1.0);

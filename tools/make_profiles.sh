@@ -19,3 +19,12 @@ python3 tools/profile_summary.py stats $OUT/${TAG}_stats $OUT/${TAG}_bench_kerne
 python3 tools/profile_summary.py stats $OUT/${TAG}_stats_cfg2 $OUT/${TAG}_bench_cfg2_kernel_stats.md > /dev/null
 python3 tools/profile_summary.py pmc $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write $OUT/${TAG}_traffic.json "cfg4 (1000 cameras / 100k points / 1M observations), fp64" > /dev/null
 for f in bench_line bench_under_rocprof bench_cfg2 bench_cfg3 bench_cfg5_f32 bench_cfg5_f64; do echo "== $f"; head -c 600 $OUT/${TAG}_$f.json; echo; done
+cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_eighth -- python3 $R/tools/solve_loop.py 1000,12500,125000 > $OUT/${TAG}_eighth.log 2>&1
+cd $R
+python3 tools/profile_summary.py stats $OUT/${TAG}_eighth $OUT/${TAG}_eighth_kernel_stats.md > /dev/null
+python3 tools/time_kernels.py cfg4 > $OUT/${TAG}_time_kernels.txt 2>&1
+for c in cfg4 cfg2 cfg3 1000,12500,125000; do python3 tools/solve_loop.py $c; done > $OUT/${TAG}_solve_loop.txt 2>&1
+python3 tools/solve_loop.py cfg5 6 32 >> $OUT/${TAG}_solve_loop.txt 2>&1
+python3 tools/solve_loop.py cfg5 6 64 >> $OUT/${TAG}_solve_loop.txt 2>&1
+rm -rf $OUT/${TAG}_stats $OUT/${TAG}_stats_cfg2 $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write $OUT/${TAG}_eighth
+cat $OUT/${TAG}_time_kernels.txt $OUT/${TAG}_solve_loop.txt
