@@ -187,46 +187,15 @@ __device__ __forceinline__ void finish_in_block(const Piggyback& pb) {
 // equal keys holds the sum over its run (other lanes: partial sums).  All 64 lanes must call it.
 //
 // Cross-lane traffic goes through DPP and v_readlane, i.e. the VALU, not through ds_bpermute: the sweeps
-// already load the LDS pipe with per-camera gathers and ds_add_f64, and the 6 x (1 + 2 NV) bpermutes of a
-// shuffle-based reduction came to more LDS-pipe time than everything else in those kernels together.
+// already load the LDS pipe with their camera-table reads, and the 6 x (1 + 2 NV) bpermutes of a shuffle-based
+// reduction came to more LDS-pipe time than everything else in those kernels together.
 //   rows of 16 lanes: suffix sums by row_shl:1,2,4,8 (lane i reads lane i+n of its row); a lane adds only
 //   when the key n lanes up equals its own -- keys are sorted, so everything between belongs to the run;
 //   across rows: from the top row down, the first lane of the next row (by then complete) is broadcast with
 //   v_readlane and added by the lanes of this row that carry its key.
-
-template <int NV, int N>
-__device__ __forceinline__ void seg_row_step(double (&v)[NV], int key, int lane) {
-    constexpr int kRowShl = 0x100;                     // DPP control: row_shl:N
-    const int k2 = dpp_int<kRowShl + N>(key);
-    const bool ok = ((lane & 15) + N < 16) && (k2 == key);
-#pragma unroll
-    for (int n = 0; n < NV; ++n) {
-        const double o = dpp_double<kRowShl + N>(v[n]);
-        if (ok) v[n] += o;
-    }
-}
-template <int NV>
-__device__ __forceinline__ void seg_reduce(double (&v)[NV], int key, int lane) {
-    seg_row_step<NV, 1>(v, key, lane);
-    seg_row_step<NV, 2>(v, key, lane);
-    seg_row_step<NV, 4>(v, key, lane);
-    seg_row_step<NV, 8>(v, key, lane);
-#pragma unroll
-    for (int r = 2; r >= 0; --r) {
-        const int f = 16 * (r + 1);
-        const int kf = __builtin_amdgcn_readlane(key, f);
-        const bool ok = (lane >> 4) == r && key == kf;
-#pragma unroll
-        for (int n = 0; n < NV; ++n) {
-            const double c = readlane_double(v[n], f);
-            if (ok) v[n] += c;
-        }
-    }
-}
-
-// The same reduction value by value (all seven steps of v[0], then v[1], ...) with the lane masks computed once:
-// a kernel that carries a software pipeline across the reduction cannot afford the registers of NV interleaved
-// chains (k_resjac spilled 100 dwords per lane with seg_reduce<9>).
+// Value by value (all seven steps of v[0], then v[1], ...) with the lane masks computed once: a kernel that carries
+// a software pipeline across the reduction cannot afford the registers of NV interleaved chains (k_resjac spilled
+// 100 dwords per lane that way).
 template <int NV>
 __device__ __forceinline__ void seg_reduce_serial(double (&v)[NV], int key, int lane) {
     constexpr int kRowShl = 0x100;
@@ -256,6 +225,14 @@ __device__ __forceinline__ void seg_reduce_serial(double (&v)[NV], int key, int 
         v[n] = x;
         __builtin_amdgcn_sched_barrier(0);
     }
+}
+
+// key of lane - 1 (lane 0: 0) through DPP and v_readlane instead of ds_bpermute
+__device__ __forceinline__ int lane_below(int key, int lane) {
+    int prev = dpp_int<0x111>(key);                          // row_shr:1
+    const int k15 = __builtin_amdgcn_readlane(key, 15), k31 = __builtin_amdgcn_readlane(key, 31);
+    const int k47 = __builtin_amdgcn_readlane(key, 47);
+    return lane == 16 ? k15 : (lane == 32 ? k31 : (lane == 48 ? k47 : prev));
 }
 
 // fp32-STORAGE mode (BASELINE config 5): uv, r, t1 and the compact Jacobian are kept as floats, all
@@ -463,7 +440,7 @@ __device__ __forceinline__ void st16(double* __restrict__ p, double a, double b)
 // Point blocks ride along (pb.V != null): V_p = sum Jp^T Jp (6, packed upper triangle) and g_p = sum Jp^T r (3) are
 // sums over the point's run of observations, and the lanes of a wave hold 64 consecutive observations of the
 // point-major order with Jp and r in registers.  The nine products are reduced over the runs inside the wave
-// (seg_reduce; the kernel is HBM-write bound, the VALU has the time) and the first lane of every run that lies
+// (seg_reduce_serial) and the first lane of every run that lies
 // inside the tile stores the point's row.  A run cut by a tile boundary leaves its pieces in edge[tile][0] (the
 // run that continues from the previous tile) and edge[tile][1] (the run that continues into the next one);
 // point_edge_fixup, riding with the camera pass that follows, adds the pieces in tile order.  No atomics; a
@@ -566,10 +543,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_resjac(
                 for (int q = 0; q < 9; ++q) v[q] = 0.0;
             }
             seg_reduce_serial<9>(v, key, lane);                  // first lane of every run: the run's sums
-            int kp = dpp_int<0x111>(key);                        // row_shr:1: the key one lane down
-            const int k15 = __builtin_amdgcn_readlane(key, 15), k31 = __builtin_amdgcn_readlane(key, 31);
-            const int k47 = __builtin_amdgcn_readlane(key, 47), k63 = __builtin_amdgcn_readlane(key, 63);
-            kp = lane == 16 ? k15 : (lane == 32 ? k31 : (lane == 48 ? k47 : kp));
+            const int kp = lane_below(key, lane), k63 = __builtin_amdgcn_readlane(key, 63);
             const bool first = on && (lane == 0 || key != kp);
             const bool head = lane == 0 && key == pprev;         // continues a run of the previous tile
             const bool tail = key == k63 && k63 == pnext;        // continues into the next tile
@@ -828,7 +802,7 @@ __global__ void k_build_cam_major(const int* __restrict__ perm, const int* __res
 // (host-built) and walks it in precomputed steps: steps[s] = (first observation, count); count <= 64 is a
 // batch that ends on a point boundary, count > 64 a single point with that many observations.
 // wsteps[wave] = (first step, number of steps).  With the step list known, the index loads of step s+1 are
-// issued while step s computes.  Per-point sums are reduced inside the wave (seg_reduce); no run ever spans
+// issued while step s computes.  Per-point sums are reduced inside the wave (seg_reduce_serial); no run ever spans
 // two waves.
 // ---------------------------------------------------------------------------------------------
 struct StepTable {
@@ -1537,8 +1511,8 @@ __global__ __launch_bounds__(kSweepThreads) void k_point_sweep(
                 y[2] = jp[2] * t0 + jp[5] * t1;
             }
             const int key = act ? p : -1 - lane;                  // run key = point index
-            seg_reduce<3>(y, key, lane);
-            const int prev = __shfl_up(key, 1);
+            seg_reduce_serial<3>(y, key, lane);
+            const int prev = lane_below(key, lane);
             if (act && (lane == 0 || prev != key)) {              // first lane of the point's run
                 zout[(size_t)kRec * p + 3] = vi[0] * y[0] + vi[1] * y[1] + vi[2] * y[2];
                 zout[(size_t)kRec * p + 4] = vi[1] * y[0] + vi[3] * y[1] + vi[4] * y[2];
@@ -1688,8 +1662,8 @@ __global__ __launch_bounds__(kSweepThreads) void k_point_sweep_rc(
             const bool act = lane < cur.y;
             if (act) contrib(c, X[0], X[1], X[2], y);
             const int key = act ? p : -1 - lane;
-            seg_reduce<3>(y, key, lane);
-            const int prev = __shfl_up(key, 1);
+            seg_reduce_serial<3>(y, key, lane);
+            const int prev = lane_below(key, lane);
             if (act && (lane == 0 || prev != key)) {
                 zout[(size_t)kRec * p + 3] = vi[0] * y[0] + vi[1] * y[1] + vi[2] * y[2];
                 zout[(size_t)kRec * p + 4] = vi[1] * y[0] + vi[3] * y[1] + vi[4] * y[2];
@@ -2497,7 +2471,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_backsub(
             y[0] = jp[0] * t0 + jp[3] * t1v; y[1] = jp[1] * t0 + jp[4] * t1v;
             y[2] = jp[2] * t0 + jp[5] * t1v;
         }
-        seg_reduce<3>(y, act ? sb : -1 - lane, lane);
+        seg_reduce_serial<3>(y, act ? sb : -1 - lane, lane);
         if (act && i == sb) { solve_point(p, y, z0, z1, z2); point_dots(p, s3, z0, z1, z2); }
         const int head = act ? lane - (i - sb) : lane;
         z0 = __shfl(z0, head); z1 = __shfl(z1, head); z2 = __shfl(z2, head);
