@@ -3,6 +3,8 @@ from __future__ import annotations
 
 import ctypes as C
 
+import weakref
+
 import numpy as np
 
 from . import _capi
@@ -41,6 +43,10 @@ class Backend:
 
     def close(self):
         if getattr(self, "_h", None):
+            try:
+                self._flush_pending()
+            except Exception:                                  # noqa: BLE001 (a dying handle must still be released)
+                pass
             self._lib.sfmba_destroy(self._h)
             self._h = None
 
@@ -61,9 +67,34 @@ class Backend:
             raise MemoryError(msg)
         raise BackendError(f"sfmba error {rc}: {msg}")
 
+    # ---- results left on the device -----------------------------------------------------------------
+    # The reference reads only ``result.x`` (sfm.py:271,281), and ``result.fun`` is 16 MB at a million observations:
+    # `solve(..., want_fun=False, want_grad=False)` leaves fun and grad in the handle's buffers and registers the result object (weakly).  They are
+    # downloaded when somebody looks at them, or -- if the object is still alive -- right before this handle's next
+    # operation overwrites the buffers; a result that was dropped unread costs no download at all.
+    def _flush_pending(self):
+        ref, self._pending = getattr(self, "_pending", None), None
+        if ref is not None:
+            obj = ref()
+            if obj is not None:
+                obj._materialize()
+
+    def _register_pending(self, obj):
+        self._pending = weakref.ref(obj)
+
+    def fetch_fun_grad(self, want_fun=True, want_grad=True):
+        """fun (2 n_obs) and / or grad (n) of the last solve, while the handle still holds them."""
+        fun = np.empty(2 * self.n_obs) if want_fun else None
+        grad = np.empty(self.n_params) if want_grad else None
+        if want_fun or want_grad:
+            self._check(self._lib.sfmba_get_fun_grad(self._h, _capi.ptr(fun) if want_fun else None,
+                                                     _capi.ptr(grad) if want_grad else None))
+        return fun, grad
+
     def set_precision(self, storage_bits: int):
         """64 (default) or 32: storage of uv / r / Jacobian; arithmetic stays fp64.  Applies from the
         next set_problem."""
+        self._flush_pending()
         self._check(self._lib.sfmba_set_precision(self._h, int(storage_bits)))
 
     def debug_option(self, name: str, value: int):
@@ -74,6 +105,7 @@ class Backend:
         self._check(self._lib.sfmba_set_stream(self._h, C.c_void_p(int(hip_stream))))
 
     def set_problem(self, n_cameras, n_points, camera_indices, point_indices, points_2d, K):
+        self._flush_pending()
         ci = np.ascontiguousarray(camera_indices, dtype=np.int64).ravel()
         pi = np.ascontiguousarray(point_indices, dtype=np.int64).ravel()
         if ci.shape != pi.shape:
@@ -176,12 +208,14 @@ class Backend:
 
     # ------------------------------------------------------------------------------------------
     def residuals(self, x):
+        self._flush_pending()
         x = _f64(x, (self.n_params,), "x")
         out = np.empty(2 * self.n_obs)
         self._check(self._lib.sfmba_residuals(self._h, _capi.ptr(x), _capi.ptr(out)))
         return out
 
     def residual_jacobian(self, x):
+        self._flush_pending()
         x = _f64(x, (self.n_params,), "x")
         r = np.empty(2 * self.n_obs)
         Jc = np.empty((self.n_obs, 2, 6))
@@ -191,6 +225,7 @@ class Backend:
         return r, Jc, Jp
 
     def normal_blocks(self, x):
+        self._flush_pending()
         x = _f64(x, (self.n_params,), "x")
         U = np.empty((self.n_cameras, 21))
         V = np.empty((self.n_points, 6))
@@ -201,6 +236,7 @@ class Backend:
         return U, V, gc, gp
 
     def schur_matvec(self, x, dc, dp, v):
+        self._flush_pending()
         x = _f64(x, (self.n_params,), "x")
         dc = _f64(dc).reshape(-1)
         dp = _f64(dp).reshape(-1)
@@ -211,7 +247,8 @@ class Backend:
         return y
 
     def dense_schur(self, x, dc, dp, rhs):
-        """(S, y): the reduced camera matrix formed by the dense path and the solution of S y = rhs."""
+        """(S, y): the formed reduced camera matrix and the solution of S y = rhs by the in-LDS PCG run to the end."""
+        self._flush_pending()
         x = _f64(x, (self.n_params,), "x")
         dc, dp, rhs = _f64(dc).reshape(-1), _f64(dp).reshape(-1), _f64(rhs).reshape(-1)
         n = 6 * self.n_cameras
@@ -222,6 +259,7 @@ class Backend:
         return S, y
 
     def time_kernel(self, x, which: int, reps: int) -> float:
+        self._flush_pending()
         x = _f64(x, (self.n_params,), "x")
         us = C.c_double()
         self._check(self._lib.sfmba_time_kernel(self._h, _capi.ptr(x), int(which), int(reps),
@@ -234,13 +272,12 @@ class Backend:
         return o
 
     def solve(self, x0, options: _capi.Options | None = None, want_fun=True, want_grad=True):
+        """-> (x, result struct, fun, grad).  fun / grad not wanted stay on the device: `fetch_fun_grad` gets them
+        until the next operation on this handle."""
+        self._flush_pending()
         x = np.array(_f64(x0, (self.n_params,), "x0"), copy=True)
         opt = options if options is not None else self.default_options()
         res = _capi.Result()
         self._check(self._lib.sfmba_solve(self._h, _capi.ptr(x), C.byref(opt), C.byref(res)))
-        fun = np.empty(2 * self.n_obs) if want_fun else None
-        grad = np.empty(self.n_params) if want_grad else None
-        if want_fun or want_grad:
-            self._check(self._lib.sfmba_get_fun_grad(self._h, _capi.ptr(fun) if want_fun else None,
-                                                     _capi.ptr(grad) if want_grad else None))
+        fun, grad = self.fetch_fun_grad(want_fun, want_grad)
         return x, res, fun, grad

@@ -320,3 +320,49 @@ def test_growing_reconstruction_reuses_the_previous_problem():
             fresh.close()
     finally:
         inc.close()
+
+
+def test_result_fun_and_grad_stay_on_the_device_until_read(orc):
+    """least_squares returns scipy's OptimizeResult with `fun` (16 MB at 1M observations) and `grad` still in the
+    handle's buffers: the reference reads result.x only (sfm.py:271,281).  They must behave like scipy's arrays
+    whenever they ARE read -- at once, after the next call on the same handle has overwritten the buffers, through
+    every dict access path -- and cost no download when the result is dropped unread."""
+    import gc
+    import pickle
+    import sfmba
+    be = sfmba.get_backend(0)
+    pa = sfmba.make_problem(5, 60, 300, seed=3)
+    pb = sfmba.make_problem(7, 90, 500, seed=4)
+
+    def run(p):
+        return sfmba.least_squares(sfmba.compute_residuals, p.x0, x_scale="jac", ftol=1e-10, method="trf", args=p.args)
+
+    n0 = getattr(be, "n_lazy_downloads", 0)
+    ra = run(pa)
+    assert getattr(be, "n_lazy_downloads", 0) == n0                  # nothing downloaded yet
+    fa = ra.fun                                                      # read at once
+    assert getattr(be, "n_lazy_downloads", 0) == n0 + 1
+    assert np.abs(fa - orc.compute_residuals(ra.x, *pa.args)).max() < 1e-8
+    assert abs(ra.optimality - np.abs(ra.grad).max()) <= 1e-12 * max(1.0, ra.optimality)
+    # kept alive across the next call: downloaded right before the buffers are overwritten
+    rb = run(pb)
+    rc = run(pa)
+    assert getattr(be, "n_lazy_downloads", 0) == n0 + 2              # rb was flushed by the call that made rc
+    assert np.abs(rb["fun"] - orc.compute_residuals(rb.x, *pb.args)).max() < 1e-8
+    assert rb.fun.shape == (2 * pb.n_obs,) and rc.fun.shape == (2 * pa.n_obs,)
+    assert np.array_equal(rc.fun, fa) and np.array_equal(rc.x, ra.x)  # same input, same bits
+    # dropped unread: no download
+    n1 = getattr(be, "n_lazy_downloads", 0)
+    rd = run(pb)
+    xd = rd.x.copy()
+    del rd
+    gc.collect()
+    re_ = run(pb)
+    assert getattr(be, "n_lazy_downloads", 0) == n1
+    # the other access paths
+    d = dict(re_.items())
+    assert d["fun"].shape == (2 * pb.n_obs,) and "grad" in re_.keys() and re_.get("fun") is d["fun"]
+    assert np.array_equal(re_.x, xd)
+    rf = pickle.loads(pickle.dumps(run(pa)))
+    assert np.array_equal(rf.fun, fa) and rf.status == ra.status
+    assert "fun:" in repr(run(pa))
