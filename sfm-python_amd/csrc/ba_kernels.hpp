@@ -1971,19 +1971,26 @@ __host__ __device__ constexpr int dense_block_index(int a, int b, int C) {      
 }
 
 // blk[a][b] (6x6, row-major) = sum over the points p seen by cameras a and b (with multiplicity) of
-// W_a(p) Vinv_p W_b(p)^T,  W_c(p) = Jc^T Jp of camera c at point p.
+// W_a(p) Vinv_p W_b(p)^T,  W_c(p) = Jc^T Jp of camera c at point p.  The workgroup of a diagonal pair (a, a) also
+// sums the reduced right-hand-side term of its camera, rhs_a = -sum W_a(p) e_p over the list entries that pair an
+// observation with itself (marked ~p by set_problem; e_p in the z half of the point records), into acc[k][a]
+// (acc == null: not wanted) -- the pass k_cam_schur<1> would make over the same observations, without its launch.
 __global__ __launch_bounds__(kCamThreads) void k_schur_blocks(const int* __restrict__ cov_ptr, const int* __restrict__ cov_pt,
                                                      const int2* __restrict__ blk_ab, const double* __restrict__ camtab,
-                                                     const double* __restrict__ pts, const double* __restrict__ Vinv,
-                                                     KMat K, double* __restrict__ Sblk) {
+                                                     const double* __restrict__ rec, const double* __restrict__ Vinv,
+                                                     KMat K, int C, double* __restrict__ Sblk, double* __restrict__ acc) {
     __shared__ double red[kCamWaves][36];
+    __shared__ double red6[kCamWaves][6];
     const int2 ab = blk_ab[blockIdx.x];
+    const bool diag = ab.x == ab.y, rhs = diag && acc != nullptr;          // workgroup-uniform
     double ta[kCamTab], tb[kCamTab];
 #pragma unroll
     for (int k = 0; k < kCamTab; ++k) { ta[k] = camtab[(size_t)ab.x * kCamRow + k]; tb[k] = camtab[(size_t)ab.y * kCamRow + k]; }
-    double s[36];
+    double s[36], g[6];
 #pragma unroll
     for (int q = 0; q < 36; ++q) s[q] = 0.0;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) g[q] = 0.0;
     auto w_of = [&](const double* t, double X, double Y, double Z, double (&W)[6][3]) {
         double jc[12], jp[6], rx, ry;
         observe<true>(t, X, Y, Z, 0.0, 0.0, K, rx, ry, jc, jp);
@@ -1993,19 +2000,26 @@ __global__ __launch_bounds__(kCamThreads) void k_schur_blocks(const int* __restr
             for (int v = 0; v < 3; ++v) W[u][v] = jc[u] * jp[v] + jc[6 + u] * jp[3 + v];
     };
     for (int k = cov_ptr[blockIdx.x] + (int)threadIdx.x; k < cov_ptr[blockIdx.x + 1]; k += kCamThreads) {
-        const int p = cov_pt[k];
-        const double* __restrict__ Xp = pts + 3 * (size_t)p;
+        const int pm = cov_pt[k];
+        const bool self = pm < 0;                                  // an observation paired with itself
+        const int p = self ? ~pm : pm;
+        const double2* __restrict__ rp = reinterpret_cast<const double2*>(rec + kRec * (size_t)p);   // X Y | Z e0 | e1 e2
         const double* __restrict__ vi = Vinv + 6 * (size_t)p;
-        const double X = Xp[0], Y = Xp[1], Z = Xp[2];
+        const double2 r0 = rp[0], r1 = rp[1], r2 = rp[2];
+        const double X = r0.x, Y = r0.y, Z = r1.x;
         const double v0 = vi[0], v1 = vi[1], v2 = vi[2], v3 = vi[3], v4 = vi[4], v5 = vi[5];
         double Wa[6][3], Wb[6][3];
         w_of(ta, X, Y, Z, Wa);
-        if (ab.x != ab.y) w_of(tb, X, Y, Z, Wb);
+        if (!diag) w_of(tb, X, Y, Z, Wb);
         else {
 #pragma unroll
             for (int u = 0; u < 6; ++u)
 #pragma unroll
                 for (int v = 0; v < 3; ++v) Wb[u][v] = Wa[u][v];
+        }
+        if (rhs && self) {
+#pragma unroll
+            for (int u = 0; u < 6; ++u) g[u] -= Wa[u][0] * r1.y + Wa[u][1] * r2.x + Wa[u][2] * r2.y;
         }
 #pragma unroll
         for (int u = 0; u < 6; ++u) {
@@ -2018,6 +2032,10 @@ __global__ __launch_bounds__(kCamThreads) void k_schur_blocks(const int* __restr
     }
     const double tot = cam_block_total<36>(s, red);              // lanes, then the four waves in wave order
     if (threadIdx.x < 36) Sblk[(size_t)blockIdx.x * 36 + threadIdx.x] = tot;
+    if (rhs) {
+        const double tg = cam_block_total<6>(g, red6);
+        if (threadIdx.x < 6) acc[(size_t)threadIdx.x * C + ab.x] = tg;
+    }
 }
 
 // Solve (U + Dc - blk) dc = -g_c - acc by block-preconditioned CG in LDS (see above).  One workgroup of 512

@@ -730,10 +730,13 @@ int launch_rhs_and_preconditioner(sfmba_handle* h) {
 // S in LDS; the camera step and the control block are left where the implicit PCG leaves them (x of vector set 0).
 // acc must hold the reduced right-hand-side term (pass B, MODE 1).
 constexpr double kDenseTolFactor = 0.1;
-int launch_dense_solve(sfmba_handle* h, double tol, int max_iters) {
+// `rhs`: the workgroups of the diagonal pairs also leave the reduced right-hand-side term -sum W e in acc (e in the
+// z half of the point records, k_prep); false: acc is the caller's (test entry).
+int launch_dense_solve(sfmba_handle* h, double tol, int max_iters, bool rhs) {
     hipLaunchKernelGGL(k_schur_blocks, dim3(h->n_blk), dim3(kCamThreads), 0, h->stream, (const int*)h->cov_ptr.as<int>(),
                        (const int*)h->cov_pt.as<int>(), (const int2*)h->blk_ab.as<int2>(), (const double*)h->tab,
-                       (const double*)(h->x + 6 * h->C), (const double*)h->Vinv.as<double>(), h->K, h->Sblk.as<double>());
+                       (const double*)h->rec, (const double*)h->Vinv.as<double>(), h->K, (int)h->C,
+                       h->Sblk.as<double>(), rhs ? h->acc() : (double*)nullptr);
     LAUNCHED(h);
     const int n = 6 * (int)h->C;
     const size_t lds = sizeof(double) * ((size_t)n * (size_t)(n | 1) + 2 * kDenseMaxN + ((21 * kDenseMaxN / 6 + 1) & ~1) +
@@ -1523,8 +1526,9 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
         chunk_ptr[C] = (int)chunks.size();
         h->n_chunks = (int)chunks.size();
     }
-    // dense reduced-camera path (few cameras): for every block pair (a <= b) the points seen by both cameras, with
-    // multiplicity (a point seen m_a, m_b times contributes m_a m_b times); two counting passes over the runs
+    // few cameras: for every block pair (a <= b) the points seen by both cameras, with multiplicity (a point seen
+    // m_a, m_b times contributes m_a m_b times); two counting passes over the runs.  The diagonal pairs' workgroups
+    // also sum the reduced right-hand side of their camera, over the entries that pair an observation with itself.
     h->dense = 6 * C <= kDenseMaxN && h->dbg.dense != 0;
     std::vector<int> cov_ptr, cov_pt;
     std::vector<int2> blk_ab;
@@ -1544,7 +1548,8 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
             for (int64_t p = 0; p < P; ++p)
                 for (int i = ptr[p]; i < ptr[p + 1]; ++i)
                     for (int j = ptr[p]; j < ptr[p + 1]; ++j)
-                        if (ci[i] <= ci[j]) cov_pt[(size_t)fill[dense_block_index(ci[i], ci[j], (int)C)]++] = (int)p;
+                        if (ci[i] <= ci[j])           // an observation paired with itself is marked (~p): the term of
+                            cov_pt[(size_t)fill[dense_block_index(ci[i], ci[j], (int)C)]++] = i == j ? ~(int)p : (int)p;   // the right-hand side
             blk_ab.resize((size_t)nblk);
             for (int a = 0; a < (int)C; ++a)
                 for (int b = a; b < (int)C; ++b) blk_ab[(size_t)dense_block_index(a, b, (int)C)] = make_int2(a, b);
@@ -1787,7 +1792,7 @@ int sfmba_dense_schur(sfmba_handle* h, const double* x, const double* dc, const 
                        h->gp.as<double>(), (const double*)nullptr, h->e.as<double>(), (int)h->P, 0.0,
                        h->Vinv.as<double>(), (double*)nullptr);
     LAUNCHED(h);
-    CHK(launch_dense_solve(h, 1e-14, 40 * 6 * (int)C));      // (test entry: to the end, to be compared with a direct solve)
+    CHK(launch_dense_solve(h, 1e-14, 40 * 6 * (int)C, /*rhs=*/false));   // (test entry: to the end, to be compared with a direct solve)
     std::vector<double> blk(36 * (size_t)h->n_blk), sol(6 * C);
     HIPCHK(h, hipMemcpyAsync(blk.data(), h->Sblk.p, sizeof(double) * blk.size(), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(sol.data(), h->vecs.p, sizeof(double) * 6 * C, hipMemcpyDeviceToHost, h->stream));
@@ -2024,14 +2029,14 @@ static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt
             LAUNCHED(h);
         }
         const bool dense = h->dense && one_rank;               // (sharded: the block pairs would need their own all-reduce)
-        if (dense) CHK(launch_cam_schur<1>(h, nullptr, nullptr, 0));               // reduced rhs term -> acc
-        else CHK(launch_rhs_and_preconditioner(h));             // ... and the preconditioner blocks
+        if (!dense) CHK(launch_rhs_and_preconditioner(h));      // reduced rhs term -> acc, preconditioner blocks
+                                                                // (few cameras: both inside launch_dense_solve)
         if (!dense) CHK(pcg_start(h, opt));                     // replaces lsmr, trf.py:477-480
         PcgCtrl hc{};
         if (dense) {
             // the same PCG inside one workgroup; an iteration there costs a twentieth of the two launches of the
             // implicit product, so the forcing term is a decade tighter (cfg2: 5 outer iterations instead of 7)
-            CHK(launch_dense_solve(h, kDenseTolFactor * opt.pcg_tol, pcg_max_iters(h, opt)));
+            CHK(launch_dense_solve(h, kDenseTolFactor * opt.pcg_tol, pcg_max_iters(h, opt), /*rhs=*/true));
         } else if (pcg_guess > 0) {
             // speculative: no read-back; surplus launches are no-ops.  Fused launches apply the update of
             // iteration k in launch k + 1, so k iterations need k + 1 launches; one spare either way.
