@@ -56,6 +56,11 @@ typedef struct sfmba_options {
     double  reg_min;       /* floor of the Levenberg-Marquardt term (1e-6), see DESIGN.md         */
     int32_t profile;       /* 1: bracket every residual+Jacobian launch with HIP events          */
     int32_t reserved;
+    double  pcg_tol_max;   /* > pcg_tol: the forcing term adapts to the progress of the outer iteration,
+                              eta_k = min(pcg_tol_max, max(pcg_tol, |g_h(x_k)| / |g_h(x_k-1)|)), eta_0 =
+                              pcg_tol_max (default 0.1; Eisenstat-Walker: loose while the scaled gradient
+                              still drops slowly, pcg_tol once it drops fast).  <= pcg_tol: fixed term.
+                              Not applied to the in-workgroup iterations of the few-camera path.    */
 } sfmba_options;
 
 typedef struct sfmba_result {

@@ -414,8 +414,12 @@ class TRFResult:
 
 def trf_schur(x0, n_cameras, n_points, camera_indices, point_indices, points_2d, K,
               ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None, linear="dense",
-              pcg_tol=1e-10, precond="block_u", reg_min=1e-6, verbose=0, comm=None):
+              pcg_tol=1e-10, precond="block_u", reg_min=1e-6, verbose=0, comm=None, pcg_tol_max=None):
     """Restatement of trf_no_bounds(tr_solver='lsmr', x_scale='jac', loss='linear').
+
+    ``pcg_tol_max`` (> ``pcg_tol``): the forcing term of the PCG adapts to the outer iteration as the HIP path's
+    does (include/sfmba.h, sfmba_options.pcg_tol_max): eta_0 = pcg_tol_max, eta_k = min(pcg_tol_max, max(pcg_tol,
+    |g_h(x_k)| / |g_h(x_k-1)|)) with g_h the scaled gradient of the iterate the system is solved at.
 
     Line references are to SCIPY/optimize/_lsq/trf.py.  Difference from scipy: gn_h of trf.py:480
     is the minimiser of |J_h p + f|^2 + reg |p|^2 through the Schur complement, not an LSMR iterate,
@@ -469,6 +473,7 @@ def trf_schur(x0, n_cameras, n_points, camera_indices, point_indices, points_2d,
         max_nfev = x.size * 100                                                # :437
     status = None
     iteration = 0
+    gh2_prev = None                     # |g_h|^2 of the previous solved iterate (adaptive forcing term)
     step_norm = None
     actual_reduction = None
     history = []
@@ -507,8 +512,12 @@ def trf_schur(x0, n_cameras, n_points, camera_indices, point_indices, points_2d,
         # damped Gauss-Newton step, :477-480:  (J^T J + reg diag(scale_inv^2)) p = -g,  gn_h = p/d
         damp = reg_term * scale_inv ** 2
         info["pcg_iters"] = 0
+        eta = pcg_tol
+        if pcg_tol_max is not None and pcg_tol_max > pcg_tol:
+            eta = pcg_tol_max if gh2_prev is None else min(pcg_tol_max, max(pcg_tol, math.sqrt(a11 / gh2_prev)))
+        gh2_prev = a11
         dc, dp = schur_solve(nb, damp[:n6].reshape(C, 6), damp[n6:].reshape(P, 3), ci, pi,
-                             -nb.gc, -nb.gp, method=linear, pcg_tol=pcg_tol, precond=precond,
+                             -nb.gc, -nb.gp, method=linear, pcg_tol=eta, precond=precond,
                              info=info, comm=comm)
         p = np.concatenate([dc.ravel(), dp.ravel()])
         gn_h = p * scale_inv

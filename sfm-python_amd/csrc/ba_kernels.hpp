@@ -1152,7 +1152,7 @@ __global__ __launch_bounds__(64) void k_prep(double* __restrict__ sc, double Del
                                              int C, int P, int bc, double* __restrict__ Dc,
                                              double* __restrict__ Minv,
                                              double* __restrict__ Vinv, double* __restrict__ e,
-                                             const double* __restrict__ jd_part, int jd_n) {
+                                             const double* __restrict__ jd_part, int jd_n, double eta_min, double eta_max) {
     // G11 = |J D^2 g|^2: either already in slot 1 (k_finish, then all-reduced over ranks) or summed here from
     // k_jdot's per-workgroup partials -- every workgroup (one wave) repeats the same 256-term sum in
     // k_finish's order, which is cheaper than a launch in between
@@ -1167,7 +1167,16 @@ __global__ __launch_bounds__(64) void k_prep(double* __restrict__ sc, double Del
         G11 = sc[1];
     }
     const double reg = reg_from_scalars(sc, G11, Delta, reg_min);
-    if (blockIdx.x == 0 && threadIdx.x == 0) sc[13] = reg;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        sc[13] = reg;
+        // forcing term of this iteration's PCG (slot 15) from the drop of the scaled gradient norm (slot 14 keeps the
+        // previous |g_h|^2; 0 at the start of a solve)
+        const double a11 = sc[8] + sc[16 + 1], prev = sc[14];
+        double eta = eta_max;
+        if (prev > 0.0 && a11 >= 0.0) eta = fmin(eta_max, fmax(eta_min, sqrt(a11 / prev)));
+        sc[15] = eta;
+        sc[14] = a11;
+    }
     if ((int)blockIdx.x < bc) {
         const int c = blockIdx.x * blockDim.x + threadIdx.x;
         if (c >= C) return;
@@ -1214,8 +1223,9 @@ struct PcgFused {
     const double* __restrict__ Ugc;      // launch 0 builds the right-hand side from g_c and acc
     double* __restrict__ vecs;
     PcgCtrl* __restrict__ ctrl2;
-    double tol;
+    double tol;                          // (unused: kept for the layout of the debug printouts)
     int max_iters;
+    const double* __restrict__ tol_dev;  // the forcing term of this iteration (k_prep leaves it in an exchange scalar)
     // LOCAL form (one rank, every camera a single chunk): pass B's workgroup owns its camera, so the per-camera
     // bookkeeping of the iteration (w = acc + Dc u, s, p, x, r, m = Minv s and the partial dot products
     // w.u, s.u, s.m, r.u) runs THERE, once per camera, and the prologue of pass A only needs, for all cameras,
@@ -1349,7 +1359,8 @@ __device__ __forceinline__ bool pcg_fused_update(const PcgFused& pf, const doubl
         const int done = (rz > 0.0) ? 0 : (rz == 0.0 ? 1 : 3);
         if (writer) {
             PcgCtrl c0;
-            c0.rz = rz; c0.rz0 = rz; c0.tol2 = pf.tol * pf.tol; c0.rz_prev = 1.0; c0.alpha_prev = 1.0;
+            const double tolv = *pf.tol_dev;
+            c0.rz = rz; c0.rz0 = rz; c0.tol2 = tolv * tolv; c0.rz_prev = 1.0; c0.alpha_prev = 1.0;
             c0.iters = 0; c0.max_iters = pf.max_iters; c0.done = done; c0.pad = 1;
             *cout = c0;
         }
@@ -2238,8 +2249,9 @@ __global__ __launch_bounds__(kDenseThreads) void k_dense_pcg(const double* __res
 __global__ __launch_bounds__(1024) void k_pcg_init(const double* __restrict__ Ugc,
                                                    const double* __restrict__ acc,
                                                    const double* __restrict__ Minv, int C,
-                                                   double* __restrict__ vecs, double tol,
+                                                   double* __restrict__ vecs, const double* __restrict__ tol_dev,
                                                    int max_iters, PcgCtrl* __restrict__ ctrl2) {
+    const double tol = *tol_dev;                 // the forcing term k_prep left for this iteration
     __shared__ double red[16];
     const size_t n6 = 6 * (size_t)C;
     double* __restrict__ xk = vecs + kPcgX * n6;

@@ -43,13 +43,14 @@ constexpr size_t kLdsDynMax = kLdsBytes - 2048; // dynamic part; every kernel he
 //                              slice (grouped so that each phase all-reduces one contiguous run of fresh values)
 //   max over ranks    [12]   : q0 = max|g| of the point slice
 //   device-local      [13]   : regularisation term of this iteration (k_prep)
+//                     [14,15]: |g_h|^2 of the previous iterate, forcing term of this iteration's PCG (k_prep)
 //   never exchanged   [16..24]: q0..q8 of the camera slice (replicated on every rank)
 constexpr int kScalSlots = 32;
 // Per-workgroup partial sums live in two halves of one buffer: A (k_update_scale, the cost of
 // k_resjac) and B (k_jdot, k_backsub).  Consecutive producers alternate halves, so the final sums of one
 // producer can ride along with the NEXT producer's launch (Piggyback) without a race on the rows.
 constexpr int kPartRows = 2048;
-constexpr int kMaxSlot = 12, kRegSlot = 13, kCamSlot = 16;
+constexpr int kMaxSlot = 12, kRegSlot = 13, kGhPrevSlot = 14, kEtaSlot = 15, kCamSlot = 16;
 constexpr int kPointSlot[9] = {12, 8, 9, 10, 11, 4, 5, 6, 7};     // slot of q0..q8 of the point slice
 
 struct DevBuf {
@@ -659,7 +660,8 @@ int launch_point_sweep(sfmba_handle* h, const double* vin, const PcgCtrl* ctrl2,
 int launch_pcg_fused(sfmba_handle* h, int L) {
     const int grid = (h->n_ranges + kWavesPerSweepBlock - 1) / kWavesPerSweepBlock;
     PcgFused pf{h->Dc.as<double>(), h->Minv.as<double>(), h->Ugc(), h->vecs.as<double>(), h->ctrl.as<PcgCtrl>(),
-                h->pcg_tol, h->pcg_cap, h->pcg_local ? h->pcg_part.as<double>() : (double*)nullptr};
+                h->pcg_tol, h->pcg_cap, (const double*)(h->scal() + kEtaSlot),
+                h->pcg_local ? h->pcg_part.as<double>() : (double*)nullptr};
     if (h->sweep_rc) {
         const size_t lds_rc = sizeof(double) * kRcRow * (size_t)h->C;
         auto kern_rc = k_point_sweep_rc<true>;
@@ -931,8 +933,8 @@ int pcg_start(sfmba_handle* h, const sfmba_options& opt) {
         return 0;
     }
     hipLaunchKernelGGL(k_pcg_init, dim3(1), dim3(1024), 0, h->stream, h->Ugc(), (const double*)h->acc(),
-                       h->Minv.as<double>(), (int)h->C, h->vecs.as<double>(), opt.pcg_tol, pcg_max_iters(h, opt),
-                       h->ctrl.as<PcgCtrl>());
+                       h->Minv.as<double>(), (int)h->C, h->vecs.as<double>(), (const double*)(h->scal() + kEtaSlot),
+                       pcg_max_iters(h, opt), h->ctrl.as<PcgCtrl>());
     LAUNCHED(h);
     return 0;
 }
@@ -1033,7 +1035,7 @@ void sfmba_default_options(sfmba_options* o) {
     o->ftol = 1e-8; o->xtol = 1e-8; o->gtol = 1e-8;
     o->max_nfev = 0; o->verbose = 0; o->max_iter = 0;
     o->pcg_tol = 1e-2; o->pcg_max_iter = 0; o->pcg_check_every = 2;
-    o->reg_min = 1e-6; o->profile = 0;
+    o->reg_min = 1e-6; o->profile = 0; o->reserved = 0; o->pcg_tol_max = 0.1;
 }
 
 int sfmba_create(sfmba_handle** out, int device_id) {
@@ -1917,6 +1919,7 @@ static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt
     h->tab = h->tabA.as<double>(); h->tab_new = h->tabB.as<double>();
     h->rec = h->recA.as<double>(); h->rec_new = h->recB.as<double>();
     CHK(upload_x(h, x_inout));
+    HIPCHK(h, hipMemsetAsync(h->scal() + kGhPrevSlot, 0, 2 * sizeof(double), h->stream));   // forcing-term memory of k_prep
     const double t_dev0 = now_s();
     report_stall(h, "upload_x", t_dev0 - t_begin);
 
@@ -2025,7 +2028,8 @@ static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt
                                h->V.as<double>(), h->gp.as<double>(), h->si.as<double>(), (int)C, (int)P, bc,
                                h->Dc.as<double>(), (h->dbg.precond == 0 ? h->Minv.as<double>() : (double*)nullptr),
                                h->Vinv.as<double>(), h->rec + 3,
-                               one_rank ? (const double*)h->partB() : (const double*)nullptr, np);
+                               one_rank ? (const double*)h->partB() : (const double*)nullptr, np, opt.pcg_tol,
+                               std::max(opt.pcg_tol, opt.pcg_tol_max));
             LAUNCHED(h);
         }
         const bool dense = h->dense && one_rank;               // (sharded: the block pairs would need their own all-reduce)

@@ -27,7 +27,8 @@ class Options(C.Structure):
     _fields_ = [("ftol", C.c_double), ("xtol", C.c_double), ("gtol", C.c_double),
                 ("max_nfev", C.c_int64), ("verbose", C.c_int32), ("max_iter", C.c_int32),
                 ("pcg_tol", C.c_double), ("pcg_max_iter", C.c_int32), ("pcg_check_every", C.c_int32),
-                ("reg_min", C.c_double), ("profile", C.c_int32), ("reserved", C.c_int32)]
+                ("reg_min", C.c_double), ("profile", C.c_int32), ("reserved", C.c_int32),
+                ("pcg_tol_max", C.c_double)]
 
 
 class Result(C.Structure):

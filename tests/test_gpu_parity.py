@@ -275,7 +275,7 @@ def _oracle_kwargs(dense):
     inside one workgroup.  Same algorithm, so one restatement in the oracle."""
     if dense:         # in LDS: a decade tighter, and the preconditioner blocks are those of the formed matrix
         return dict(linear="pcg", pcg_tol=1e-3, precond="schur_exact")
-    return dict(linear="pcg", pcg_tol=1e-2, precond="schur")
+    return dict(linear="pcg", pcg_tol=1e-2, pcg_tol_max=0.1, precond="schur")
 
 
 def _ran_dense(be, calls):

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol(lib):
 
 def test_struct_layouts_match_header():
     from sfmba import _capi
-    assert ctypes.sizeof(_capi.Options) == 72
+    assert ctypes.sizeof(_capi.Options) == 80
     assert ctypes.sizeof(_capi.Result) == 128
 
 
