@@ -16,10 +16,12 @@ be.set_precision(bits)
 be.set_problem(*pb.args)
 opt = be.default_options()
 opt.ftol = 1e-10
+opt.profile = 1 if os.environ.get("SFMBA_K1_EVENTS") else 0      # K1 bracketed by HIP events (in-solve duration)
 out = []
 for k in range(n):
     x, res, _, _ = be.solve(pb.x0, opt, want_fun=False, want_grad=False)
-    out.append((res.iterations, res.nfev, res.pcg_iterations, res.seconds_total, res.rmse))
+    out.append((res.iterations, res.nfev, res.pcg_iterations, res.seconds_total, res.rmse, res.resjac_avg_us))
 it = sum(o[0] for o in out[n // 2:]); t = sum(o[3] for o in out[n // 2:])
 print(cfg, bits, "iterations/solve", sorted(set(o[0] for o in out)), "pcg", sorted(set(o[2] for o in out)),
-      "rmse", out[-1][4], "it/s %.1f" % (it / t), "ms/solve %.3f" % (1e3 * t / (n - n // 2)))
+      "rmse", out[-1][4], "it/s %.1f" % (it / t), "ms/solve %.3f" % (1e3 * t / (n - n // 2)),
+      *(("K1 in-solve us %.2f" % (sum(o[5] for o in out[n // 2:]) / (n - n // 2)),) if opt.profile else ()))
