@@ -132,6 +132,32 @@ def test_ring_scene_large_rotations_match_scipy():
     assert np.abs(res.fun - g["ring_fun"]).max() < 5e-2
 
 
+def test_solver_settings_of_the_hip_path_reach_scipys_answer():
+    """The restatement with the settings the HIP path ships -- Schur-diagonal preconditioner, adaptive forcing term
+    (1e-2 ... 0.1), or, for few cameras, the diagonal blocks of the formed matrix and a fixed 1e-3 -- against scipy's
+    recorded results on the tiny problems and the ring; the exact-block preconditioner equals the per-observation one
+    when no (camera, point) pair is observed twice."""
+    from sfmba.synthetic import make_ring_problem
+    g = np.load(os.path.join(GOLDEN, "lsq_tiny_cases.npz"))
+    for k in range(int(g["n_cases"])):
+        pre = f"l{k}_"
+        C, P, N = (int(v) for v in g[pre + "dims"])
+        pb = make_problem(C, P, N, seed=int(g[pre + "seed"]))
+        status, nfev, njev, cost, rmse, opt = g[pre + "summary"]
+        for kw in (dict(pcg_tol=1e-2, pcg_tol_max=0.1, precond="schur"), dict(pcg_tol=1e-3, precond="schur_exact")):
+            res = orc.trf_schur(pb.x0, *pb.args, ftol=1e-10, linear="pcg", **kw)
+            assert res.status in (1, 2, 3, 4), kw
+            assert abs(float(np.sqrt(np.mean(res.fun ** 2))) - rmse) < 1e-6 and res.cost <= cost * (1 + 1e-9), kw
+    pb = make_ring_problem(12, 150, 900, seed=1)
+    key = pb.camera_indices.astype(np.int64) * pb.n_points + pb.point_indices
+    if len(np.unique(key)) == len(key):                    # no duplicated pair: the two preconditioners coincide
+        a = orc.trf_schur(pb.x0, *pb.args, ftol=1e-10, linear="pcg", pcg_tol=1e-3, precond="schur", max_nfev=4)
+        b = orc.trf_schur(pb.x0, *pb.args, ftol=1e-10, linear="pcg", pcg_tol=1e-3, precond="schur_exact", max_nfev=4)
+        assert np.abs(a.x - b.x).max() <= 1e-9 * np.abs(a.x).max()
+    with pytest.raises(ValueError):
+        orc.trf_schur(pb.x0, *pb.args, ftol=1e-10, linear="pcg", pcg_tol=1e-3, precond="nope", max_nfev=2)
+
+
 def test_trf_schur_cfg2_matches_recorded_scipy_run():
     path = os.path.join(GOLDEN, "scipy_cfg2_run.json")
     if not os.path.exists(path):
