@@ -1546,12 +1546,43 @@ __global__ __launch_bounds__(kSweepThreads) void k_point_sweep(
 constexpr int kRcRow = 18;
 constexpr int kRcMaxCams = 1100;          // 18 doubles x C within the 160 KiB LDS (FUSED additionally needs C <= 1024)
 
-template <bool FUSED>
+// The table of the recomputing pass A in global memory (GTAB): R | T | a' | u_T per camera, 18 doubles, for the vector
+// u of the current PCG iterate (u_planes: plane-major [6][C]; with ctrl2 the base of the vector sets, as in the sweep).
+__global__ __launch_bounds__(256) void k_rc_table(const double* __restrict__ camtab, const double* __restrict__ u_planes,
+                                                  const PcgCtrl* __restrict__ ctrl2, int L, int C,
+                                                  double* __restrict__ rctab) {
+    if (ctrl2 != nullptr) {
+        const PcgCtrl* __restrict__ ctrl = ctrl2 + (L & 1);
+        if (ctrl->done != 0) return;                          // grid-uniform
+        u_planes += (size_t)((ctrl->iters & 1) * kPcgVecs + kPcgU) * 6 * C;
+    }
+    const int cam = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cam >= C) return;
+    const double* __restrict__ rt = camtab + cam_rt_offset(C) + (size_t)kCamRT * cam;
+    const double* __restrict__ wbc = camtab + cam_wbc_offset(C);
+    double* __restrict__ row = rctab + (size_t)kRcRow * cam;
+#pragma unroll
+    for (int k = 0; k < kCamRT; ++k) row[k] = rt[k];
+    double u[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) u[k] = u_planes[(size_t)k * C + cam];
+    const double wx = wbc[cam], wy = wbc[(size_t)C + cam], wz = wbc[2 * (size_t)C + cam];
+    const double b = wbc[3 * (size_t)C + cam], cc = wbc[4 * (size_t)C + cam];
+    const double c0 = wy * u[2] - wz * u[1], c1 = wz * u[0] - wx * u[2], c2 = wx * u[1] - wy * u[0];   // w x u_w
+    const double d0 = wy * c2 - wz * c1, d1 = wz * c0 - wx * c2, d2 = wx * c1 - wy * c0;               // w x (w x u_w)
+    row[12] = u[0] - b * c0 + cc * d0; row[13] = u[1] - b * c1 + cc * d1; row[14] = u[2] - b * c2 + cc * d2;
+    row[15] = u[3]; row[16] = u[4]; row[17] = u[5];
+}
+
+// GTAB (more cameras than the LDS holds): the table [C][18] was written to global memory by k_rc_table and its rows are
+// gathered from L2 by nine 16-byte loads per observation; `vin` is not used.
+template <bool FUSED, bool GTAB = false>
 __global__ __launch_bounds__(kSweepThreads) void k_point_sweep_rc(
     StepTable st, const int* __restrict__ cam_idx, const int* __restrict__ pt_idx,
     const double* __restrict__ camtab, const double* __restrict__ pts, KMat K, const double* __restrict__ vin,
     const double* __restrict__ Vinv, double* __restrict__ zout, const double* __restrict__ acc, int C,
-    const PcgCtrl* __restrict__ ctrl2, int L, PcgFused pf) {
+    const PcgCtrl* __restrict__ ctrl2, int L, PcgFused pf, const double* __restrict__ rctab) {
+    static_assert(!(FUSED && GTAB), "the fused PCG update needs the table in LDS");
     extern __shared__ __align__(16) double smem[];
     const int n6 = 6 * C;
     const int wg = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -1588,22 +1619,27 @@ __global__ __launch_bounds__(kSweepThreads) void k_point_sweep_rc(
             if (ctrl->done != 0) return;                      // grid-uniform
             vin += (size_t)((ctrl->iters & 1) * kPcgVecs + kPcgU) * n6;
         }
-        for (int cam = threadIdx.x; cam < C; cam += blockDim.x) {     // vin: plane-major [6][C]
-            double u[6];
+        if (!GTAB) {
+            for (int cam = threadIdx.x; cam < C; cam += blockDim.x) {     // vin: plane-major [6][C]
+                double u[6];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) u[k] = vin[(size_t)k * C + cam];
-            put_au(cam, u);
+                for (int k = 0; k < 6; ++k) u[k] = vin[(size_t)k * C + cam];
+                put_au(cam, u);
+            }
         }
     }
-    for (int e = threadIdx.x; e < C * (kCamRT / 2); e += blockDim.x) {     // R | T: 6 x 16 bytes per camera, coalesced
-        const int cam = e / (kCamRT / 2), k = e - cam * (kCamRT / 2);
-        reinterpret_cast<double2*>(smem + (size_t)kRcRow * cam)[k] = reinterpret_cast<const double2*>(rt)[e];
+    if (!GTAB) {
+        for (int e = threadIdx.x; e < C * (kCamRT / 2); e += blockDim.x) {     // R | T: 6 x 16 bytes per camera, coalesced
+            const int cam = e / (kCamRT / 2), k = e - cam * (kCamRT / 2);
+            reinterpret_cast<double2*>(smem + (size_t)kRcRow * cam)[k] = reinterpret_cast<const double2*>(rt)[e];
+        }
+        __syncthreads();
     }
-    __syncthreads();
+    const double* __restrict__ table = GTAB ? rctab : smem;
 
-    // y contribution of one observation: camera row `cc` (LDS), point X
+    // y contribution of one observation: camera row `cc` (LDS, or L2 with GTAB), point X
     auto contrib = [&](int cc, double X, double Y, double Z, double* y) {
-        const double2* __restrict__ row = reinterpret_cast<const double2*>(smem + (size_t)kRcRow * cc);
+        const double2* __restrict__ row = reinterpret_cast<const double2*>(table + (size_t)kRcRow * cc);
         const double2 r01 = row[0], r23 = row[1], r45 = row[2], r67 = row[3], r8t = row[4], t12 = row[5];
         const double2 a01 = row[6], a2u = row[7], u12 = row[8];
         const double R0 = r01.x, R1 = r01.y, R2 = r23.x, R3 = r23.y, R4 = r45.x, R5 = r45.y, R6 = r67.x, R7 = r67.y,

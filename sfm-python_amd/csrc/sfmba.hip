@@ -218,6 +218,8 @@ struct sfmba_handle {
     bool f32_next = false;                   // takes effect at the next sfmba_set_problem
     bool lds_tab = true, lds_vec = true;     // camera table (K1, K2) / camera vector (sweeps) staged in LDS
     bool sweep_rc = false;                   // pass A recomputes the blocks from an LDS table (k_point_sweep_rc)
+    bool sweep_rc_g = false;                 // ... from a table in global memory (more cameras than the LDS holds)
+    DevBuf rctab;                            // [C][18], k_rc_table
     bool dense = false;                      // reduced camera matrix formed and factorised (6 C <= kDenseMaxN) instead of PCG
     DevBuf cov_ptr, cov_pt, blk_ab, Sblk;    // dense path: per block pair (a <= b) the points both cameras see
     int n_blk = 0;
@@ -637,7 +639,18 @@ int launch_point_sweep(sfmba_handle* h, const double* vin, const PcgCtrl* ctrl2,
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), lds, h->stream, step_table(h), (const int*)h->cam_idx.as<int>(),
                            (const int*)h->pt_idx.as<int>(), (const double*)h->tab, (const double*)(h->x + 6 * h->C), h->K, vin,
                            (const double*)h->Vinv.as<double>(), h->rec, (const double*)h->acc(), (int)h->C, ctrl2, L,
-                           PcgFused{});
+                           PcgFused{}, (const double*)nullptr);
+        LAUNCHED(h);
+        return 0;
+    }
+    if (h->sweep_rc_g) {                  // the same with its table in global memory: one small launch builds it
+        hipLaunchKernelGGL(k_rc_table, dim3((unsigned)((h->C + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->tab, vin,
+                           ctrl2, L, (int)h->C, h->rctab.as<double>());
+        LAUNCHED(h);
+        hipLaunchKernelGGL((k_point_sweep_rc<false, true>), dim3(grid), dim3(kSweepThreads), 0, h->stream, step_table(h),
+                           (const int*)h->cam_idx.as<int>(), (const int*)h->pt_idx.as<int>(), (const double*)h->tab,
+                           (const double*)(h->x + 6 * h->C), h->K, vin, (const double*)h->Vinv.as<double>(), h->rec,
+                           (const double*)h->acc(), (int)h->C, ctrl2, L, PcgFused{}, (const double*)h->rctab.as<double>());
         LAUNCHED(h);
         return 0;
     }
@@ -670,7 +683,7 @@ int launch_pcg_fused(sfmba_handle* h, int L) {
                            (const int*)h->cam_idx.as<int>(), (const int*)h->pt_idx.as<int>(), (const double*)h->tab,
                            (const double*)(h->x + 6 * h->C), h->K, (const double*)h->vecs.as<double>(),
                            (const double*)h->Vinv.as<double>(), h->rec, (const double*)h->acc(), (int)h->C,
-                           (const PcgCtrl*)h->ctrl.as<PcgCtrl>(), L, pf);
+                           (const PcgCtrl*)h->ctrl.as<PcgCtrl>(), L, pf, (const double*)nullptr);
         LAUNCHED(h);
         return 0;
     }
@@ -690,7 +703,7 @@ template <int MODE>
 int launch_cam_schur(sfmba_handle* h, const double* vin, const PcgCtrl* ctrl_done, int set, bool local = false) {
     const PcgLocal pl{h->Dc.as<double>(), h->Minv.as<double>(), h->vecs.as<double>(),
                       local ? h->pcg_part.as<double>() : (double*)nullptr};
-    if (h->f32 && !h->sweep_rc)           // pass A applies the stored fp32 blocks: pass B rounds its own the same way
+    if (h->f32 && !h->sweep_rc && !h->sweep_rc_g)   // pass A applies the stored fp32 blocks: pass B rounds its own the same way
         hipLaunchKernelGGL((k_cam_schur<MODE, true>), dim3(h->n_chunks), dim3(kCamThreads), 0, h->stream, cam_major(h),
                            (const double*)h->tab, (const double*)h->rec, h->K, vin, (int)h->C, h->acc(),
                            h->cam_partial.as<double>(), ctrl_done, set, pl);
@@ -711,7 +724,7 @@ int launch_rhs_and_preconditioner(sfmba_handle* h) {
         CHK(launch_cam_schur<1>(h, nullptr, nullptr, 0));
         return exchange(h, h->acc(), 6 * C, 0);
     }
-    if (h->f32 && !h->sweep_rc)
+    if (h->f32 && !h->sweep_rc && !h->sweep_rc_g)
         hipLaunchKernelGGL((k_cam_rhs_diag<true>), dim3(h->n_chunks), dim3(kRhsThreads), 0, h->stream, cam_major(h),
                            (const double*)h->tab, (const double*)h->rec, (const double*)h->Vinv.as<double>(), h->K, (int)C,
                            h->acc(), h->cam_partial.as<double>());
@@ -755,7 +768,7 @@ int launch_dense_solve(sfmba_handle* h, double tol, int max_iters, bool rhs) {
 // acc = (S - Dc) v for a plane-major vector v outside the PCG (test and timing entries): pass A, pass B
 int schur_product_standalone(sfmba_handle* h, const double* v_planes) {
     const double* va = v_planes;
-    if (!h->lds_vec && !h->sweep_rc) {    // pass A gathers v from a camera-major copy in L2
+    if (!h->lds_vec && !h->sweep_rc && !h->sweep_rc_g) {    // pass A gathers v from a camera-major copy in L2
         hipLaunchKernelGGL(k_transpose, dim3((unsigned)((6 * h->C + 255) / 256)), dim3(256), 0, h->stream, v_planes,
                            6, (int)h->C, h->vcm.as<double>(), (const PcgCtrl*)nullptr, 0);
         LAUNCHED(h);
@@ -1564,6 +1577,7 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     if (h->dbg.tab_lds == 0) h->lds_tab = false;               // test hooks (sfmba_debug_option): force the L2 placements
     if (h->dbg.vec_lds == 0) h->lds_vec = false;
     h->sweep_rc = C <= kRcMaxCams && (size_t)C * kRcRow * sizeof(double) <= kLdsDynMax && h->dbg.sweep_rc != 0;
+    h->sweep_rc_g = !h->sweep_rc && h->dbg.sweep_rc != 0;      // too many cameras for the LDS: the table lives in L2
     h->pcg_fused = (h->lds_vec || h->sweep_rc) && C <= kSweepThreads;
     if (h->dbg.pcg_fused == 0) h->pcg_fused = false;
 
@@ -1615,6 +1629,7 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     HIPCHK(h, h->vecs.ensure(sizeof(double) * 2 * kPcgVecs * 6 * C));
     HIPCHK(h, h->vtmp.ensure(sizeof(double) * 6 * C));
     HIPCHK(h, h->vcm.ensure(sizeof(double) * 6 * C));
+    if (h->sweep_rc_g) HIPCHK(h, h->rctab.ensure(sizeof(double) * kRcRow * (size_t)C));
     h->red_bc = grid_1d(6 * C, 256, 32);
     h->red_grid = h->red_bc + grid_1d(3 * P, 256, 992);   // <= 1024 partial rows, summed by k_jdot's rider workgroup
     HIPCHK(h, h->part.ensure(sizeof(double) * (size_t)(2 * kPartRows * kNQ)));
@@ -1857,7 +1872,7 @@ int sfmba_time_kernel(sfmba_handle* h, const double* x, int32_t which, int32_t r
             case 1: CHK((launch_resjac<false, false>(h, h->x, h->tab, &np))); break;
             case 2: CHK(launch_normal_blocks(h, h->x, h->tab, h->rec)); break;
             case 3: CHK(schur_product_standalone(h, h->vtmp.as<double>())); break;
-            case 4: CHK(launch_point_sweep(h, (h->lds_vec || h->sweep_rc) ? h->vtmp.as<double>() : h->vcm.as<double>(), nullptr, 0)); break;
+            case 4: CHK(launch_point_sweep(h, (h->lds_vec || h->sweep_rc || h->sweep_rc_g) ? h->vtmp.as<double>() : h->vcm.as<double>(), nullptr, 0)); break;
             case 5: CHK(launch_cam_schur<0>(h, h->vtmp.as<double>(), nullptr, 0)); break;
             case 6: CHK(launch_cam_schur<1>(h, nullptr, nullptr, 0)); break;
             case 7: CHK((launch_resjac<true, true>(h, h->x, h->tab, &np, nullptr, nullptr, /*blocks=*/false))); break;
