@@ -280,6 +280,9 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         n_launch1, n_coll1 = be.counters()
+        # outside the timed region: the same residual+Jacobian kernel compiled WITHOUT the point-block sums (another
+        # symbol, so its launches do not mix with the solver's in a rocprofv3 trace of this command), back to back
+        k1_plain_us = be.time_kernel(pb.x0, 7, 50) if world == 1 else None
 
     if td is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -339,7 +342,14 @@ def main():
                                  "not stored; SURVEY 8d's 184 N figure writes it a second time",
                          "achieved_if_counted_as_survey_184B": (k1_bytes_survey(Cl, Pl, Nl) / (k1_us * 1e-6) / 1e9)
                                                                 if k1_us > 0 else None,
-                         "launches_timed": sum(r[4] for r in results)},
+                         "launches_timed": sum(r[4] for r in results),
+                         "without_point_blocks": (None if not k1_plain_us else {
+                             "note": "k_resjac<...,BLOCKS=false>: the kernel as it was before it absorbed the point pass "
+                                     "(V_p, g_p; 72 B per point less), 50 back-to-back launches outside the timed region",
+                             "avg_launch_us": k1_plain_us,
+                             "algorithmic_bytes_per_launch": kb(Cl, Pl, Nl) - 72 * Pl,
+                             "achieved": (kb(Cl, Pl, Nl) - 72 * Pl) / (k1_plain_us * 1e-6) / 1e9,
+                             "frac": (kb(Cl, Pl, Nl) - 72 * Pl) / (k1_plain_us * 1e-6) / 1e9 / HBM_PEAK_GBS})},
         }
         if world == 1 and not a.no_per_call:
             line["per_call_ms"] = per_call_times(a.workload, a.storage_bits)

@@ -453,7 +453,7 @@ struct PointBlocksOut {
     double* __restrict__ edge;                   // [tiles][2][kEdgeRow]
 };
 
-template <bool LDS_TAB, bool JAC, bool STORE_R, bool F32>
+template <bool LDS_TAB, bool JAC, bool STORE_R, bool F32, bool BLOCKS = false>
 __global__ __launch_bounds__(kSweepThreads) void k_resjac(
     const double* __restrict__ camtab, const double* __restrict__ pts, const int* __restrict__ cam_idx,
     const int* __restrict__ pt_idx, const double* __restrict__ uv, double* __restrict__ r,
@@ -464,7 +464,8 @@ __global__ __launch_bounds__(kSweepThreads) void k_resjac(
     if (skip != nullptr && *skip != 0.0) return;   // speculative launch cancelled by k_tr_step
     const int stride = gridDim.x * blockDim.x;
     const int lane = threadIdx.x & 63;
-    const bool blocks = JAC && pb.V != nullptr;    // grid-uniform
+    static_assert(JAC || !BLOCKS, "the point blocks are sums of Jacobian entries");
+    constexpr bool blocks = BLOCKS;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     // pipeline registers: batch i (uv, X ready), batch i+stride (indices ready)
     int c0 = 0, p0 = 0, c1 = 0, p1 = 0;

@@ -523,12 +523,12 @@ PointBlocksOut point_blocks_out(sfmba_handle* h) {
     return PointBlocksOut{h->V.as<double>(), h->gp.as<double>(), h->edge.as<double>()};
 }
 
-template <bool LDS, bool JAC, bool STORE_R, bool F32>
-int launch_resjac_v(sfmba_handle* h, const double* x, const double* tab, int grid, size_t lds,
-                    hipEvent_t ev0, hipEvent_t ev1, bool blocks) {
+template <bool LDS, bool JAC, bool STORE_R, bool F32, bool BLOCKS>
+int launch_resjac_b(sfmba_handle* h, const double* x, const double* tab, int grid, size_t lds,
+                    hipEvent_t ev0, hipEvent_t ev1) {
     const double* pts = x + 6 * h->C;
-    const PointBlocksOut pb = blocks ? point_blocks_out(h) : PointBlocksOut{nullptr, nullptr, nullptr};
-    auto kern = k_resjac<LDS, JAC, STORE_R, F32>;
+    const PointBlocksOut pb = BLOCKS ? point_blocks_out(h) : PointBlocksOut{nullptr, nullptr, nullptr};
+    auto kern = k_resjac<LDS, JAC, STORE_R, F32, BLOCKS>;
     CHK(set_lds(h, kern, lds));
     if (ev0) {
         hipExtLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), (uint32_t)lds, h->stream, ev0, ev1, 0u, tab, pts,
@@ -543,6 +543,14 @@ int launch_resjac_v(sfmba_handle* h, const double* x, const double* tab, int gri
     }
     LAUNCHED(h);
     return 0;
+}
+template <bool LDS, bool JAC, bool STORE_R, bool F32>
+int launch_resjac_v(sfmba_handle* h, const double* x, const double* tab, int grid, size_t lds,
+                    hipEvent_t ev0, hipEvent_t ev1, bool blocks) {
+    if constexpr (JAC) {
+        if (blocks) return launch_resjac_b<LDS, JAC, STORE_R, F32, true>(h, x, tab, grid, lds, ev0, ev1);
+    }
+    return launch_resjac_b<LDS, JAC, STORE_R, F32, false>(h, x, tab, grid, lds, ev0, ev1);
 }
 
 // `blocks`: the Jacobian launch also leaves V_p, g_p of x (the point half of the normal equations; the camera half
