@@ -13,11 +13,10 @@ def main():
     t = time.time(); pb = sfmba.make_config(cfg); print("gen s", time.time() - t, flush=True)
     be = sfmba.get_backend(0)
     t = time.time(); be.set_problem(*pb.args); print("set_problem s", time.time() - t, flush=True)
-    bytes_k1 = 136 * N + 24 * P + 48 * C
-    for which, name, nbytes in [(0, "resjac", bytes_k1), (1, "residual", 40 * N + 24 * P + 48 * C),
-                                (2, "normal_blocks", 40 * N + 96 * P + 264 * C), (3, "schur_product", 108 * N + 96 * P),
-                                (4, "pass_A", 104 * N + 72 * P), (5, "pass_B", 4 * N + 48 * P + 232 * C),
-                                (6, "rhs_pass", 4 * N + 48 * P + 184 * C)]:
+    for which, name, nbytes in [(0, "resjac+blocks", 136 * N + 96 * P + 48 * C), (7, "resjac alone", 136 * N + 24 * P + 48 * C),
+                                (1, "residual", 40 * N + 24 * P + 48 * C), (2, "camera_blocks", 52 * N + 216 * C),
+                                (3, "schur_product", 64 * N + 72 * P), (4, "pass_A", 8 * N + 72 * P),
+                                (5, "pass_B", 52 * N + 232 * C), (6, "rhs_pass", 52 * N + 184 * C)]:
         us = be.time_kernel(pb.x0, which, 20)
         print(f"{name:14s} {us:9.2f} us  {nbytes / us / 1e3:8.1f} GB/s (algorithmic)", flush=True)
     for it in range(2):
