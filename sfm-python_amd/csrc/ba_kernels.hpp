@@ -1930,11 +1930,19 @@ __global__ __launch_bounds__(kCamThreads) void k_cam_schur(CamMajor cm, const do
 // 192-thread workgroups: the kernel needs ~150 VGPRs (three waves per SIMD), and four 3-wave workgroups per CU keep
 // 1024 camera workgroups resident at once where three 4-wave ones would take a 1000-camera problem in two rounds.
 constexpr int kRhsThreads = 192;
+// minv (one rank, every camera a single chunk): the workgroup also inverts its camera's preconditioner block
+// (U + Dc - sd), which is complete the moment its 27 sums are -- k_cam_prep_schur's work without its launch.
+struct RhsPrecond {
+    const double* __restrict__ Ugc;      // null: Minv is made by k_cam_prep_schur (several ranks or chunks)
+    const double* __restrict__ Dc;
+    double* __restrict__ Minv;
+};
 template <bool ROUND>
 __global__ __launch_bounds__(kRhsThreads) void k_cam_rhs_diag(CamMajor cm, const double* __restrict__ camtab,
                                                               const double* __restrict__ rec,
                                                               const double* __restrict__ Vinv, KMat K, int C,
-                                                              double* __restrict__ out, double* __restrict__ partial) {
+                                                              double* __restrict__ out, double* __restrict__ partial,
+                                                              RhsPrecond mp) {
     __shared__ double red[kRhsThreads / 64][27];
     const int4 ch = cm.chunks[blockIdx.x];
     double t[kCamTab];
@@ -1996,6 +2004,28 @@ __global__ __launch_bounds__(kRhsThreads) void k_cam_rhs_diag(CamMajor cm, const
     if (threadIdx.x < 27) {
         if (ch.w == 1) out[(size_t)threadIdx.x * C + ch.x] = s;
         else partial[(size_t)blockIdx.x * 27 + threadIdx.x] = s;
+    }
+    if (mp.Ugc != nullptr) {                                  // (ch.w == 1 for every camera on this path)
+        __shared__ double sdl[21];
+        if (threadIdx.x >= 6 && threadIdx.x < 27) sdl[threadIdx.x - 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double B[6][6], inv[21];
+            int n = 0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = i; j < 6; ++j) {
+                    B[i][j] = mp.Ugc[(size_t)ch.x * 27 + n] - sdl[n];
+                    B[j][i] = B[i][j];
+                    ++n;
+                }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) B[i][i] += mp.Dc[(size_t)i * C + ch.x];
+            spd6_inverse(B, inv);
+#pragma unroll
+            for (int q = 0; q < 21; ++q) mp.Minv[(size_t)q * C + ch.x] = inv[q];
+        }
     }
 }
 

@@ -732,15 +732,19 @@ int launch_rhs_and_preconditioner(sfmba_handle* h) {
         CHK(launch_cam_schur<1>(h, nullptr, nullptr, 0));
         return exchange(h, h->acc(), 6 * C, 0);
     }
+    // one rank and single-chunk cameras: every workgroup inverts its own preconditioner block (RhsPrecond)
+    const bool own_inverse = !multi_rank(h) && !h->cam_multi;
+    const RhsPrecond mp = own_inverse ? RhsPrecond{h->Ugc(), h->Dc.as<double>(), h->Minv.as<double>()} : RhsPrecond{nullptr, nullptr, nullptr};
     if (h->f32 && !h->sweep_rc && !h->sweep_rc_g)
         hipLaunchKernelGGL((k_cam_rhs_diag<true>), dim3(h->n_chunks), dim3(kRhsThreads), 0, h->stream, cam_major(h),
                            (const double*)h->tab, (const double*)h->rec, (const double*)h->Vinv.as<double>(), h->K, (int)C,
-                           h->acc(), h->cam_partial.as<double>());
+                           h->acc(), h->cam_partial.as<double>(), mp);
     else
         hipLaunchKernelGGL((k_cam_rhs_diag<false>), dim3(h->n_chunks), dim3(kRhsThreads), 0, h->stream, cam_major(h),
                            (const double*)h->tab, (const double*)h->rec, (const double*)h->Vinv.as<double>(), h->K, (int)C,
-                           h->acc(), h->cam_partial.as<double>());
+                           h->acc(), h->cam_partial.as<double>(), mp);
     LAUNCHED(h);
+    if (own_inverse) return 0;
     CHK(launch_cam_combine(h, 27, h->acc(), 1, (int)C, nullptr, nullptr));
     CHK(exchange(h, h->acc(), 27 * C, 0));                  // acc | sd: one contiguous plane-major vector
     hipLaunchKernelGGL(k_cam_prep_schur, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, h->stream, (const double*)h->Ugc(),
