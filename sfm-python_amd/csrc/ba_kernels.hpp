@@ -1728,6 +1728,74 @@ __global__ __launch_bounds__(kSweepThreads) void k_point_sweep_rc(
     }
 }
 
+// The local form of the PCG update as a kernel of its own (more cameras than the fused launch takes: one thread per
+// camera of a 1024-thread workgroup).  Pass B's workgroup of every camera has done that camera's bookkeeping and left
+// four partial dot products (PcgLocal); this kernel sums them -- every workgroup all of them, in the same order -- and
+// applies  u <- u - alpha m  to its own 1024 cameras.  Same arithmetic as the local branch of pcg_fused_update, shifted
+// by one in the launch index: launch L reads u from vector set L & 1 and the control block ctrl2[L & 1], writes set
+// (L + 1) & 1 and ctrl2[(L + 1) & 1].  (The two-kernel update it replaces, k_pcg_update, reads 51 doubles per camera
+// in every one of its workgroups: 49 us at 5000 cameras.)
+__global__ __launch_bounds__(1024) void k_pcg_update_local(double* __restrict__ vecs, const double* __restrict__ part,
+                                                           PcgCtrl* __restrict__ ctrl2, int L, int C) {
+    __shared__ double red4[16][4];
+    const size_t n6 = 6 * (size_t)C;
+    const PcgCtrl ci = ctrl2[L & 1];
+    PcgCtrl* __restrict__ cout = ctrl2 + ((L + 1) & 1);
+    const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
+    if (ci.done != 0) {                                       // grid-uniform
+        if (writer) *cout = ci;
+        return;
+    }
+    double q4[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q4[k] += part[(size_t)k * C + c];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) q4[k] = wave_sum(q4[k]);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) red4[threadIdx.x >> 6][k] = q4[k];
+    }
+    __syncthreads();
+    double tot[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tot[k] += red4[w][k];
+    }
+    const double delta = tot[0], su = tot[1], sm = tot[2], gamma = tot[3];     // w.u, s.u, s.m, r.u (true gamma_i)
+    const double beta = ci.iters == 0 ? 0.0 : ci.rz / ci.rz_prev;             // the beta pass B built s and p with
+    const double den = delta - (ci.iters == 0 ? 0.0 : beta * gamma / ci.alpha_prev);
+    const double alpha = gamma / den;
+    if (!(den > 0.0) || !isfinite(alpha)) {                    // S not SPD / NaN: x stays the last good iterate
+        if (writer) { PcgCtrl co = ci; co.done = 3; *cout = co; }
+        return;
+    }
+    const double rz = gamma - 2.0 * alpha * su + alpha * alpha * sm;          // gamma_{i+1}
+    int done = 0;
+    if (!(rz > ci.tol2 * ci.rz0)) done = 1;                   // also catches NaN and a cancelled-out (<= 0) value
+    else if (ci.iters + 1 >= ci.max_iters) done = 2;
+    if (writer) {
+        PcgCtrl co = ci;
+        co.rz_prev = gamma; co.alpha_prev = alpha; co.rz = rz; co.iters = ci.iters + 1; co.done = done;
+        *cout = co;
+    }
+    const int cam = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cam >= C) return;
+    const double* __restrict__ vold = vecs + (size_t)(L & 1) * kPcgVecs * n6;
+    double* __restrict__ vnew = vecs + (size_t)((L + 1) & 1) * kPcgVecs * n6;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const size_t e = (size_t)k * C + cam;
+        vnew[kPcgU * n6 + e] = vold[kPcgU * n6 + e] - alpha * vecs[kPcgM * n6 + e];
+        if (done != 0) {                                      // the deferred x += alpha p of the last iteration (x is kept
+            const double xk = vecs[kPcgX * n6 + e] + alpha * vecs[kPcgP * n6 + e];     // in both sets)
+            vecs[kPcgX * n6 + e] = xk;
+            vecs[(size_t)kPcgVecs * n6 + kPcgX * n6 + e] = xk;
+        }
+    }
+}
+
 // Pass B: acc_c = sum_{i in c} Jc_i^T ( Jc_i v_c - Jp_i z_p )   (MODE 0; v_c wave-uniform, z gathered), or
 //         acc_c = - sum Jc_i^T Jp_i e_p                          (MODE 1; the z slot of the records holds e, written by
 //         k_prep), over one camera chunk, with the

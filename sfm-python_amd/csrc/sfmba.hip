@@ -294,6 +294,7 @@ struct sfmba_handle {
     double pcg_tol = 0.0; int pcg_cap = 0; // options of the running PCG (fused launch 0 writes the control block)
     bool pcg_fused = false;               // PCG update fused into the launch of pass A (v in LDS, C <= 1024)
     bool pcg_local = false;               // ... with the per-camera bookkeeping in pass B (one rank, single-chunk cameras)
+    bool pcg_local2 = false;              // the same bookkeeping with the light update as a kernel of its own (> 1024 cameras)
     DevBuf pcg_part;                      // [4][C] partial dot products of the local form
     int pcg_hint = 0;                     // largest PCG iteration count a solve on this handle has needed
     std::vector<int> pcg_hist;            // PCG iterations of outer iteration k in the previous solve on this handle: the
@@ -952,6 +953,7 @@ int pcg_max_iters(const sfmba_handle* h, const sfmba_options& opt) {
 int pcg_start(sfmba_handle* h, const sfmba_options& opt) {
     h->pcg_L = 0;
     h->pcg_local = h->pcg_fused && !multi_rank(h) && !h->cam_multi && h->dbg.pcg_local != 0;
+    h->pcg_local2 = !h->pcg_fused && h->sweep_rc_g && !multi_rank(h) && !h->cam_multi && h->dbg.pcg_local != 0;
     if (h->pcg_fused) {                   // launch 0 of the fused form initialises the solve itself
         h->pcg_tol = opt.pcg_tol;
         h->pcg_cap = pcg_max_iters(h, opt);
@@ -982,7 +984,14 @@ int pcg_enqueue(sfmba_handle* h, int count) {
         }
         const PcgCtrl* cd = ctrl2 + (L & 1);                     // current until k_pcg_update writes the other one
         CHK(launch_point_sweep(h, h->vecs.as<double>(), ctrl2, L));
-        CHK(launch_cam_schur<0>(h, h->vecs.as<double>(), cd, -1));
+        CHK(launch_cam_schur<0>(h, h->vecs.as<double>(), cd, -1, h->pcg_local2));
+        if (h->pcg_local2) {                                    // pass B did the bookkeeping: the light update
+            hipLaunchKernelGGL(k_pcg_update_local, dim3((unsigned)((h->C + 1023) / 1024)), dim3(1024), 0, h->stream,
+                               h->vecs.as<double>(), (const double*)h->pcg_part.as<double>(), ctrl2, L, (int)h->C);
+            LAUNCHED(h);
+            h->pcg_L = L + 1;
+            continue;
+        }
         CHK(exchange(h, h->acc(), 6 * h->C, 0, &cd->done));
         hipLaunchKernelGGL(k_pcg_update, dim3(kPcgUpdateBlocks), dim3(1024), 0, h->stream, (const double*)h->acc(),
                            h->Dc.as<double>(), h->Minv.as<double>(), (int)h->C, h->vecs.as<double>(), ctrl2, L);

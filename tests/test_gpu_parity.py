@@ -194,8 +194,8 @@ def test_random_track_length_distributions(be, orc):
 
 
 def test_many_cameras_global_table_variants(be, orc):
-    """More cameras than fit the LDS: 1300 (camera table of K1 read from L2), 1800 / 2600 (two-kernel PCG sizes),
-    21000 (camera vector of pass A gathered from the camera-major copy in L2)."""
+    """More cameras than fit the LDS: 1300 (camera table of K1 read from L2), 1800 / 2600 / 21000 (pass A with its
+    table in global memory)."""
     from sfmba import make_problem
     for C in (1300, 1800, 2600, 21000):
         pb = make_problem(C, 500, 6000, seed=C)
@@ -423,11 +423,14 @@ def test_fused_pcg_launch_equals_sweep_plus_update(dbg):
                 assert np.abs(a.fun - b.fun).max() <= 1e-6
 
 
-def test_full_solves_with_many_cameras_vs_oracle(orc):
-    """Camera counts past the fused PCG launch, the recomputing pass A and the LDS-resident camera table, end to
-    end: 1300 and 1800 cameras (camera table of K1 read from L2, pass A reading the stored Jacobian, k_pcg_update
-    as a kernel of its own)."""
+def test_full_solves_with_many_cameras_vs_oracle(orc, dbg):
+    """Camera counts past the fused PCG launch and the LDS-resident tables, end to end: 1300 and 1800 cameras (camera
+    table of K1 read from L2; pass A recomputing from a table in global memory, k_rc_table; the per-camera PCG
+    bookkeeping in pass B with k_pcg_update_local).  The older forms stay reachable through debug options and must
+    walk through the same iterations: the two-kernel update (pcg_local = 0) and pass A reading the stored Jacobian
+    (sweep_rc = 0)."""
     import sfmba
+    tls = sfmba.get_backend(0)
     for C, P, N in ((1300, 4000, 40000), (1800, 3000, 30000)):
         pb = sfmba.make_problem(C, P, N, seed=21)
         o = orc.trf_schur(pb.x0, *pb.args, ftol=1e-10, **_oracle_kwargs(False))
@@ -437,6 +440,15 @@ def test_full_solves_with_many_cameras_vs_oracle(orc):
         assert abs(res.cost - o.cost) <= 1e-9 * o.cost
         r = sfmba.compute_residuals(res.x, *pb.args)
         assert np.abs(r - res.fun).max() < 1e-8
+        if C == 1300:
+            for name in ("pcg_local", "sweep_rc"):
+                dbg((tls,), name, 0)
+                alt = sfmba.least_squares(sfmba.compute_residuals, pb.x0, x_scale="jac", ftol=1e-10, method="trf",
+                                          args=pb.args)
+                dbg((tls,), name, -1)
+                assert (alt.nfev, alt.pcg_iterations) == (res.nfev, res.pcg_iterations), name
+                assert abs(alt.cost - res.cost) <= 1e-12 * res.cost, name
+                assert np.abs(alt.x - res.x).max() <= 1e-6 * np.abs(res.x).max(), name
 
 
 def test_cfg3_full_loop_vs_oracle(orc):
