@@ -106,7 +106,7 @@ struct PinnedBuf {
 // part 0 on the calling thread, and returns when all are done.
 class HostPool {
 public:
-    static constexpr int kMax = 8;
+    static constexpr int kMax = 16;
     ~HostPool() {
         { std::lock_guard<std::mutex> lk(m_); stop_ = true; ++gen_; }
         cv_.notify_all();
