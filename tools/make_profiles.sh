@@ -1,6 +1,9 @@
 #!/bin/bash
-# Regenerates the rocprofv3 evidence under profiles/ on the GPU box:  bash tools/make_profiles.sh r02
-# (run through gpurun; outputs go to gpurun_out/<tag>_*, summaries are copied to profiles/ by hand afterwards)
+# Regenerates the rocprofv3 evidence under profiles/ on the GPU box:  bash tools/make_profiles.sh r02   (through gpurun)
+# Writes gpurun_out/<tag>_*: the default bench line, the same command under --kernel-trace --stats, the two PMC passes
+# (FETCH_SIZE, WRITE_SIZE -> <tag>_traffic.json), cfg2 under the tracer, the cfg3 / cfg5 bench lines, the eighth-size
+# shard under the tracer, back-to-back kernel timings and solve loops.  Raw CSV directories are deleted at the end;
+# the summaries are copied to profiles/ by hand afterwards.
 set -o pipefail
 TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT
