@@ -249,3 +249,67 @@ def test_bal_reader_round_trip_and_model_mapping(tmp_path):
         sfmba.read_bal(tmp_path / "bad.txt")
     with pytest.raises(ValueError):
         sfmba.write_bal(tmp_path / "k.txt", x0, nC, nP, ci, pi, uv, sfmba.K_SCEAUX)      # principal point: not BAL
+
+
+def test_lazy_result_behaves_like_scipys_without_a_gpu():
+    """The host logic of `result.fun` / `result.grad` staying on the device (sfmba.api.LazyResult, Backend._flush_pending),
+    against a stand-in for the back end: downloaded on first access through any dict path, exactly once; downloaded
+    before the handle's next operation when the result is still alive; never when it was dropped."""
+    import gc
+    import pickle
+    import weakref
+    from sfmba import api
+
+    class FakeBackend:
+        def __init__(self):
+            self.fetches = 0
+            self._pending = None
+            self.generation = 0
+
+        def _register_pending(self, obj):
+            self._pending = weakref.ref(obj)
+
+        def _flush_pending(self):                       # what Backend does before every operation on the handle
+            ref, self._pending = self._pending, None
+            if ref is not None and ref() is not None:
+                ref()._materialize()
+
+        def fetch_fun_grad(self, want_fun=True, want_grad=True):
+            self.fetches += 1
+            return np.full(4, float(self.generation)), np.full(3, -float(self.generation))
+
+        def next_operation(self):
+            self._flush_pending()
+            self.generation += 1
+
+    class Res:
+        status, cost, optimality, nfev, njev, iterations, pcg_iterations = 2, 1.5, 1e-9, 6, 5, 5, 18
+        rmse = rmse0 = cost0 = seconds_total = seconds_device = resjac_avg_us = 0.0
+        resjac_launches = 0
+
+    be = FakeBackend()
+    x = np.arange(3.0)
+    r = api._make_result(x, Res(), be, verbose=0)
+    assert be.fetches == 0 and r.status == 2 and r.success and r.x is x and set(("fun", "grad")) <= set(r.keys())
+    assert np.array_equal(r.fun, np.zeros(4)) and be.fetches == 1          # first access downloads ...
+    assert np.array_equal(r["grad"], -np.zeros(3)) and r.get("fun") is r.fun and be.fetches == 1       # ... once
+    be.next_operation()
+    assert be.fetches == 1
+    kept = api._make_result(x, Res(), be, verbose=0)                         # alive across the next operation:
+    be.next_operation()                                                      # downloaded right before it
+    assert be.fetches == 2 and np.array_equal(kept.fun, np.full(4, 1.0))     # (generation 1 = its own solve)
+    dropped = api._make_result(x, Res(), be, verbose=0)
+    del dropped
+    gc.collect()
+    be.next_operation()
+    assert be.fetches == 2                                                   # dropped unread: no download
+    for access in (lambda o: dict(o.items())["fun"], lambda o: list(o.values()), lambda o: repr(o), lambda o: o.copy()["fun"],
+                   lambda o: pickle.loads(pickle.dumps(o)).fun, lambda o: o == {}):
+        o = api._make_result(x, Res(), be, verbose=0)
+        n = be.fetches
+        access(o)
+        assert be.fetches == n + 1 and isinstance(o.fun, np.ndarray)
+        assert be._pending is None                                           # nothing left to flush
+    o = api._make_result(x, Res(), be, verbose=0)
+    with pytest.raises(AttributeError):
+        o.no_such_field
