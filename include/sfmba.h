@@ -115,7 +115,10 @@ int  sfmba_set_precision(sfmba_handle* h, int32_t storage_bits);
  * bundle_adjustment.py:40).  Any observation order is accepted; point-major (what
  * Graph.pt3ds_pt2ds produces, graph.py:186-191) is the fast path.
  * A new problem returns the handle to single-process operation: a registered exchange callback, RCCL
- * communicator or direct link is dropped and has to be set up again after this call. */
+ * communicator or direct link is dropped and has to be set up again after this call.  The drop is not silent: when
+ * a transport was active, every compute call on the handle fails with -1 until one is set up again
+ * (sfmba_set_exchange / sfmba_comm_init / sfmba_p2p_attach) or single-rank use of the shard is acknowledged
+ * (sfmba_set_exchange(h, NULL, 0, NULL, NULL, 0), sfmba_comm_destroy, sfmba_p2p_detach). */
 int  sfmba_set_problem(sfmba_handle* h, int64_t n_cameras, int64_t n_points, int64_t n_obs,
                        const int64_t* camera_indices, const int64_t* point_indices,
                        const double* points_2d, const double* K);
@@ -168,6 +171,10 @@ int64_t sfmba_p2p_calls(const sfmba_handle* h);      /* collectives served by th
 /* Running totals since sfmba_create: kernel launches enqueued by the library and collectives performed (any
  * transport).  Differences around a solve give launches / collectives per outer iteration (bench.py). */
 int  sfmba_get_counters(const sfmba_handle* h, int64_t* kernel_launches, int64_t* collectives);
+/* PCG iterations of every outer iteration of the last completed sfmba_solve on this handle (the record the next
+ * solve's speculative launches are sized from); returns the number of outer iterations, writes min(that, cap)
+ * entries.  What the full-size parity tests compare with the recorded oracle runs (tests/golden/oracle_cfg*.json). */
+int32_t sfmba_get_pcg_history(const sfmba_handle* h, int32_t* out, int32_t cap);
 
 /* ---- compute_residuals (bundle_adjustment.py:35-42) ----------------------------------------- */
 /* x: (6C+3P) float64 -> r_out: (2N) float64, interleaved x,y in the caller's observation order. */

@@ -302,6 +302,8 @@ struct sfmba_handle {
                                           // call (sfm.py:59-71), and the counts repeat; with a record the speculative
                                           // batch is that count (+1 launch for the fused update), without the spare
     bool solved = false;
+    bool transport_dropped = false;          // sfmba_set_problem tore down an active transport: the next compute call
+                                             // fails until one is set up again (or single-rank use is acknowledged)
     std::vector<const void*> lds_ready;      // kernels already opted in to 160 KiB dynamic LDS
     int last_pcg_iters = 0;
 
@@ -941,6 +943,10 @@ int download_residuals(sfmba_handle* h, double* r_out) {
 
 int check_ready(sfmba_handle* h, const void* x) {
     if (!h->have_problem) return fail(h, -1, "sfmba_set_problem has not been called");
+    if (h->transport_dropped)
+        return fail(h, -1, "sfmba_set_problem removed this handle's multi-rank transport (direct link / RCCL communicator / "
+                           "callback): set it up again for the new problem, or call sfmba_set_exchange(h, NULL, 0, NULL, NULL, 0) "
+                           "to solve the shard on its own");
     if (!x) return fail(h, -1, "x is NULL");
     return 0;
 }
@@ -1164,6 +1170,7 @@ int sfmba_set_exchange(sfmba_handle* h, void* arena, int64_t arena_doubles, sfmb
                        void* ctx, int64_t n_obs_total) {
     CHK(enter(h));
     if (!h->have_problem) return fail(h, -1, "call sfmba_set_problem before sfmba_set_exchange");
+    h->transport_dropped = false;
     if (!fn) {
         h->ar_fn = nullptr; h->ar_ctx = nullptr;
         h->arena = h->arena_own.as<double>();
@@ -1205,11 +1212,13 @@ int sfmba_comm_init(sfmba_handle* h, const void* id128, int32_t rank, int32_t wo
     h->ar_fn = nullptr; h->ar_ctx = nullptr;
     h->arena = h->arena_own.as<double>();
     h->N_total = n_obs_total;
+    h->transport_dropped = false;
     return 0;
 }
 
 int sfmba_comm_destroy(sfmba_handle* h) {
     CHK(enter(h));
+    h->transport_dropped = false;
     if (h->comm) {
         if (h->stream) HIPCHK(h, hipStreamSynchronize(h->stream));
         if (RcclApi* api = rccl_api()) (void)api->CommDestroy(h->comm);
@@ -1316,11 +1325,13 @@ int sfmba_p2p_attach(sfmba_handle* h, const void* handles, int32_t rank, int32_t
         return fail(h, -5, "direct all-reduce self-test failed (%s)", words[1] ? "timeout waiting for a peer" : "wrong sum");
     }
     p.ready = true;
+    h->transport_dropped = false;
     return 0;
 }
 
 int sfmba_p2p_detach(sfmba_handle* h) {
     CHK(enter(h));
+    h->transport_dropped = false;
     p2p_release(h);
     return 0;
 }
@@ -1332,6 +1343,13 @@ int sfmba_problem_reuse(const sfmba_handle* h, int64_t* obs_reused, int64_t* obs
     if (obs_reused) *obs_reused = h->obs_reused;
     if (obs_uploaded) *obs_uploaded = h->obs_uploaded;
     return 0;
+}
+
+int32_t sfmba_get_pcg_history(const sfmba_handle* h, int32_t* out, int32_t cap) {
+    if (!h) return -1;
+    const int32_t n = (int32_t)h->pcg_hist.size();
+    for (int32_t k = 0; k < n && k < cap && out; ++k) out[k] = h->pcg_hist[(size_t)k];
+    return n;
 }
 
 int sfmba_get_counters(const sfmba_handle* h, int64_t* kernel_launches, int64_t* collectives) {
@@ -1372,9 +1390,13 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     // communicator, callback) is torn down and has to be set up again after this call (include/sfmba.h).  The
     // staging buffer of the direct link stays allocated until sfmba_p2p_detach / _export / _destroy, because
     // peers may still have it mapped.
+    // The drop is not silent: the next compute call on this handle fails (-1) until a transport is attached again
+    // or single-rank operation is acknowledged (check_ready).
+    const bool had_transport = multi_rank(h);
+    HIPCHK(h, hipStreamSynchronize(h->stream));                  // collectives in flight; a previous upload may still read the staging
     if (h->p2p.ready) p2p_close_peers(h);
     if (h->comm) { if (RcclApi* api = rccl_api()) (void)api->CommDestroy(h->comm); h->comm = nullptr; }
-    HIPCHK(h, hipStreamSynchronize(h->stream));                  // a previous upload may still read the staging
+    if (had_transport) h->transport_dropped = true;
 
     // ---- incremental re-use ---------------------------------------------------------
     // The reference calls BA once per fused edge on a growing reconstruction (/root/reference/sfm_lite/sfm.py:59-71):

@@ -304,8 +304,38 @@ class LazyResult(OptimizeResult):
             self._materialize()
         return self
 
+    # keys() and __iter__ as Python-level delegations: CPython's dict(res), {**res}, d.update(res) and res | d then
+    # take the generic keys() + __getitem__ route instead of copying the underlying table (which holds None for the
+    # lazy fields) behind this class's back
+    def keys(self):
+        return dict.keys(self)
+
+    def __iter__(self):
+        return dict.__iter__(self)
+
     def items(self):
         return dict.items(self._all())
+
+    def pop(self, key, *default):
+        self._touch(key)
+        return dict.pop(self, key, *default)
+
+    def popitem(self):
+        return dict.popitem(self._all())
+
+    def setdefault(self, key, default=None):
+        self._touch(key)
+        return dict.setdefault(self, key, default)
+
+    def __or__(self, other):
+        return OptimizeResult(dict.__or__(dict(self._all()), other))
+
+    def __ror__(self, other):
+        return OptimizeResult(dict.__or__(dict(other), dict(self._all())))
+
+    def __ior__(self, other):
+        dict.update(self._all(), other)
+        return self
 
     def values(self):
         return dict.values(self._all())

@@ -203,6 +203,12 @@ class Backend:
         self._lib.sfmba_get_counters(self._h, C.byref(a), C.byref(b))
         return int(a.value), int(b.value)
 
+    def pcg_history(self):
+        """PCG iterations of every outer iteration of the last solve on this handle."""
+        buf = (C.c_int32 * 4096)()
+        n = int(self._lib.sfmba_get_pcg_history(self._h, buf, 4096))
+        return [int(buf[k]) for k in range(min(n, 4096))]
+
     def p2p_calls(self) -> int:
         return int(self._lib.sfmba_p2p_calls(self._h))
 

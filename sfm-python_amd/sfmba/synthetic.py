@@ -175,3 +175,43 @@ def make_ring_problem(n_cameras: int, n_points: int, n_obs: int, seed: int = 0, 
     x_true = np.concatenate([np.hstack([cam_w, cam_T]).ravel(), pts.ravel()])
     x0 = x_true + rng.normal(0.0, x0_noise, x_true.shape)
     return BAProblem(n_cameras, n_points, cam_idx, pt_idx, uv, K, x0, x_true)
+
+
+def growing_reconstruction(pb: BAProblem, order=None, first: int = 2):
+    """The sequence of bundle-adjustment inputs an incremental reconstruction of ``pb`` produces when BA runs
+    after every newly registered camera, the way ``SFM.construct`` grows its graph
+    (``/root/reference/sfm_lite/sfm.py:59-71``: initial two-view registration, then one camera per fused edge).
+
+    Yields one ``dict`` per stage with
+
+    * ``registered``: list of C flags (node k registered?), ``new_camera``: node ids registered at this stage;
+    * ``cloud``: original point ids in creation order (a point enters the cloud at the first stage where two
+      registered cameras see it -- triangulation needs two views -- and keeps its cloud index afterwards,
+      ``graph.py:101-119``); ``n_new_points``: how many were appended at this stage;
+    * ``observations``: ``(cloud_index, node_id, (x, y))`` tuples in ``Graph.pt3ds_pt2ds`` order
+      (``graph.py:186-191``): point-major, observations of unregistered nodes skipped.
+
+    Structure only: poses and coordinates are the caller's state (they change with every BA result).
+    """
+    C = pb.n_cameras
+    order = list(range(C)) if order is None else list(order)
+    assert sorted(order) == list(range(C)) and 2 <= first <= C
+    ci, pi, uv = pb.camera_indices, pb.point_indices, pb.points_2d
+    in_cloud = np.zeros(pb.n_points, dtype=bool)
+    cloud: list = []
+    registered = np.zeros(C, dtype=bool)
+    for k in range(first, C + 1):
+        new_cams = [c for c in order[:k] if not registered[c]]
+        registered[order[:k]] = True
+        seen = registered[ci]
+        views = np.bincount(pi[seen], minlength=pb.n_points)
+        fresh = np.flatnonzero((views >= 2) & ~in_cloud)
+        in_cloud[fresh] = True
+        cloud.extend(int(p) for p in fresh)
+        cloud_index = -np.ones(pb.n_points, dtype=np.int64)
+        cloud_index[np.asarray(cloud, dtype=np.int64)] = np.arange(len(cloud))
+        keep = np.flatnonzero(seen & in_cloud[pi])
+        keep = keep[np.argsort(cloud_index[pi[keep]], kind="stable")]
+        obs = [(int(cloud_index[pi[i]]), int(ci[i]), (int(uv[i, 0]), int(uv[i, 1]))) for i in keep]
+        yield dict(registered=[bool(f) for f in registered], new_camera=new_cams, cloud=list(cloud),
+                   n_new_points=len(fresh), observations=obs)

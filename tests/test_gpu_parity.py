@@ -658,6 +658,19 @@ def test_exchange_path_world1_nccl(dbg):
         x2, res2, _, _ = be2.solve(pb.x0, opt)
         assert res2.status == ref.status and int(res2.nfev) == ref.nfev
         assert res2.cost == ref.cost and np.array_equal(x2, ref.x)
+        # a new problem tears the transport down (include/sfmba.h) -- and says so: the next compute call fails until a
+        # transport is attached again or single-rank use is acknowledged; it does not quietly solve the shard alone
+        be2.set_problem(*pb.args)
+        with pytest.raises(ValueError, match="transport"):
+            be2.solve(pb.x0, opt)
+        with pytest.raises(ValueError, match="transport"):
+            be2.residuals(pb.x0)
+        nc = sdist.NativeComm(be2, n_obs_local=pb.n_obs)            # set up again: works
+        x3 = be2.solve(pb.x0, opt)[0]
+        assert np.array_equal(x3, ref.x)
+        be2.set_problem(*pb.args)
+        be2.set_exchange(0, 0, None, 0)                              # acknowledged: single-rank
+        assert np.array_equal(be2.solve(pb.x0, opt)[0], ref.x)
         be2.comm_destroy()
         be2.close()
     finally:

@@ -251,6 +251,17 @@ def test_bal_reader_round_trip_and_model_mapping(tmp_path):
         sfmba.write_bal(tmp_path / "k.txt", x0, nC, nP, ci, pi, uv, sfmba.K_SCEAUX)      # principal point: not BAL
 
 
+def _arr(v):
+    assert isinstance(v, np.ndarray), type(v)
+    return v
+
+
+def _upd(o):
+    d = {}
+    d.update(o)
+    return d
+
+
 def test_lazy_result_behaves_like_scipys_without_a_gpu():
     """The host logic of `result.fun` / `result.grad` staying on the device (sfmba.api.LazyResult, Backend._flush_pending),
     against a stand-in for the back end: downloaded on first access through any dict path, exactly once; downloaded
@@ -304,11 +315,15 @@ def test_lazy_result_behaves_like_scipys_without_a_gpu():
     be.next_operation()
     assert be.fetches == 2                                                   # dropped unread: no download
     for access in (lambda o: dict(o.items())["fun"], lambda o: list(o.values()), lambda o: repr(o), lambda o: o.copy()["fun"],
-                   lambda o: pickle.loads(pickle.dumps(o)).fun, lambda o: o == {}):
+                   lambda o: pickle.loads(pickle.dumps(o)).fun, lambda o: o == {},
+                   # CPython's dict fast paths (PyDict_Merge and friends) must not hand out the placeholder None
+                   lambda o: _arr(dict(o)["fun"]), lambda o: _arr({**o}["grad"]), lambda o: _arr(_upd(o)["fun"]),
+                   lambda o: _arr((o | {})["fun"]), lambda o: _arr(({} | o)["grad"]), lambda o: _arr(o.pop("fun")),
+                   lambda o: _arr(o.setdefault("fun", 7)), lambda o: _arr(dict(o.popitem() for _ in range(len(o)))["fun"])):
         o = api._make_result(x, Res(), be, verbose=0)
         n = be.fetches
         access(o)
-        assert be.fetches == n + 1 and isinstance(o.fun, np.ndarray)
+        assert be.fetches == n + 1 and (isinstance(o.get("fun", np.zeros(1)), np.ndarray))
         assert be._pending is None                                           # nothing left to flush
     o = api._make_result(x, Res(), be, verbose=0)
     with pytest.raises(AttributeError):

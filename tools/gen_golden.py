@@ -9,6 +9,9 @@ of /root/reference/sfm_lite/sfm.py:266-268).  No reference source is written any
 
     python tools/gen_golden.py            # fast fixtures (seconds)
     python tools/gen_golden.py --cfg2     # also the ~7 min scipy run on the SceauxCastle-scale synthetic
+    python tools/gen_golden.py --full cfg4   # oracle.trf_schur with the shipped settings at BASELINE's full size
+    python tools/gen_golden.py --full cfg5   #   (cfg4: ~1 min, cfg5: ~15 min and ~25 GB; build container only)
+    python tools/gen_golden.py --growing  # scipy + the reference residual on a 2 -> 11 camera growing reconstruction
 """
 from __future__ import annotations
 
@@ -227,10 +230,107 @@ def lsq_cfg2(ba):
     print(f"  cfg2: {res.njev} iterations in {t_lsq:.1f}s, rmse {summary['rmse']:.9f}")
 
 
+def oracle_full(name):
+    """Recorded run of the ORACLE (not the reference: scipy's own path would need ~20 min per iteration at cfg4,
+    SURVEY.md section 6) with the settings the HIP path ships -- PCG on the implicit Schur complement, Schur-diagonal
+    block preconditioner, adaptive forcing term 1e-2 ... 1e-1 -- on a BASELINE.json configuration at full size.
+    What the GPU tests compare at sizes the oracle cannot be run at inside the suite: status, nfev, njev, cost,
+    RMSE and the PCG iterations of every outer iteration."""
+    sys.path.insert(0, ROOT)
+    from oracle import ba_oracle as orc
+    from sfmba.synthetic import CONFIGS, make_config
+    pb = make_config(name)
+    t = time.time()
+    o = orc.trf_schur(pb.x0, *pb.args, ftol=1e-10, linear="pcg", pcg_tol=1e-2, pcg_tol_max=0.1, precond="schur",
+                      verbose=1)
+    dt = time.time() - t
+    rec = dict(config=dict(name=name, n_cameras=CONFIGS[name][0], n_points=CONFIGS[name][1], n_obs=CONFIGS[name][2],
+                           seed=0, ftol=1e-10),
+               oracle_settings=dict(linear="pcg", pcg_tol=1e-2, pcg_tol_max=0.1, precond="schur", reg_min=1e-6),
+               numpy_version=np.__version__, seconds=dt,
+               status=int(o.status), nfev=int(o.nfev), njev=int(o.njev), cost=float(o.cost),
+               rmse=float(np.sqrt(np.mean(o.fun ** 2))), optimality=float(o.optimality),
+               cost0=float(o.history[0]["cost"]),
+               pcg_iterations=[int(h["pcg_iters"]) for h in o.history[1:]],
+               cost_per_iteration=[float(h["cost"]) for h in o.history],
+               x_checksum=dict(sum=float(np.sum(o.x)), abs_sum=float(np.sum(np.abs(o.x))),
+                               cams_sum=float(np.sum(o.x[:6 * pb.n_cameras]))))
+    with open(os.path.join(OUT, f"oracle_{name}.json"), "w") as f:
+        json.dump(rec, f, indent=1)
+    print(f"  oracle {name}: status {o.status} nfev {o.nfev} cost {o.cost!r} pcg {rec['pcg_iterations']} in {dt:.0f}s")
+
+
+def lsq_growing(ba):
+    """scipy.optimize.least_squares with the kwargs of sfm.py:266-268 driving the REFERENCE's compute_residuals on
+    every stage of a growing reconstruction cut from the SceauxCastle-scale synthetic (sfm.py:59-71: BA after every
+    registration, each call warm-started from the previous result).  Pack / unpack as sfm.py:248-262, 271-281 with
+    scipy's Rotation.  Stage inputs are derived from ``sfmba.synthetic.growing_reconstruction`` (structure) and
+    scipy's own previous result (state), so a test can replay the chain with its own solver."""
+    from sfmba.synthetic import growing_reconstruction
+    pb = make_problem(11, 3000, 10000, seed=0)
+    order = [0, 5, 2, 7, 1, 6, 3, 4, 10, 8, 9]
+    C = pb.n_cameras
+    cams0 = pb.x0[:6 * C].reshape(C, 6)
+    pts0 = pb.x0[6 * C:].reshape(-1, 3)
+    H = [np.eye(4) for _ in range(C)]
+    X3d = np.zeros((0, 3))
+    stages = []
+    arrays = {"order": np.array(order)}
+    for k, st in enumerate(growing_reconstruction(pb, order)):
+        for c in st["new_camera"]:                                   # "PnP": the noisy initial pose of the generator
+            H[c][:3, :3] = Rot.from_rotvec(cams0[c, :3]).as_matrix()
+            H[c][:3, 3] = cams0[c, 3:]
+        new = st["cloud"][len(X3d):]
+        X3d = np.vstack([X3d, pts0[new]])                            # "triangulation": the noisy initial points
+        data = st["observations"]
+        pt_indices, cam_indices, pt2ds = map(np.array, zip(*[(p, c, uv) for p, c, uv in data]))
+        reg = [c for c in range(C) if st["registered"][c]]
+        camera_map = {c: i for i, c in enumerate(reg)}
+        params = [(Rot.from_matrix(H[c][:3, :3]).as_rotvec(), H[c][:3, 3].flatten()) for c in reg]
+        camera_indices = np.array([camera_map[c] for c in cam_indices])
+        x0 = np.hstack([np.hstack([e, t]).ravel() for e, t in params] + [X3d.ravel()])
+        n_cam, n_points, n_obs = len(reg), len(X3d), len(pt_indices)
+        S = ba.create_sparsity_matrix(n_cam, n_points, n_obs, camera_indices, pt_indices)
+        t = time.time()
+        res = least_squares(ba.compute_residuals, x0, jac_sparsity=S, verbose=0, x_scale="jac", ftol=1e-10,
+                            method="trf", args=(n_cam, n_points, camera_indices, pt_indices, pt2ds, pb.K))
+        dt = time.time() - t
+        r0 = ba.compute_residuals(x0, n_cam, n_points, camera_indices, pt_indices, pt2ds, pb.K)
+        stages.append(dict(stage=k, n_cameras=n_cam, n_points=n_points, n_obs=n_obs, status=int(res.status),
+                           nfev=int(res.nfev), njev=int(res.njev), cost=float(res.cost),
+                           rmse=float(np.sqrt(np.mean(res.fun ** 2))), rmse0=float(np.sqrt(np.mean(r0 ** 2))),
+                           optimality=float(res.optimality), seconds=dt))
+        arrays[f"s{k:02d}_x0"] = x0
+        arrays[f"s{k:02d}_x"] = res.x
+        print(f"  growing stage {k}: {n_cam}/{n_points}/{n_obs} status {res.status} njev {res.njev} "
+              f"rmse {stages[-1]['rmse0']:.6f} -> {stages[-1]['rmse']:.9f} in {dt:.0f}s", flush=True)
+        cp = res.x[:n_cam * 6].reshape((n_cam, 6))
+        for c, n in camera_map.items():
+            H[c] = np.eye(4)
+            H[c][:3, :3] = Rot.from_rotvec(cp[n, :3]).as_matrix()
+            H[c][:3, 3] = cp[n, 3:]
+        X3d = res.x[n_cam * 6:].reshape((n_points, 3))
+    rec = dict(base=dict(n_cameras=11, n_points=3000, n_obs=10000, seed=0), order=order, ftol=1e-10,
+               scipy_version=__import__("scipy").__version__, numpy_version=np.__version__,
+               host="build container, 1 thread", stages=stages)
+    with open(os.path.join(OUT, "scipy_growing_run.json"), "w") as f:
+        json.dump(rec, f, indent=1)
+    np.savez_compressed(os.path.join(OUT, "scipy_growing_x.npz"), **arrays)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cfg2", action="store_true")
+    ap.add_argument("--full", choices=("cfg3", "cfg4", "cfg5"))
+    ap.add_argument("--growing", action="store_true")
     a = ap.parse_args()
+    if a.full:                                   # oracle only: needs no reference
+        os.makedirs(OUT, exist_ok=True)
+        oracle_full(a.full)
+        return
+    if a.growing:
+        lsq_growing(load_ref())
+        return
     if not os.path.exists(REF_BA):
         sys.exit("reference not present: fixtures can only be generated in the build container")
     os.makedirs(OUT, exist_ok=True)
