@@ -143,6 +143,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg4", choices=["cfg2", "cfg3", "cfg4", "cfg5"])
+    ap.add_argument("--shard-of", type=int, default=0, metavar="G",
+                    help="N = 1 only: run rank 0's share of the workload sharded G ways (all cameras, 1/G of the points and "
+                         "observations) instead of the whole problem -- with --force-exchange the per-rank critical path "
+                         "of a G-GPU strong-scaling run, measured on one GPU (DESIGN.md section 9)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--settle", type=float, default=0.5,
                     help="seconds of untimed solves before the warm-up steps (start-up transient of the GPU queue)")
@@ -203,6 +207,8 @@ def main():
     else:
         td = None
         pb = sfmba.make_problem(C, P, N, seed=0)
+    if world == 1 and a.shard_of > 1:
+        pb = sdist.shard_problem(pb, sdist.partition_points(pb.point_indices, pb.n_points, a.shard_of)[0])
     scaling = a.scaling if world > 1 else "strong"          # at N = 1 the two coincide
     Cl, Pl, Nl = pb.n_cameras, pb.n_points, pb.n_obs          # this rank's share
 
@@ -222,9 +228,9 @@ def main():
             if a.exchange == "torch":
                 ex = sdist.Exchange(be, n_obs_local=Nl, device="cuda")
             link = None
-            if world > 1 and not a.no_direct:
+            if (world > 1 or a.force_exchange) and not a.no_direct:
                 try:
-                    link = sdist.DirectLink(be)
+                    link = sdist.DirectLink(be, allow_single=a.force_exchange)
                 except Exception as exc:                      # noqa: BLE001 -- keep the run alive on the other transport
                     print(f"[bench] direct all-reduce set-up raised ({exc}); continuing without it",
                           file=sys.stderr, flush=True)
@@ -318,7 +324,8 @@ def main():
             "launches_per_iteration": round((n_launch1 - n_launch0) / steps, 1),
             "collectives_per_iteration": round((n_coll1 - n_coll0) / steps, 1),
             "config": {"workload": (f"{a.workload}: {C} cameras / {P} points / {N} observations, seed 0 (SURVEY.md 8d "
-                                    f"generator)" + ("" if world == 1 else
+                                    f"generator)" + ((f"; RANK 0'S SHARE of a {a.shard_of}-way sharding only" if a.shard_of > 1 else "")
+                                                     if world == 1 else
                                                      f", observations sharded at point boundaries over {world} GPUs"
                                                      if strong else f" PER GPU shard, shared cameras")),
                        "solver": "TRF (scipy trf_no_bounds restated) + analytic Jacobian + Schur PCG, ftol=1e-10",

@@ -32,7 +32,25 @@ namespace sfmba {
 
 constexpr int kCamTab = 17;          // entries of a camera-table row: R (9) T (3) w (3) b c
 constexpr int kCamRow = 18;          // ... and its stride: rows are 16-byte aligned (nine 16-byte loads per row)
-constexpr int kRec = 6;              // doubles per point record X Y Z | z0 z1 z2 (see k_fill_rec)
+// Point records (see k_fill_rec) and the inverse point blocks: what the camera-major passes GATHER per observation.
+//   layout 0: rec [P][6] = X Y Z | z0 z1 z2, Vinv [P][6] in an array of its own (48-byte rows straddle 64-byte sectors)
+//   layout 1: both padded to 8 doubles: every gather is one 64-byte sector
+//   layout 2: ONE 128-byte record per point, X Y Z z0 z1 z2 . . | Vinv(6) . . : the pass that needs both
+//             (k_cam_rhs_diag) touches one cache line per observation instead of two
+// Measured: at 100k points the compact layout 0 wins (its 4.8 MB tables all but fit an XCD's 4 MiB
+// L2; the camera-major pass B takes 13.8 us against 15.3 / 18.1 us with layouts 1 / 2), at 1M points layouts 1 / 2 win
+// pass B (201 -> 168 / 174 us) and layout 2 wins the pass that gathers both (432 -> 192 us).  Shipped: layout 0 for
+// the records, plus a 128-byte record of its own for that one pass (kRhsRec below) at every size.
+#ifndef SFMBA_REC_LAYOUT
+#define SFMBA_REC_LAYOUT 0
+#endif
+constexpr int kRecLayout = SFMBA_REC_LAYOUT;
+constexpr int kRec = kRecLayout == 0 ? 6 : (kRecLayout == 1 ? 8 : 16);       // doubles per point record
+constexpr int kVinvRow = kRecLayout == 0 ? 6 : (kRecLayout == 1 ? 8 : 16);   // stride of the inverse point blocks
+constexpr int kVinvInRec = kRecLayout == 2 ? 8 : -1;                         // offset inside the record (layout 2)
+// What k_cam_rhs_diag gathers per observation, one cache line: X Y Z e0 e1 e2 . . | Vinv(6) . .  (written by k_prep,
+// which produces e and Vinv of every point anyway)
+constexpr int kRhsRec = 16;
 constexpr int kSweepThreads = 1024;  // one workgroup per CU, 16 waves sharing one LDS camera table
 constexpr int kWavesPerSweepBlock = kSweepThreads / 64;
 
@@ -437,6 +455,37 @@ __device__ __forceinline__ void st16(double* __restrict__ p, double a, double b)
     *reinterpret_cast<double2*>(p) = make_double2(a, b);
 }
 
+// Camera rows of one 64-observation tile gathered THROUGH the LDS (more cameras than the LDS holds a table of, BASELINE
+// config 5): the wave requests the 64 rows its lanes need -- 64 x 144 B = nine 1-KiB pieces -- with LDS-DMA loads whose
+// per-lane SOURCE address walks the rows piece by piece (lane l of piece k fetches 16-byte piece (64 k + l) mod 9 of the
+// row of lane (64 k + l) / 9), so that one wave instruction touches the ~8 rows of 7-8 lanes contiguously instead of 64
+// rows at a stride (nine lane-divergent 16-byte loads per observation kept the texture addresser busy for 387 us of
+// K1 at 10M observations: 0.26 of the HBM roofline).  The rows land in lane order in the wave's private 9 KiB slab and
+// every lane reads its own row back with nine ds_read_b128 (rows at a stride of 36 dwords: conflict-free).  No
+// registers are held while the pieces fly; the request for tile i + 1 is issued as soon as tile i's rows have been read
+// out of the slab.
+constexpr int kRowPieces = kCamRow / 2;                       // 16-byte pieces per row
+constexpr size_t kRowSlabDoubles = 64 * (size_t)kCamRow;      // per wave
+// (Tried and dropped, A/B on one box: the pieces issued from inline assembly with counted waits, so that the stores of a
+// tile need not be acknowledged before the next request -- while a builtin LDS-DMA load is in flight hipcc waits vmcnt(0)
+// at the next use of any loaded register -- and every load of k_resjac's loop issued from inline assembly with one
+// counted wait per tile.  Same durations to within 2 %: these sweeps are not waiting on their own stores.)
+__device__ __forceinline__ void rows_request(const double* __restrict__ table, int cam, int lane, double* slab) {
+#pragma unroll
+    for (int k = 0; k < kRowPieces; ++k) {
+        const int q = k * 64 + lane;
+        const int row = q / kRowPieces, piece = q - kRowPieces * row;
+        const int cr = __shfl(cam, row);
+        __builtin_amdgcn_global_load_lds(table + (size_t)cr * kCamRow + 2 * piece,
+                                         (__attribute__((address_space(3))) void*)(slab + 2 * 64 * k), 16, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);       // piece by piece: nine address computations in flight together spill
+    }
+}
+// the pieces have landed (every earlier vector-memory operation of the wave has completed) ...
+__device__ __forceinline__ void rows_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// ... and, before the slab is requested again, the reads of it have returned
+__device__ __forceinline__ void rows_read_done() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 // Point blocks ride along (pb.V != null): V_p = sum Jp^T Jp (6, packed upper triangle) and g_p = sum Jp^T r (3) are
 // sums over the point's run of observations, and the lanes of a wave hold 64 consecutive observations of the
 // point-major order with Jp and r in registers.  The nine products are reduced over the runs inside the wave
@@ -481,12 +530,26 @@ __global__ __launch_bounds__(kSweepThreads) void k_resjac(
         for (int k = threadIdx.x; k < n2; k += blockDim.x) dst[k] = src[k];
         __syncthreads();
     }
-    const double* __restrict__ tab = LDS_TAB ? smem : camtab;
+    // !LDS_TAB: the rows of each tile are gathered through the wave's LDS slab (rows_request)
+    double* const slab = smem + (size_t)(threadIdx.x >> 6) * kRowSlabDoubles;
+    if (!LDS_TAB && i - lane < N) rows_request(camtab, c0, lane, slab);
     double acc = 0.0;
     while (i - lane < N) {                       // wave-uniform: the segmented reduction needs all 64 lanes
         const bool on = i < N;
-        // issue the next batch's loads first
         const int in = i + stride, in2 = in + stride;
+        double tl[kCamRow];                      // the camera row by nine 16-byte reads (LDS table, or the wave's slab)
+        if (!LDS_TAB) rows_wait();
+        {
+            const double2* __restrict__ trow = reinterpret_cast<const double2*>(LDS_TAB ? smem + (size_t)c0 * kCamRow
+                                                                                         : slab + (size_t)lane * kCamRow);
+#pragma unroll
+            for (int k = 0; k < kCamRow / 2; ++k) { const double2 q = trow[k]; tl[2 * k] = q.x; tl[2 * k + 1] = q.y; }
+        }
+        if (!LDS_TAB) {
+            rows_read_done();
+            if (in - lane < N) rows_request(camtab, c1, lane, slab);     // the next tile's rows
+        }
+        // issue the next batch's loads first
         int c2 = 0, p2 = 0;
         double2 uv1 = make_double2(0.0, 0.0);
         double X1 = 0.0, Y1 = 0.0, Z1 = 0.0;
@@ -504,12 +567,6 @@ __global__ __launch_bounds__(kSweepThreads) void k_resjac(
             if (ib + 64 < N) pnext = pt_idx[ib + 64];
         }
         double jc[12], jp[6], rx, ry;
-        double tl[kCamRow];                      // the camera row by nine 16-byte loads (LDS or, past 160 KiB, L2)
-        {
-            const double2* __restrict__ trow = reinterpret_cast<const double2*>(tab + (size_t)c0 * kCamRow);
-#pragma unroll
-            for (int k = 0; k < kCamRow / 2; ++k) { const double2 q = trow[k]; tl[2 * k] = q.x; tl[2 * k + 1] = q.y; }
-        }
         observe<JAC>(tl, X0, Y0, Z0, uv0.x, uv0.y, K, rx, ry, jc, jp);
         if (on) {
             acc += rx * rx + ry * ry;
@@ -1014,7 +1071,8 @@ __device__ __forceinline__ double reg_from_scalars(const double* __restrict__ sc
 __device__ __forceinline__ void point_prep_one(const double* __restrict__ V, const double* __restrict__ gp,
                                                const double* __restrict__ sip, const double* __restrict__ dp_extra,
                                                int p, double reg, double* __restrict__ Vinv,
-                                               double* __restrict__ e) {
+                                               double* __restrict__ e, const double* __restrict__ pts = nullptr,
+                                               double* __restrict__ rhsrec = nullptr) {
     double a[6], inv[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) a[k] = V[(size_t)p * 6 + k];
@@ -1026,22 +1084,29 @@ __device__ __forceinline__ void point_prep_one(const double* __restrict__ V, con
     }
     chol3_inverse(a, inv);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) Vinv[(size_t)p * 6 + k] = inv[k];
+    for (int k = 0; k < 6; ++k) Vinv[(size_t)p * kVinvRow + k] = inv[k];
     if (e) {                              // e points at the z slot of the point records: stride kRec
         const double g0 = gp[3 * (size_t)p], g1 = gp[3 * (size_t)p + 1], g2 = gp[3 * (size_t)p + 2];
-        e[(size_t)kRec * p + 0] = inv[0] * g0 + inv[1] * g1 + inv[2] * g2;
-        e[(size_t)kRec * p + 1] = inv[1] * g0 + inv[3] * g1 + inv[4] * g2;
-        e[(size_t)kRec * p + 2] = inv[2] * g0 + inv[4] * g1 + inv[5] * g2;
+        const double e0 = inv[0] * g0 + inv[1] * g1 + inv[2] * g2;
+        const double e1 = inv[1] * g0 + inv[3] * g1 + inv[4] * g2;
+        const double e2 = inv[2] * g0 + inv[4] * g1 + inv[5] * g2;
+        e[(size_t)kRec * p + 0] = e0; e[(size_t)kRec * p + 1] = e1; e[(size_t)kRec * p + 2] = e2;
+        if (rhsrec != nullptr) {
+            double* __restrict__ rr = rhsrec + (size_t)kRhsRec * p;
+            st16(rr, pts[3 * (size_t)p], pts[3 * (size_t)p + 1]); st16(rr + 2, pts[3 * (size_t)p + 2], e0); st16(rr + 4, e1, e2);
+            st16(rr + 8, inv[0], inv[1]); st16(rr + 10, inv[2], inv[3]); st16(rr + 12, inv[4], inv[5]);
+        }
     }
 }
 
 // Per point: Vinv = (V + reg diag(si_p^2))^-1 and e_p = Vinv g_p.
 __global__ void k_point_prep(const double* __restrict__ V, const double* __restrict__ gp,
                              const double* __restrict__ sip, const double* __restrict__ dp_extra,
-                             int P, double reg, double* __restrict__ Vinv, double* __restrict__ e) {
+                             int P, double reg, double* __restrict__ Vinv, double* __restrict__ e,
+                             const double* __restrict__ pts, double* __restrict__ rhsrec) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
-    point_prep_one(V, gp, sip, dp_extra, p, reg, Vinv, e);
+    point_prep_one(V, gp, sip, dp_extra, p, reg, Vinv, e, pts, rhsrec);
 }
 
 // out = packed upper triangle of A^-1 for a symmetric positive definite 6x6 A (Cholesky, inverse of the factor)
@@ -1094,10 +1159,10 @@ __device__ __forceinline__ void spd6_inverse(const double (&A)[6][6], double (&o
 // sd (optional, plane-major [21][C]): sum_i W_i Vinv W_i^T of the camera's own observations -- with it the block
 // is the true diagonal block of the reduced camera matrix S (Schur-diagonal preconditioner) and Dc is read, not
 // written (it was formed before the pass that produced sd).
-__device__ __forceinline__ void cam_prep_one(const double* __restrict__ Ugc, const double* __restrict__ sic,
-                                             const double* __restrict__ dc_extra, int C, int c, double reg,
-                                             double* __restrict__ Dc, double* __restrict__ Minv,
-                                             const double* __restrict__ sd = nullptr) {
+__device__ __forceinline__ void cam_prep_regs(const double* __restrict__ Ugc, const double* __restrict__ sic,
+                                              const double* __restrict__ dc_extra, int C, int c, double reg,
+                                              double* __restrict__ Dc, double* __restrict__ Minv,
+                                              const double* __restrict__ sd, double (&out)[21]) {
     double A[6][6];
     {
         int n = 0;
@@ -1120,10 +1185,16 @@ __device__ __forceinline__ void cam_prep_one(const double* __restrict__ Ugc, con
         }
         A[a][a] += d;
     }
-    double out[21];
     spd6_inverse(A, out);
 #pragma unroll
     for (int n = 0; n < 21; ++n) Minv[(size_t)n * C + c] = out[n];          // packed upper triangle, plane n = [C]
+}
+__device__ __forceinline__ void cam_prep_one(const double* __restrict__ Ugc, const double* __restrict__ sic,
+                                             const double* __restrict__ dc_extra, int C, int c, double reg,
+                                             double* __restrict__ Dc, double* __restrict__ Minv,
+                                             const double* __restrict__ sd = nullptr) {
+    double out[21];
+    cam_prep_regs(Ugc, sic, dc_extra, C, c, reg, Dc, Minv, sd, out);
 }
 
 __global__ void k_cam_prep(const double* __restrict__ Ugc, const double* __restrict__ sic,
@@ -1153,7 +1224,8 @@ __global__ __launch_bounds__(64) void k_prep(double* __restrict__ sc, double Del
                                              int C, int P, int bc, double* __restrict__ Dc,
                                              double* __restrict__ Minv,
                                              double* __restrict__ Vinv, double* __restrict__ e,
-                                             const double* __restrict__ jd_part, int jd_n, double eta_min, double eta_max) {
+                                             const double* __restrict__ jd_part, int jd_n, double eta_min, double eta_max,
+                                             const double* __restrict__ pts, double* __restrict__ rhsrec) {
     // G11 = |J D^2 g|^2: either already in slot 1 (k_finish, then all-reduced over ranks) or summed here from
     // k_jdot's per-workgroup partials -- every workgroup (one wave) repeats the same 256-term sum in
     // k_finish's order, which is cheaper than a launch in between
@@ -1188,7 +1260,7 @@ __global__ __launch_bounds__(64) void k_prep(double* __restrict__ sc, double Del
     }
     const int p = (blockIdx.x - bc) * blockDim.x + threadIdx.x;
     if (p >= P) return;
-    point_prep_one(V, gp, si + 6 * (size_t)C, nullptr, p, reg, Vinv, e);
+    point_prep_one(V, gp, si + 6 * (size_t)C, nullptr, p, reg, Vinv, e, pts, rhsrec);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1234,8 +1306,27 @@ struct PcgFused {
     // with alpha from the summed partials and gamma_new = gamma - 2 alpha (s.u) + alpha^2 (s.m), gamma = sum r.u
     // being the TRUE value of the previous iterate (one recurrence step from an exact anchor: no drift).
     double* __restrict__ part;           // [4][C] partial dot products of the cameras (null: not the local form)
+    // STEPPED form (sharded solves): the whole update of an iteration is done ONCE, by the single workgroup that also
+    // all-reduces the product (k_pcg_step), and the solve is started by k_pcg_begin; the prologue of pass A then only
+    // fetches the new u (6 doubles per camera) for its LDS table.  Both control blocks always hold the same state.
+    int stepped;
 };
 constexpr int kPcgM = kPcgUcm;           // the local form keeps m = Minv s where the two-kernel form keeps its copy of u
+
+// STEPPED prologue of a fused pass-A launch (see PcgFused::stepped): fetch the u of the current iterate
+__device__ __forceinline__ bool pcg_stepped_fetch(const PcgFused& pf, int C, double (&uu)[6]) {
+    const PcgCtrl cs = pf.ctrl2[0];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) uu[k] = 0.0;
+    if (cs.done != 0) return false;                            // grid-uniform
+    const int cam = threadIdx.x;
+    if (cam < C) {
+        const double* __restrict__ us = pf.vecs + (size_t)((cs.iters & 1) * kPcgVecs + kPcgU) * 6 * C;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) uu[k] = us[(size_t)k * C + cam];
+    }
+    return true;
+}
 
 // The PCG update in the prologue of a fused pass-A launch (see PcgFused): returns false when the launch has
 // nothing more to do (the solve had finished or finishes here; grid-uniform).  Otherwise uu = the new u of
@@ -1432,7 +1523,7 @@ __device__ __forceinline__ bool pcg_fused_update(const PcgFused& pf, const doubl
     return done == 0;                                             // grid-uniform
 }
 
-template <bool LDS_VEC, bool FUSED>
+template <bool LDS_VEC, bool FUSED, bool STEPPED = false>
 __global__ __launch_bounds__(kSweepThreads) void k_point_sweep(
     StepTable st, ObsArrays o, const double* __restrict__ vin, const double* __restrict__ Vinv,
     double* __restrict__ zout, const double* __restrict__ acc, int C,
@@ -1452,7 +1543,8 @@ __global__ __launch_bounds__(kSweepThreads) void k_point_sweep(
     if (cur.y <= 64 && lane < cur.y) { c = o.cam_idx[i]; p = o.pt_idx[i]; }
     if (FUSED) {
         double uu[6];
-        if (!pcg_fused_update(pf, acc, C, L, uu)) return;
+        if (STEPPED) { if (!pcg_stepped_fetch(pf, C, uu)) return; }
+        else if (!pcg_fused_update(pf, acc, C, L, uu)) return;
         if ((int)threadIdx.x < C) {
 #pragma unroll
             for (int k = 0; k < 6; ++k) smem[6 * threadIdx.x + k] = uu[k];
@@ -1505,7 +1597,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_point_sweep(
             }
             y[0] = wave_sum(y[0]); y[1] = wave_sum(y[1]); y[2] = wave_sum(y[2]);
             if (lane == 0) {
-                const double* vi = Vinv + 6 * (size_t)pp;
+                const double* vi = Vinv + kVinvRow * (size_t)pp;
                 zout[(size_t)kRec * pp + 3] = vi[0] * y[0] + vi[1] * y[1] + vi[2] * y[2];
                 zout[(size_t)kRec * pp + 4] = vi[1] * y[0] + vi[3] * y[1] + vi[4] * y[2];
                 zout[(size_t)kRec * pp + 5] = vi[2] * y[0] + vi[4] * y[1] + vi[5] * y[2];
@@ -1516,7 +1608,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_point_sweep(
             if (act) {
                 load_blocks(o, i, jc, jp);
 #pragma unroll                                     // every lane of a run reads its point's block: no dependent
-                for (int k = 0; k < 6; ++k) vi[k] = Vinv[6 * (size_t)p + k];       // gather after the reduction
+                for (int k = 0; k < 6; ++k) vi[k] = Vinv[kVinvRow * (size_t)p + k];       // gather after the reduction
                 double t0, t1;
                 jcv(jc, c, t0, t1);
                 y[0] = jp[0] * t0 + jp[3] * t1; y[1] = jp[1] * t0 + jp[4] * t1;
@@ -1577,7 +1669,7 @@ __global__ __launch_bounds__(256) void k_rc_table(const double* __restrict__ cam
 
 // GTAB (more cameras than the LDS holds): the table [C][18] was written to global memory by k_rc_table and its rows are
 // gathered from L2 by nine 16-byte loads per observation; `vin` is not used.
-template <bool FUSED, bool GTAB = false>
+template <bool FUSED, bool GTAB = false, bool STEPPED = false>
 __global__ __launch_bounds__(kSweepThreads) void k_point_sweep_rc(
     StepTable st, const int* __restrict__ cam_idx, const int* __restrict__ pt_idx,
     const double* __restrict__ camtab, const double* __restrict__ pts, KMat K, const double* __restrict__ vin,
@@ -1585,6 +1677,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_point_sweep_rc(
     const PcgCtrl* __restrict__ ctrl2, int L, PcgFused pf, const double* __restrict__ rctab) {
     static_assert(!(FUSED && GTAB), "the fused PCG update needs the table in LDS");
     extern __shared__ __align__(16) double smem[];
+    if (kVinvInRec >= 0) Vinv = zout + kVinvInRec;            // record layout 2: one base address for both
     const int n6 = 6 * C;
     const int wg = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -1612,7 +1705,8 @@ __global__ __launch_bounds__(kSweepThreads) void k_point_sweep_rc(
     };
     if (FUSED) {
         double uu[6];
-        if (!pcg_fused_update(pf, acc, C, L, uu)) return;
+        if (STEPPED) { if (!pcg_stepped_fetch(pf, C, uu)) return; }
+        else if (!pcg_fused_update(pf, acc, C, L, uu)) return;
         if ((int)threadIdx.x < C) put_au(threadIdx.x, uu);
     } else {
         if (ctrl2 != nullptr) {                               // two-kernel PCG: vin = base of the vector sets
@@ -1637,10 +1731,13 @@ __global__ __launch_bounds__(kSweepThreads) void k_point_sweep_rc(
         __syncthreads();
     }
     const double* __restrict__ table = GTAB ? rctab : smem;
+    // GTAB: the rows of a step are gathered through the wave's LDS slab (rows_request, see k_resjac); a point with more
+    // than 64 observations reads its rows from global memory as before
+    double* const slab = smem + (size_t)(threadIdx.x >> 6) * kRowSlabDoubles;
+    static_assert(kRcRow == kCamRow, "rows_request moves rows of kCamRow doubles");
 
-    // y contribution of one observation: camera row `cc` (LDS, or L2 with GTAB), point X
-    auto contrib = [&](int cc, double X, double Y, double Z, double* y) {
-        const double2* __restrict__ row = reinterpret_cast<const double2*>(table + (size_t)kRcRow * cc);
+    // y contribution of one observation from its camera row (nine 16-byte pieces) and its point X
+    auto contrib = [&](const double2* __restrict__ row, double X, double Y, double Z, double* y) {
         const double2 r01 = row[0], r23 = row[1], r45 = row[2], r67 = row[3], r8t = row[4], t12 = row[5];
         const double2 a01 = row[6], a2u = row[7], u12 = row[8];
         const double R0 = r01.x, R1 = r01.y, R2 = r23.x, R3 = r23.y, R4 = r45.x, R5 = r45.y, R6 = r67.x, R7 = r67.y,
@@ -1670,25 +1767,58 @@ __global__ __launch_bounds__(kSweepThreads) void k_point_sweep_rc(
             y[0] += j0 * tk; y[1] += j1 * tk; y[2] += j2 * tk;
         }
     };
+    auto row_of = [&](int cc) { return reinterpret_cast<const double2*>(table + (size_t)kRcRow * cc); };
 
+    // the point one step ahead; its inverse block too, except with GTAB, where the registers of a second copy across
+    // the step would spill: there it is requested at the top of the step that uses it, behind the row traffic
     auto load_point = [&](bool on, int pp, double* X, double* vi) {
         if (on) {
-            const double* __restrict__ Xp = pts + 3 * (size_t)pp;
-            X[0] = Xp[0]; X[1] = Xp[1]; X[2] = Xp[2];
+            if (kVinvInRec >= 0) {               // record layout 2: coordinates and inverse block from ONE 128-byte record
+                const double2* __restrict__ rp = reinterpret_cast<const double2*>(zout + (size_t)kRec * pp);
+                const double2 xy = rp[0], zz = rp[1];
+                X[0] = xy.x; X[1] = xy.y; X[2] = zz.x;
+                if (!GTAB) {
+                    const double2 v0 = rp[4], v1 = rp[5], v2 = rp[6];
+                    vi[0] = v0.x; vi[1] = v0.y; vi[2] = v1.x; vi[3] = v1.y; vi[4] = v2.x; vi[5] = v2.y;
+                }
+            } else {
+                const double* __restrict__ Xp = pts + 3 * (size_t)pp;
+                X[0] = Xp[0]; X[1] = Xp[1]; X[2] = Xp[2];
+                if (!GTAB) {
 #pragma unroll
-            for (int k = 0; k < 6; ++k) vi[k] = Vinv[6 * (size_t)pp + k];
+                    for (int k = 0; k < 6; ++k) vi[k] = Vinv[kVinvRow * (size_t)pp + k];
+                }
+            }
         }
     };
     double X[3] = {0.0, 0.0, 0.0}, vi[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     load_point(cur.y <= 64 && lane < cur.y, p, X, vi);
+    bool requested = false;                       // (wave-uniform) the slab holds / will hold the rows of step `cur`
     while (s < s_end) {
+        double y[3] = {0.0, 0.0, 0.0};
+        if (GTAB && cur.y <= 64) {
+            // this step's rows out of the slab and the next step's request BEFORE this iteration's own loads are issued
+            if (!requested) rows_request(rctab, c, lane, slab);
+            rows_wait();
+            if (lane < cur.y) contrib(reinterpret_cast<const double2*>(slab + (size_t)lane * kRcRow), X[0], X[1], X[2], y);
+            rows_read_done();
+            requested = s + 1 < s_end && nxt.y <= 64;
+            if (requested) rows_request(rctab, cn, lane, slab);
+        } else {
+            requested = false;
+        }
         int2 n3 = make_int2(0, 0);
         if (s + 3 < s_end) n3 = st.steps[s + 3];
+        n3.x = __builtin_amdgcn_readfirstlane(n3.x);      // wave-uniform: keep the descriptor in scalar registers
+        n3.y = __builtin_amdgcn_readfirstlane(n3.y);
         int c2 = 0, p2 = 0;
         if (nn.y <= 64 && lane < nn.y) { c2 = cam_idx[nn.x + lane]; p2 = pt_idx[nn.x + lane]; }
         double Xn[3] = {0.0, 0.0, 0.0}, vin_[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         load_point(nxt.y <= 64 && lane < nxt.y, pn, Xn, vin_);
-        double y[3] = {0.0, 0.0, 0.0};
+        if (GTAB && cur.y <= 64 && lane < cur.y) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) vi[k] = Vinv[kVinvRow * (size_t)p + k];
+        }
         if (cur.y > 64) {                          // one point with more than 64 observations
             const int run_end = cur.x + cur.y;
             const int pp = pt_idx[cur.x];
@@ -1696,19 +1826,19 @@ __global__ __launch_bounds__(kSweepThreads) void k_point_sweep_rc(
             const double Xl = Xp[0], Yl = Xp[1], Zl = Xp[2];
             for (int j = cur.x + lane; j < run_end; j += 64) {
                 double w[3];
-                contrib(cam_idx[j], Xl, Yl, Zl, w);
+                contrib(row_of(cam_idx[j]), Xl, Yl, Zl, w);
                 y[0] += w[0]; y[1] += w[1]; y[2] += w[2];
             }
             y[0] = wave_sum(y[0]); y[1] = wave_sum(y[1]); y[2] = wave_sum(y[2]);
             if (lane == 0) {
-                const double* vl = Vinv + 6 * (size_t)pp;
+                const double* vl = Vinv + kVinvRow * (size_t)pp;
                 zout[(size_t)kRec * pp + 3] = vl[0] * y[0] + vl[1] * y[1] + vl[2] * y[2];
                 zout[(size_t)kRec * pp + 4] = vl[1] * y[0] + vl[3] * y[1] + vl[4] * y[2];
                 zout[(size_t)kRec * pp + 5] = vl[2] * y[0] + vl[4] * y[1] + vl[5] * y[2];
             }
         } else {
             const bool act = lane < cur.y;
-            if (act) contrib(c, X[0], X[1], X[2], y);
+            if (!GTAB && act) contrib(row_of(c), X[0], X[1], X[2], y);
             const int key = act ? p : -1 - lane;
             seg_reduce_serial<3>(y, key, lane);
             const int prev = lane_below(key, lane);
@@ -1722,8 +1852,10 @@ __global__ __launch_bounds__(kSweepThreads) void k_point_sweep_rc(
         c = cn; p = pn; cn = c2; pn = p2;
 #pragma unroll
         for (int k = 0; k < 3; ++k) X[k] = Xn[k];
+        if (!GTAB) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) vi[k] = vin_[k];
+            for (int k = 0; k < 6; ++k) vi[k] = vin_[k];
+        }
         ++s;
     }
 }
@@ -1997,7 +2129,10 @@ __global__ __launch_bounds__(kCamThreads) void k_cam_schur(CamMajor cm, const do
 // Output plane-major [27][C] (acc | sd: one contiguous vector for the all-reduce) or partial[chunk][27].
 // 192-thread workgroups: the kernel needs ~150 VGPRs (three waves per SIMD), and four 3-wave workgroups per CU keep
 // 1024 camera workgroups resident at once where three 4-wave ones would take a 1000-camera problem in two rounds.
-constexpr int kRhsThreads = 192;
+#ifndef SFMBA_RHS_THREADS
+#define SFMBA_RHS_THREADS 192
+#endif
+constexpr int kRhsThreads = SFMBA_RHS_THREADS;
 // minv (one rank, every camera a single chunk): the workgroup also inverts its camera's preconditioner block
 // (U + Dc - sd), which is complete the moment its 27 sums are -- k_cam_prep_schur's work without its launch.
 struct RhsPrecond {
@@ -2010,7 +2145,7 @@ __global__ __launch_bounds__(kRhsThreads) void k_cam_rhs_diag(CamMajor cm, const
                                                               const double* __restrict__ rec,
                                                               const double* __restrict__ Vinv, KMat K, int C,
                                                               double* __restrict__ out, double* __restrict__ partial,
-                                                              RhsPrecond mp) {
+                                                              RhsPrecond mp, const double* __restrict__ rhsrec) {
     __shared__ double red[kRhsThreads / 64][27];
     const int4 ch = cm.chunks[blockIdx.x];
     double t[kCamTab];
@@ -2031,8 +2166,9 @@ __global__ __launch_bounds__(kRhsThreads) void k_cam_rhs_diag(CamMajor cm, const
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
             const size_t pp = (size_t)(p[u] < 0 ? 0 : p[u]);
-            const double2* __restrict__ rp = reinterpret_cast<const double2*>(rec + kRec * pp);
-            const double2* __restrict__ vp = reinterpret_cast<const double2*>(Vinv + 6 * pp);
+            // one 128-byte record per observation (kRhsRec) when k_prep has written them, else the two gathers
+            const double2* __restrict__ rp = reinterpret_cast<const double2*>(rhsrec != nullptr ? rhsrec + kRhsRec * pp : rec + kRec * pp);
+            const double2* __restrict__ vp = rhsrec != nullptr ? rp + 4 : reinterpret_cast<const double2*>(Vinv + kVinvRow * pp);
             const double2 r0 = rp[0], r1 = rp[1], r2 = rp[2], v0 = vp[0], v1 = vp[1], v2 = vp[2];
             X[u][0] = r0.x; X[u][1] = r0.y; X[u][2] = r1.x;
             e[u][0] = r1.y; e[u][1] = r2.x; e[u][2] = r2.y;
@@ -2051,21 +2187,33 @@ __global__ __launch_bounds__(kRhsThreads) void k_cam_rhs_diag(CamMajor cm, const
 #pragma unroll
                 for (int q = 0; q < 3; ++q) { jc[3 + q] = -jp[q]; jc[9 + q] = -jp[3 + q]; }
             }
-            double W[6][3], Y[6][3];
+            // W = Jc^T Jp has rank two (the two residual rows), so neither W nor W Vinv is formed:
+            //     -W e          = -Jc^T (Jp e)
+            //     W Vinv W^T    = Jc^T G Jc,   G = Jp Vinv Jp^T  (2 x 2, symmetric)
+            // 111 multiply-adds per observation instead of 171, and no 6 x 3 temporaries in registers
+            const double s0 = jp[0] * e[u][0] + jp[1] * e[u][1] + jp[2] * e[u][2];
+            const double s1 = jp[3] * e[u][0] + jp[4] * e[u][1] + jp[5] * e[u][2];
+            const double h00 = vi[u][0] * jp[0] + vi[u][1] * jp[1] + vi[u][2] * jp[2];      // Vinv jp_0 (Vinv packed upper)
+            const double h01 = vi[u][1] * jp[0] + vi[u][3] * jp[1] + vi[u][4] * jp[2];
+            const double h02 = vi[u][2] * jp[0] + vi[u][4] * jp[1] + vi[u][5] * jp[2];
+            const double h10 = vi[u][0] * jp[3] + vi[u][1] * jp[4] + vi[u][2] * jp[5];      // Vinv jp_1
+            const double h11 = vi[u][1] * jp[3] + vi[u][3] * jp[4] + vi[u][4] * jp[5];
+            const double h12 = vi[u][2] * jp[3] + vi[u][4] * jp[4] + vi[u][5] * jp[5];
+            const double g00 = jp[0] * h00 + jp[1] * h01 + jp[2] * h02;
+            const double g01 = jp[0] * h10 + jp[1] * h11 + jp[2] * h12;
+            const double g11 = jp[3] * h10 + jp[4] * h11 + jp[5] * h12;
+            double m0[6], m1[6];
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
-#pragma unroll
-                for (int j = 0; j < 3; ++j) W[i][j] = jc[i] * jp[j] + jc[6 + i] * jp[3 + j];
-                Y[i][0] = W[i][0] * vi[u][0] + W[i][1] * vi[u][1] + W[i][2] * vi[u][2];      // W Vinv (Vinv packed upper)
-                Y[i][1] = W[i][0] * vi[u][1] + W[i][1] * vi[u][3] + W[i][2] * vi[u][4];
-                Y[i][2] = W[i][0] * vi[u][2] + W[i][1] * vi[u][4] + W[i][2] * vi[u][5];
-                a[i] -= W[i][0] * e[u][0] + W[i][1] * e[u][1] + W[i][2] * e[u][2];
+                a[i] -= jc[i] * s0 + jc[6 + i] * s1;
+                m0[i] = g00 * jc[i] + g01 * jc[6 + i];
+                m1[i] = g01 * jc[i] + g11 * jc[6 + i];
             }
             int n = 6;
 #pragma unroll
             for (int i = 0; i < 6; ++i)
 #pragma unroll
-                for (int j = i; j < 6; ++j) a[n++] += Y[i][0] * W[j][0] + Y[i][1] * W[j][1] + Y[i][2] * W[j][2];
+                for (int j = i; j < 6; ++j) a[n++] += jc[i] * m0[j] + jc[6 + i] * m1[j];
         }
     }
     const double s = cam_block_total<27, kRhsThreads / 64>(a, red);
@@ -2150,7 +2298,7 @@ __global__ __launch_bounds__(kCamThreads) void k_schur_blocks(const int* __restr
         const bool self = pm < 0;                                  // an observation paired with itself
         const int p = self ? ~pm : pm;
         const double2* __restrict__ rp = reinterpret_cast<const double2*>(rec + kRec * (size_t)p);   // X Y | Z e0 | e1 e2
-        const double* __restrict__ vi = Vinv + 6 * (size_t)p;
+        const double* __restrict__ vi = Vinv + kVinvRow * (size_t)p;
         const double2 r0 = rp[0], r1 = rp[1], r2 = rp[2];
         const double X = r0.x, Y = r0.y, Z = r1.x;
         const double v0 = vi[0], v1 = vi[1], v2 = vi[2], v3 = vi[3], v4 = vi[4], v5 = vi[5];
@@ -2422,6 +2570,7 @@ __global__ __launch_bounds__(1024) void k_pcg_init(const double* __restrict__ Ug
         c0.done = (s[0] > 0.0) ? 0 : (s[0] == 0.0 ? 1 : 3);
         c0.pad = 0;
         ctrl2[0] = c0;
+        ctrl2[1] = c0;
     }
 }
 
@@ -2576,7 +2725,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_backsub(
         }
     };
     auto solve_point = [&](int p, const double* y, double& z0, double& z1, double& z2) {
-        const double* vi = Vinv + 6 * (size_t)p;
+        const double* vi = Vinv + kVinvRow * (size_t)p;
         const double b0 = -gp[3 * (size_t)p] - y[0], b1 = -gp[3 * (size_t)p + 1] - y[1],
                      b2 = -gp[3 * (size_t)p + 2] - y[2];
         z0 = vi[0] * b0 + vi[1] * b1 + vi[2] * b2;
@@ -2715,22 +2864,10 @@ struct P2pArgs {
     const double* skip;                       // speculative trial cancelled: no collective, but still post
 };
 
-__global__ __launch_bounds__(256) void k_p2p_allreduce(double* __restrict__ vec, int count, int op, P2pArgs a) {
+// The collective itself, for the workgroups of one launch (any block size; slices by blockIdx).
+__device__ __forceinline__ void p2p_allreduce_body(double* __restrict__ vec, int count, int op, const P2pArgs& a) {
     __shared__ unsigned s_last;
-    if (a.skip != nullptr && *a.skip != 0.0) {                // identical on all ranks: sequence number untouched
-        if (a.post.host != nullptr && blockIdx.x == 0 && threadIdx.x < 64) post_mailbox(a.post);
-        return;
-    }
-    if (a.cancel != nullptr && *a.cancel != 0) return;        // grid-uniform, identical on all ranks
-    if (*a.error != 0u) {                                     // an earlier collective of this solve gave up: do not wait
-        if (a.post.host != nullptr && blockIdx.x == 0 && threadIdx.x < 64) post_mailbox(a.post);   // again, let the
-        return;                                               // host see the error word at the next hand-off
-    }
     const int tid = threadIdx.x;
-    if (a.rider.part != nullptr) {                            // (single workgroup) final sums that feed this collective
-        finish_in_block(a.rider);
-        __syncthreads();
-    }
     const unsigned long long seq = *a.seq + 1ull;             // the last workgroup to arrive publishes it
     const int par = (int)(seq & 1ull);
     const int per = (count + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -2771,9 +2908,170 @@ __global__ __launch_bounds__(256) void k_p2p_allreduce(double* __restrict__ vec,
         }
         vec[e] = s;
     }
+}
+
+__global__ __launch_bounds__(256) void k_p2p_allreduce(double* __restrict__ vec, int count, int op, P2pArgs a) {
+    if (a.skip != nullptr && *a.skip != 0.0) {                // identical on all ranks: sequence number untouched
+        if (a.post.host != nullptr && blockIdx.x == 0 && threadIdx.x < 64) post_mailbox(a.post);
+        return;
+    }
+    if (a.cancel != nullptr && *a.cancel != 0) return;        // grid-uniform, identical on all ranks
+    if (*a.error != 0u) {                                     // an earlier collective of this solve gave up: do not wait
+        if (a.post.host != nullptr && blockIdx.x == 0 && threadIdx.x < 64) post_mailbox(a.post);   // again, let the
+        return;                                               // host see the error word at the next hand-off
+    }
+    const int tid = threadIdx.x;
+    if (a.rider.part != nullptr) {                            // (single workgroup) final sums that feed this collective
+        finish_in_block(a.rider);
+        __syncthreads();
+    }
+    p2p_allreduce_body(vec, count, op, a);
     if (a.post.host != nullptr) {                             // (single workgroup) the reduced scalars go to the host
         __syncthreads();
         if (tid < 64) post_mailbox(a.post);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// STEPPED PCG (sharded solves): the product of an iteration is complete only after its all-reduce, and the reduced
+// vector is the same on every rank -- so the whole update of the iteration is done ONCE per rank, by the single
+// workgroup that performs the all-reduce, instead of redundantly in the prologue of every workgroup of pass A
+// (12 us of a 20 us launch on an eighth-size shard) or in eight workgroups that each read every vector
+// (k_pcg_update: 49 us at 5000 cameras).  Standard recurrences (those of k_pcg_update and of the oracle):
+//     w = acc + Dc u;  delta = w.u;  beta = gamma / gamma_prev;  alpha = gamma / (delta - beta gamma / alpha_prev)
+//     p = u + beta p;  s = w + beta s;  x += alpha p;  r -= alpha s;  u = Minv r;  gamma' = r.u
+// State: x r p s plane-major in vector set 0 (x in both sets: k_backsub picks one by the iteration count), u of
+// iteration i in set i & 1; BOTH control blocks always hold the same, latest state.
+// k_pcg_begin starts a solve: per camera the preconditioner block (U + Dc - sd)^-1 (what k_cam_prep_schur does), the
+// right-hand side r = -g_c - acc, u = Minv r, and gamma_0 as one partial per 64-camera workgroup (summed, in order, by
+// the first k_pcg_step: ctrl.pad = number of partials, rz = rz0 = 0 until then).
+// ---------------------------------------------------------------------------------------------
+constexpr int kPcgBeginThreads = 64;
+__global__ __launch_bounds__(kPcgBeginThreads) void k_pcg_begin(const double* __restrict__ Ugc, const double* __restrict__ acc,
+                                                                const double* __restrict__ sd, double* __restrict__ Dc,
+                                                                double* __restrict__ Minv, int C, double* __restrict__ vecs,
+                                                                const double* __restrict__ tol_dev, int max_iters,
+                                                                PcgCtrl* __restrict__ ctrl2, double* __restrict__ part0) {
+    const int cam = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n6 = 6 * (size_t)C;
+    double t = 0.0;
+    if (cam < C) {
+        double m[21], rr[6];
+        cam_prep_regs(Ugc, nullptr, nullptr, C, cam, 0.0, Dc, Minv, sd, m);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) rr[k] = -Ugc[(size_t)cam * 27 + 21 + k] - acc[(size_t)k * C + cam];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const size_t e = (size_t)k * C + cam;
+            const double z = minv_row(m, rr, k);
+            t += z * rr[k];
+            vecs[kPcgX * n6 + e] = 0.0; vecs[(size_t)kPcgVecs * n6 + kPcgX * n6 + e] = 0.0;
+            vecs[kPcgP * n6 + e] = 0.0; vecs[kPcgS * n6 + e] = 0.0;
+            vecs[kPcgR * n6 + e] = rr[k];
+            vecs[kPcgU * n6 + e] = z;
+            vecs[kPcgUcm * n6 + 6 * (size_t)cam + k] = z;
+        }
+    }
+    t = wave_sum(t);
+    if (threadIdx.x == 0) part0[blockIdx.x] = t;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        PcgCtrl c0;
+        const double tolv = *tol_dev;
+        c0.rz = 0.0; c0.rz0 = 0.0; c0.tol2 = tolv * tolv; c0.rz_prev = 1.0; c0.alpha_prev = 1.0;
+        c0.iters = 0; c0.max_iters = max_iters; c0.done = 0; c0.pad = (int)gridDim.x;
+        ctrl2[0] = c0; ctrl2[1] = c0;
+    }
+}
+
+struct PcgStepArgs {
+    const double* __restrict__ Dc;
+    const double* __restrict__ Minv;
+    double* __restrict__ vecs;
+    PcgCtrl* __restrict__ ctrl2;
+    const double* __restrict__ part0;    // gamma_0 partials of k_pcg_begin (null: ctrl.rz is valid from the start, k_pcg_init)
+    int C;
+};
+template <bool P2P>
+__global__ __launch_bounds__(1024) void k_pcg_step(double* __restrict__ acc, PcgStepArgs ps, P2pArgs a) {
+    __shared__ double slots_a[16];
+    __shared__ double slots_b[16];
+    PcgCtrl ci = ps.ctrl2[0];
+    if (ci.done != 0) return;                                 // identical on all ranks: no collective either
+    const int C = ps.C;
+    const size_t n6 = 6 * (size_t)C;
+    if (P2P) {
+        if (*a.error == 0u) p2p_allreduce_body(acc, 6 * C, 0, a);
+        __syncthreads();
+    }
+    const bool writer = threadIdx.x == 0;
+    if (ci.iters == 0 && ps.part0 != nullptr) {               // gamma_0: k_pcg_begin's partials, in order
+        double g0 = 0.0;
+        for (int b = 0; b < ci.pad; ++b) g0 += ps.part0[b];
+        ci.rz = g0; ci.rz0 = g0;
+        if (!(g0 > 0.0)) {                                    // zero right-hand side (x = 0 is the solution) / NaN
+            ci.done = g0 == 0.0 ? 1 : 3;
+            if (writer) { ps.ctrl2[0] = ci; ps.ctrl2[1] = ci; }
+            return;
+        }
+    }
+    const int set = ci.iters & 1;
+    const double* __restrict__ u_in = ps.vecs + ((size_t)set * kPcgVecs + kPcgU) * n6;
+    double* __restrict__ u_out = ps.vecs + ((size_t)(set ^ 1) * kPcgVecs + kPcgU) * n6;
+    double* __restrict__ ucm_out = ps.vecs + ((size_t)(set ^ 1) * kPcgVecs + kPcgUcm) * n6;
+    double* __restrict__ X0 = ps.vecs + kPcgX * n6;
+    double* __restrict__ X1 = ps.vecs + (size_t)kPcgVecs * n6 + kPcgX * n6;
+    double* __restrict__ R = ps.vecs + kPcgR * n6;
+    double* __restrict__ Pv = ps.vecs + kPcgP * n6;
+    double* __restrict__ Sv = ps.vecs + kPcgS * n6;
+    double d = 0.0;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const size_t e = (size_t)k * C + c;
+            const double ue = u_in[e];
+            d += (acc[e] + ps.Dc[e] * ue) * ue;
+        }
+    }
+    const double delta = block_sum_all(d, slots_a);
+    const double gamma = ci.rz;
+    const double beta = ci.iters == 0 ? 0.0 : gamma / ci.rz_prev;
+    const double den = delta - (ci.iters == 0 ? 0.0 : beta * gamma / ci.alpha_prev);
+    const double alpha = gamma / den;
+    if (!(den > 0.0) || !isfinite(alpha)) {                    // S not SPD / NaN: x stays the last good iterate
+        if (writer) { ci.done = 3; ps.ctrl2[0] = ci; ps.ctrl2[1] = ci; }
+        return;
+    }
+    double t = 0.0;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        double rr[6], m[21];
+#pragma unroll
+        for (int n = 0; n < 21; ++n) m[n] = ps.Minv[(size_t)n * C + c];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const size_t e = (size_t)k * C + c;
+            const double ue = u_in[e];
+            const double we = acc[e] + ps.Dc[e] * ue;
+            const double pk = ue + beta * Pv[e];
+            const double sk = we + beta * Sv[e];
+            const double xk = X0[e] + alpha * pk;
+            rr[k] = R[e] - alpha * sk;
+            Pv[e] = pk; Sv[e] = sk; X0[e] = xk; X1[e] = xk; R[e] = rr[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const double z = minv_row(m, rr, k);
+            t += z * rr[k];
+            u_out[(size_t)k * C + c] = z;
+            ucm_out[6 * (size_t)c + k] = z;
+        }
+    }
+    const double rz = block_sum_all(t, slots_b);
+    if (writer) {
+        PcgCtrl co = ci;
+        co.rz_prev = gamma; co.alpha_prev = alpha; co.rz = rz; co.iters = ci.iters + 1;
+        if (!(rz > ci.tol2 * ci.rz0)) co.done = 1;            // also catches NaN
+        else if (co.iters >= ci.max_iters) co.done = 2;
+        ps.ctrl2[0] = co; ps.ctrl2[1] = co;
     }
 }
 

@@ -231,6 +231,8 @@ struct sfmba_handle {
         int dense = -1;                      // 0: PCG although the dense reduced-camera path would apply
         int precond = -1;                    // 0: block-Jacobi preconditioner from U + Dc instead of the Schur diagonal
         int pcg_local = -1;                  // 0: the fused PCG keeps its whole update in pass A's prologue
+        int pcg_step = -1;                   // 1: the stepped PCG (k_pcg_begin / k_pcg_step) on a single rank too;
+                                             // 0: sharded solves keep the round-2 forms (update in every workgroup)
         int cam_chunk = 0;                   // > 0: chunk length of the camera-major kernels
         int pcg_guess_bias = 0;              // added to the number of speculatively enqueued PCG iterations
         int trace_pcg = 0, trace_stalls = 0, trace_timing = 0;   // stderr diagnostics
@@ -246,6 +248,7 @@ struct sfmba_handle {
     int n_chunks = 0;
     bool cam_multi = false;                  // some camera has more than one chunk: k_cam_combine runs
     DevBuf xa, xb, tabA, tabB, r, J, t1;     // ONE Jacobian / residual buffer set
+    DevBuf rhsrec;                           // [P][kRhsRec]: what k_cam_rhs_diag gathers (written by k_prep)
     DevBuf V, Vinv, gp, e, recA, recB;       // rec: point records X Y Z | z (k_fill_rec), one per parameter vector
     DevBuf edge;                             // pieces of the point rows cut by K1's tiles (PointBlocksOut)
     DevBuf g, si, sg, p;                     // n-vectors; p = [dc | dp]
@@ -295,6 +298,7 @@ struct sfmba_handle {
     bool pcg_fused = false;               // PCG update fused into the launch of pass A (v in LDS, C <= 1024)
     bool pcg_local = false;               // ... with the per-camera bookkeeping in pass B (one rank, single-chunk cameras)
     bool pcg_local2 = false;              // the same bookkeeping with the light update as a kernel of its own (> 1024 cameras)
+    bool pcg_step = false;                // stepped form: the update once per iteration in the collective's workgroup (sharded solves)
     DevBuf pcg_part;                      // [4][C] partial dot products of the local form
     int pcg_hint = 0;                     // largest PCG iteration count a solve on this handle has needed
     std::vector<int> pcg_hist;            // PCG iterations of outer iteration k in the previous solve on this handle: the
@@ -373,20 +377,13 @@ const unsigned* p2p_error_word(const sfmba_handle* h) { return h->p2p.ready ? h-
 
 constexpr size_t kP2pFlagBytes = sizeof(unsigned long long) * 2 * kP2pMaxRanks * kP2pFlagStride;
 
-int p2p_allreduce(sfmba_handle* h, double* ptr, int64_t count, int op, const int* cancel,
-                  unsigned long long max_mask = 0, const Piggyback* rider = nullptr, const Mailbox* post = nullptr,
-                  const double* skip = nullptr) {
+constexpr int64_t kPcgStepP2pMax = 6 * 1024;   // k_pcg_step<true> copies the vector to every rank with ONE workgroup
+
+void p2p_fill_args(sfmba_handle* h, P2pArgs& a) {
     auto& p = h->p2p;
-    P2pArgs a{};
     for (int q = 0; q < p.world; ++q) { a.data[q] = p.data[q]; a.flags[q] = p.flags[q]; }
     a.rank = p.rank; a.world = p.world; a.stride = p.stride;
     a.seq = reinterpret_cast<unsigned long long*>(p.words + 2);
-    a.cancel = cancel;
-    a.max_mask = max_mask;
-    if (rider) a.rider = *rider;
-    if (post) a.post = *post;
-    a.skip = skip;
-    if ((rider || post) && count > 512) return fail(h, -1, "rider / post need a single-workgroup collective");
     a.ticket = p.words; a.error = p.words + 1;
     // Ticks of the 100 MHz wall clock.  Steady state: 3 s.  The FIRST collective of a solve is the rendezvous of
     // ranks that entered sfmba_solve at different times (Python skew, first-use code-object loads; no barrier is
@@ -394,6 +391,20 @@ int p2p_allreduce(sfmba_handle* h, double* ptr, int64_t count, int op, const int
     a.timeout = p.first_in_solve ? 6000000000ll : 300000000ll;
     if (h->dbg.p2p_timeout_ms > 0) a.timeout = 100000ll * h->dbg.p2p_timeout_ms;       // test hook
     p.first_in_solve = false;
+}
+
+int p2p_allreduce(sfmba_handle* h, double* ptr, int64_t count, int op, const int* cancel,
+                  unsigned long long max_mask = 0, const Piggyback* rider = nullptr, const Mailbox* post = nullptr,
+                  const double* skip = nullptr) {
+    auto& p = h->p2p;
+    P2pArgs a{};
+    p2p_fill_args(h, a);
+    a.cancel = cancel;
+    a.max_mask = max_mask;
+    if (rider) a.rider = *rider;
+    if (post) a.post = *post;
+    a.skip = skip;
+    if ((rider || post) && count > 512) return fail(h, -1, "rider / post need a single-workgroup collective");
     const int grid = (int)std::min<int64_t>(kP2pMaxBlocks, std::max<int64_t>(1, (count + 511) / 512));
     hipLaunchKernelGGL(k_p2p_allreduce, dim3(grid), dim3(256), 0, h->stream, ptr, (int)count, op, a);
     LAUNCHED(h);
@@ -435,6 +446,10 @@ int set_lds(sfmba_handle* h, Kern k, size_t bytes) {
     h->lds_ready.push_back(fn);
     return 0;
 }
+
+// inverse point blocks: an array of their own, or (record layout 2) a slot of the CURRENT parameter vector's point
+// records -- written by k_prep / k_point_prep for h->rec before every consumer of the iteration
+double* vinv_ptr(const sfmba_handle* h) { return kVinvInRec < 0 ? h->Vinv.as<double>() : h->rec + kVinvInRec; }
 
 ObsArrays obs_arrays(const sfmba_handle* h) {
     return ObsArrays{h->cam_idx.as<int>(), h->pt_idx.as<int>(), h->pt_ptr.as<int>(),
@@ -567,8 +582,9 @@ int launch_resjac(sfmba_handle* h, const double* x, const double* tab, int* npar
     if (h->lds_tab)
         return h->f32 ? launch_resjac_v<true, JAC, STORE_R, true>(h, x, tab, grid, lds, ev0, ev1, blocks)
                       : launch_resjac_v<true, JAC, STORE_R, false>(h, x, tab, grid, lds, ev0, ev1, blocks);
-    return h->f32 ? launch_resjac_v<false, JAC, STORE_R, true>(h, x, tab, grid, 0, ev0, ev1, blocks)
-                  : launch_resjac_v<false, JAC, STORE_R, false>(h, x, tab, grid, 0, ev0, ev1, blocks);
+    const size_t slabs = sizeof(double) * kRowSlabDoubles * kWavesPerSweepBlock;       // rows gathered through the LDS
+    return h->f32 ? launch_resjac_v<false, JAC, STORE_R, true>(h, x, tab, grid, slabs, ev0, ev1, blocks)
+                  : launch_resjac_v<false, JAC, STORE_R, false>(h, x, tab, grid, slabs, ev0, ev1, blocks);
 }
 
 // sum of `nparts` partial rows of width nq into the exchange scalars starting at slot `slot`
@@ -649,7 +665,7 @@ int launch_point_sweep(sfmba_handle* h, const double* vin, const PcgCtrl* ctrl2,
         CHK(set_lds(h, kern, lds));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), lds, h->stream, step_table(h), (const int*)h->cam_idx.as<int>(),
                            (const int*)h->pt_idx.as<int>(), (const double*)h->tab, (const double*)(h->x + 6 * h->C), h->K, vin,
-                           (const double*)h->Vinv.as<double>(), h->rec, (const double*)h->acc(), (int)h->C, ctrl2, L,
+                           (const double*)vinv_ptr(h), h->rec, (const double*)h->acc(), (int)h->C, ctrl2, L,
                            PcgFused{}, (const double*)nullptr);
         LAUNCHED(h);
         return 0;
@@ -658,9 +674,12 @@ int launch_point_sweep(sfmba_handle* h, const double* vin, const PcgCtrl* ctrl2,
         hipLaunchKernelGGL(k_rc_table, dim3((unsigned)((h->C + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->tab, vin,
                            ctrl2, L, (int)h->C, h->rctab.as<double>());
         LAUNCHED(h);
-        hipLaunchKernelGGL((k_point_sweep_rc<false, true>), dim3(grid), dim3(kSweepThreads), 0, h->stream, step_table(h),
+        const size_t slabs = sizeof(double) * kRowSlabDoubles * kWavesPerSweepBlock;    // rows gathered through the LDS
+        auto kern_g = k_point_sweep_rc<false, true>;
+        CHK(set_lds(h, kern_g, slabs));
+        hipLaunchKernelGGL(kern_g, dim3(grid), dim3(kSweepThreads), slabs, h->stream, step_table(h),
                            (const int*)h->cam_idx.as<int>(), (const int*)h->pt_idx.as<int>(), (const double*)h->tab,
-                           (const double*)(h->x + 6 * h->C), h->K, vin, (const double*)h->Vinv.as<double>(), h->rec,
+                           (const double*)(h->x + 6 * h->C), h->K, vin, (const double*)vinv_ptr(h), h->rec,
                            (const double*)h->acc(), (int)h->C, ctrl2, L, PcgFused{}, (const double*)h->rctab.as<double>());
         LAUNCHED(h);
         return 0;
@@ -670,10 +689,10 @@ int launch_point_sweep(sfmba_handle* h, const double* vin, const PcgCtrl* ctrl2,
         auto kern = k_point_sweep<true, false>;
         CHK(set_lds(h, kern, lds));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), lds, h->stream, step_table(h), obs_arrays(h), vin,
-                           h->Vinv.as<double>(), h->rec, (const double*)h->acc(), (int)h->C, ctrl2, L, PcgFused{});
+                           vinv_ptr(h), h->rec, (const double*)h->acc(), (int)h->C, ctrl2, L, PcgFused{});
     } else {
         hipLaunchKernelGGL((k_point_sweep<false, false>), dim3(grid), dim3(kSweepThreads), 0, h->stream, step_table(h),
-                           obs_arrays(h), vin, h->Vinv.as<double>(), h->rec, (const double*)h->acc(),
+                           obs_arrays(h), vin, vinv_ptr(h), h->rec, (const double*)h->acc(),
                            (int)h->C, ctrl2, L, PcgFused{});
     }
     LAUNCHED(h);
@@ -685,24 +704,24 @@ int launch_pcg_fused(sfmba_handle* h, int L) {
     const int grid = (h->n_ranges + kWavesPerSweepBlock - 1) / kWavesPerSweepBlock;
     PcgFused pf{h->Dc.as<double>(), h->Minv.as<double>(), h->Ugc(), h->vecs.as<double>(), h->ctrl.as<PcgCtrl>(),
                 h->pcg_tol, h->pcg_cap, (const double*)(h->scal() + kEtaSlot),
-                h->pcg_local ? h->pcg_part.as<double>() : (double*)nullptr};
+                h->pcg_local ? h->pcg_part.as<double>() : (double*)nullptr, h->pcg_step ? 1 : 0};
     if (h->sweep_rc) {
         const size_t lds_rc = sizeof(double) * kRcRow * (size_t)h->C;
-        auto kern_rc = k_point_sweep_rc<true>;
+        auto kern_rc = h->pcg_step ? k_point_sweep_rc<true, false, true> : k_point_sweep_rc<true, false, false>;
         CHK(set_lds(h, kern_rc, lds_rc));
         hipLaunchKernelGGL(kern_rc, dim3(grid), dim3(kSweepThreads), lds_rc, h->stream, step_table(h),
                            (const int*)h->cam_idx.as<int>(), (const int*)h->pt_idx.as<int>(), (const double*)h->tab,
                            (const double*)(h->x + 6 * h->C), h->K, (const double*)h->vecs.as<double>(),
-                           (const double*)h->Vinv.as<double>(), h->rec, (const double*)h->acc(), (int)h->C,
+                           (const double*)vinv_ptr(h), h->rec, (const double*)h->acc(), (int)h->C,
                            (const PcgCtrl*)h->ctrl.as<PcgCtrl>(), L, pf, (const double*)nullptr);
         LAUNCHED(h);
         return 0;
     }
     const size_t lds = sizeof(double) * 6 * (size_t)h->C;
-    auto kern = k_point_sweep<true, true>;
+    auto kern = h->pcg_step ? k_point_sweep<true, true, true> : k_point_sweep<true, true, false>;
     CHK(set_lds(h, kern, lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), lds, h->stream, step_table(h), obs_arrays(h),
-                       (const double*)h->vecs.as<double>(), h->Vinv.as<double>(), h->rec,
+                       (const double*)h->vecs.as<double>(), vinv_ptr(h), h->rec,
                        (const double*)h->acc(), (int)h->C, (const PcgCtrl*)h->ctrl.as<PcgCtrl>(), L, pf);
     LAUNCHED(h);
     return 0;
@@ -726,6 +745,15 @@ int launch_cam_schur(sfmba_handle* h, const double* vin, const PcgCtrl* ctrl_don
     return launch_cam_combine(h, 6, h->acc(), 1, (int)h->C, nullptr, ctrl_done ? &ctrl_done->done : nullptr);
 }
 
+// Stepped PCG (k_pcg_begin / k_pcg_step): every sharded solve, and single-rank solves on request (debug option).
+bool pcg_step_mode(const sfmba_handle* h) {
+    if (h->dbg.precond == 0) return false;                   // (the block-Jacobi-of-U debug form keeps the old kernels)
+    return multi_rank(h) ? h->dbg.pcg_step != 0 : h->dbg.pcg_step == 1;
+}
+// k_pcg_begin leaves one gamma_0 partial per 64 cameras in pcg_part ([4][C] doubles): always fits
+bool pcg_begin_fits(const sfmba_handle* h) { return (h->C + kPcgBeginThreads - 1) / kPcgBeginThreads <= 4 * h->C; }
+int pcg_max_iters_of(const sfmba_handle* h) { return h->pcg_cap > 0 ? h->pcg_cap : (int)std::max<int64_t>(20, 2 * 6 * h->C); }
+
 // Reduced right-hand side term -> acc and, with the Schur-diagonal preconditioner, the diagonal blocks of
 // W Vinv W^T -> sd in the same pass; all-reduce; block inverses.  (k_prep has written e into the records and, for
 // the block-Jacobi-of-U form, Minv itself.)
@@ -736,20 +764,28 @@ int launch_rhs_and_preconditioner(sfmba_handle* h) {
         return exchange(h, h->acc(), 6 * C, 0);
     }
     // one rank and single-chunk cameras: every workgroup inverts its own preconditioner block (RhsPrecond)
-    const bool own_inverse = !multi_rank(h) && !h->cam_multi;
+    const bool own_inverse = !multi_rank(h) && !h->cam_multi && !pcg_step_mode(h);
     const RhsPrecond mp = own_inverse ? RhsPrecond{h->Ugc(), h->Dc.as<double>(), h->Minv.as<double>()} : RhsPrecond{nullptr, nullptr, nullptr};
     if (h->f32 && !h->sweep_rc && !h->sweep_rc_g)
         hipLaunchKernelGGL((k_cam_rhs_diag<true>), dim3(h->n_chunks), dim3(kRhsThreads), 0, h->stream, cam_major(h),
-                           (const double*)h->tab, (const double*)h->rec, (const double*)h->Vinv.as<double>(), h->K, (int)C,
-                           h->acc(), h->cam_partial.as<double>(), mp);
+                           (const double*)h->tab, (const double*)h->rec, (const double*)vinv_ptr(h), h->K, (int)C,
+                           h->acc(), h->cam_partial.as<double>(), mp, (const double*)h->rhsrec.as<double>());
     else
         hipLaunchKernelGGL((k_cam_rhs_diag<false>), dim3(h->n_chunks), dim3(kRhsThreads), 0, h->stream, cam_major(h),
-                           (const double*)h->tab, (const double*)h->rec, (const double*)h->Vinv.as<double>(), h->K, (int)C,
-                           h->acc(), h->cam_partial.as<double>(), mp);
+                           (const double*)h->tab, (const double*)h->rec, (const double*)vinv_ptr(h), h->K, (int)C,
+                           h->acc(), h->cam_partial.as<double>(), mp, (const double*)h->rhsrec.as<double>());
     LAUNCHED(h);
     if (own_inverse) return 0;
     CHK(launch_cam_combine(h, 27, h->acc(), 1, (int)C, nullptr, nullptr));
     CHK(exchange(h, h->acc(), 27 * C, 0));                  // acc | sd: one contiguous plane-major vector
+    if (pcg_step_mode(h) && pcg_begin_fits(h)) {            // block inverses AND the start of the PCG in one launch
+        hipLaunchKernelGGL(k_pcg_begin, dim3((unsigned)((C + kPcgBeginThreads - 1) / kPcgBeginThreads)), dim3(kPcgBeginThreads), 0,
+                           h->stream, (const double*)h->Ugc(), (const double*)h->acc(), (const double*)h->sd(), h->Dc.as<double>(),
+                           h->Minv.as<double>(), (int)C, h->vecs.as<double>(), (const double*)(h->scal() + kEtaSlot),
+                           pcg_max_iters_of(h), h->ctrl.as<PcgCtrl>(), h->pcg_part.as<double>());
+        LAUNCHED(h);
+        return 0;
+    }
     hipLaunchKernelGGL(k_cam_prep_schur, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, h->stream, (const double*)h->Ugc(),
                        (const double*)h->sd(), (int)C, h->Dc.as<double>(), h->Minv.as<double>());
     LAUNCHED(h);
@@ -765,7 +801,7 @@ constexpr double kDenseTolFactor = 0.1;
 int launch_dense_solve(sfmba_handle* h, double tol, int max_iters, bool rhs) {
     hipLaunchKernelGGL(k_schur_blocks, dim3(h->n_blk), dim3(kCamThreads), 0, h->stream, (const int*)h->cov_ptr.as<int>(),
                        (const int*)h->cov_pt.as<int>(), (const int2*)h->blk_ab.as<int2>(), (const double*)h->tab,
-                       (const double*)h->rec, (const double*)h->Vinv.as<double>(), h->K, (int)h->C,
+                       (const double*)h->rec, (const double*)vinv_ptr(h), h->K, (int)h->C,
                        h->Sblk.as<double>(), rhs ? h->acc() : (double*)nullptr);
     LAUNCHED(h);
     const int n = 6 * (int)h->C;
@@ -827,7 +863,7 @@ int launch_backsub(sfmba_handle* h, int* nparts) {
         auto kern = k_backsub<true>;
         CHK(set_lds(h, kern, lds));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), lds, h->stream, h->ranges.as<int2>(),
-                           h->n_ranges, obs_arrays(h), h->vecs.as<double>(), dc, h->Vinv.as<double>(),
+                           h->n_ranges, obs_arrays(h), h->vecs.as<double>(), dc, vinv_ptr(h),
                            h->gp.as<double>(), h->t1.as<double>(), dp, h->partB(), (int)h->C,
                            ctrl2, h->pcg_L, h->g.as<double>(), h->si.as<double>(), h->sg.as<double>());
     } else {
@@ -835,7 +871,7 @@ int launch_backsub(sfmba_handle* h, int* nparts) {
                            (const double*)h->vecs.as<double>(), 6, (int)h->C, dc, ctrl2, h->pcg_L);
         hipLaunchKernelGGL(k_backsub<false>, dim3(grid), dim3(kSweepThreads), 0, h->stream,
                            h->ranges.as<int2>(), h->n_ranges, obs_arrays(h), h->vecs.as<double>(), dc,
-                           h->Vinv.as<double>(), h->gp.as<double>(), h->t1.as<double>(), dp,
+                           vinv_ptr(h), h->gp.as<double>(), h->t1.as<double>(), dp,
                            h->partB(), (int)h->C, (const PcgCtrl*)nullptr, 0, h->g.as<double>(),
                            h->si.as<double>(), h->sg.as<double>());
     }
@@ -958,6 +994,11 @@ int pcg_max_iters(const sfmba_handle* h, const sfmba_options& opt) {
 // x = 0, r = rhs, u = Minv r (acc holds the reduced right-hand side term of pass B, MODE 1)
 int pcg_start(sfmba_handle* h, const sfmba_options& opt) {
     h->pcg_L = 0;
+    if (h->pcg_step) {                    // k_pcg_begin (launched with the preconditioner) has started the solve
+        h->pcg_local = h->pcg_local2 = false;
+        h->pcg_tol = opt.pcg_tol;
+        return 0;
+    }
     h->pcg_local = h->pcg_fused && !multi_rank(h) && !h->cam_multi && h->dbg.pcg_local != 0;
     h->pcg_local2 = !h->pcg_fused && h->sweep_rc_g && !multi_rank(h) && !h->cam_multi && h->dbg.pcg_local != 0;
     if (h->pcg_fused) {                   // launch 0 of the fused form initialises the solve itself
@@ -978,6 +1019,29 @@ int pcg_enqueue(sfmba_handle* h, int count) {
     PcgCtrl* ctrl2 = h->ctrl.as<PcgCtrl>();
     for (int k = 0; k < count; ++k) {
         const int L = h->pcg_L;
+        if (h->pcg_step) {
+            // pass A (prologue: fetch u), pass B, then ONE single-workgroup launch that all-reduces the product over the
+            // ranks and performs the whole update of the iteration (k_pcg_step); a finished solve voids all three
+            if (h->pcg_fused) CHK(launch_pcg_fused(h, L));
+            else CHK(launch_point_sweep(h, h->vecs.as<double>(), ctrl2, L));
+            CHK(launch_cam_schur<0>(h, h->vecs.as<double>(), ctrl2, -1, false));
+            const PcgStepArgs ps{h->Dc.as<double>(), h->Minv.as<double>(), h->vecs.as<double>(), ctrl2,
+                                 (const double*)h->pcg_part.as<double>(), (int)h->C};
+            if (h->p2p.ready && 6 * h->C <= h->p2p.stride && 6 * h->C <= kPcgStepP2pMax) {
+                P2pArgs a{};
+                p2p_fill_args(h, a);
+                hipLaunchKernelGGL(k_pcg_step<true>, dim3(1), dim3(1024), 0, h->stream, h->acc(), ps, a);
+                LAUNCHED(h);
+                ++h->p2p.calls;
+                ++h->n_collectives;
+            } else {
+                CHK(exchange(h, h->acc(), 6 * h->C, 0, &ctrl2->done));
+                hipLaunchKernelGGL(k_pcg_step<false>, dim3(1), dim3(1024), 0, h->stream, h->acc(), ps, P2pArgs{});
+                LAUNCHED(h);
+            }
+            h->pcg_L = L + 1;
+            continue;
+        }
         if (h->pcg_fused) {
             CHK(launch_pcg_fused(h, L));
             // a launch that found the solve finished (or finished it) produced no z: its control block (written
@@ -1143,6 +1207,7 @@ int sfmba_debug_option(sfmba_handle* h, const char* name, int64_t value) {
     else if (n == "dense") h->dbg.dense = v;
     else if (n == "precond") h->dbg.precond = v;
     else if (n == "pcg_local") h->dbg.pcg_local = v;
+    else if (n == "pcg_step") h->dbg.pcg_step = v;
     else if (n == "tab_lds") h->dbg.tab_lds = v;
     else if (n == "vec_lds") h->dbg.vec_lds = v;
     else if (n == "cam_chunk") h->dbg.cam_chunk = v;
@@ -1651,6 +1716,7 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     HIPCHK(h, h->cam_partial.ensure(sizeof(double) * 27 * chunks.size()));
     HIPCHK(h, h->recA.ensure(sizeof(double) * kRec * P));
     HIPCHK(h, h->recB.ensure(sizeof(double) * kRec * P));
+    HIPCHK(h, h->rhsrec.ensure(sizeof(double) * kRhsRec * P));
     if (h->dense) {
         HIPCHK(h, h->cov_ptr.ensure(sizeof(int) * cov_ptr.size()));
         HIPCHK(h, h->cov_pt.ensure(sizeof(int) * cov_pt.size()));
@@ -1659,7 +1725,7 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     }
     HIPCHK(h, h->t1.ensure(esz * 2 * ldz));
     HIPCHK(h, h->V.ensure(sizeof(double) * 6 * P));
-    HIPCHK(h, h->Vinv.ensure(sizeof(double) * 6 * P));
+    HIPCHK(h, h->Vinv.ensure(sizeof(double) * (kVinvInRec < 0 ? kVinvRow * P : 8)));
     HIPCHK(h, h->gp.ensure(sizeof(double) * 3 * P));
     HIPCHK(h, h->edge.ensure(sizeof(double) * 2 * kEdgeRow * (size_t)((N + 63) / 64)));
     HIPCHK(h, h->e.ensure(sizeof(double) * 3 * P));
@@ -1811,7 +1877,7 @@ int sfmba_schur_matvec(sfmba_handle* h, const double* x, const double* dc, const
     HIPCHK(h, hipMemcpyAsync(h->vtmp.p, vp.data(), sizeof(double) * 6 * C, hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(k_point_prep, dim3((h->P + 255) / 256), dim3(256), 0, h->stream, h->V.as<double>(),
                        h->gp.as<double>(), (const double*)nullptr, h->e.as<double>(), (int)h->P, 0.0,
-                       h->Vinv.as<double>(), (double*)nullptr);
+                       vinv_ptr(h), (double*)nullptr, (const double*)nullptr, (double*)nullptr);
     LAUNCHED(h);
     CHK(schur_product_standalone(h, h->vtmp.as<double>()));
     CHK(exchange(h, h->acc(), 6 * C, 0));
@@ -1850,7 +1916,7 @@ int sfmba_dense_schur(sfmba_handle* h, const double* x, const double* dc, const 
     HIPCHK(h, hipMemcpyAsync(h->acc(), accp.data(), sizeof(double) * 6 * C, hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(k_point_prep, dim3((h->P + 255) / 256), dim3(256), 0, h->stream, h->V.as<double>(),
                        h->gp.as<double>(), (const double*)nullptr, h->e.as<double>(), (int)h->P, 0.0,
-                       h->Vinv.as<double>(), (double*)nullptr);
+                       vinv_ptr(h), (double*)nullptr, (const double*)nullptr, (double*)nullptr);
     LAUNCHED(h);
     CHK(launch_dense_solve(h, 1e-14, 40 * 6 * (int)C, /*rhs=*/false));   // (test entry: to the end, to be compared with a direct solve)
     std::vector<double> blk(36 * (size_t)h->n_blk), sol(6 * C);
@@ -1893,7 +1959,7 @@ int sfmba_time_kernel(sfmba_handle* h, const double* x, int32_t which, int32_t r
         CHK(launch_update_scale(h, 1));
         hipLaunchKernelGGL(k_point_prep, dim3((h->P + 255) / 256), dim3(256), 0, h->stream, h->V.as<double>(),
                            h->gp.as<double>(), h->si.as<double>() + 6 * h->C, (const double*)nullptr, (int)h->P,
-                           1e-6, h->Vinv.as<double>(), h->rec + 3);
+                           1e-6, vinv_ptr(h), h->rec + 3, (const double*)(h->x + 6 * h->C), h->rhsrec.as<double>());
         LAUNCHED(h);
         // v = the camera slice of the gradient, as plane-major planes (and camera-major when v is not staged in LDS)
         hipLaunchKernelGGL(k_transpose, dim3((unsigned)((6 * h->C + 255) / 256)), dim3(256), 0, h->stream,
@@ -1919,6 +1985,13 @@ int sfmba_time_kernel(sfmba_handle* h, const double* x, int32_t which, int32_t r
             case 5: CHK(launch_cam_schur<0>(h, h->vtmp.as<double>(), nullptr, 0)); break;
             case 6: CHK(launch_cam_schur<1>(h, nullptr, nullptr, 0)); break;
             case 7: CHK((launch_resjac<true, true>(h, h->x, h->tab, &np, nullptr, nullptr, /*blocks=*/false))); break;
+            case 8:    // reduced right-hand side + Schur-diagonal blocks (without the 6x6 inverses)
+                hipLaunchKernelGGL((k_cam_rhs_diag<false>), dim3(h->n_chunks), dim3(kRhsThreads), 0, h->stream, cam_major(h),
+                                   (const double*)h->tab, (const double*)h->rec, (const double*)vinv_ptr(h), h->K, (int)h->C,
+                                   h->acc(), h->cam_partial.as<double>(), RhsPrecond{nullptr, nullptr, nullptr},
+                                   (const double*)h->rhsrec.as<double>());
+                LAUNCHED(h);
+                break;
             case 10:   // streaming-store ceiling: fill the Jacobian planes, 16 B per lane, one stream
                 hipLaunchKernelGGL(k_fill16, dim3(h->n_cu * 2), dim3(1024), 0, h->stream, h->J.as<double>(),
                                    (int64_t)((h->f32 ? 3 : 6) * h->ld), 1.0);
@@ -2085,12 +2158,15 @@ static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt
             hipLaunchKernelGGL(k_prep, dim3(bc + bp), dim3(64), 0, h->stream, sc, Delta, opt.reg_min, h->Ugc(),
                                h->V.as<double>(), h->gp.as<double>(), h->si.as<double>(), (int)C, (int)P, bc,
                                h->Dc.as<double>(), (h->dbg.precond == 0 ? h->Minv.as<double>() : (double*)nullptr),
-                               h->Vinv.as<double>(), h->rec + 3,
+                               vinv_ptr(h), h->rec + 3,
                                one_rank ? (const double*)h->partB() : (const double*)nullptr, np, opt.pcg_tol,
-                               std::max(opt.pcg_tol, opt.pcg_tol_max));
+                               std::max(opt.pcg_tol, opt.pcg_tol_max), (const double*)(h->x + 6 * C),
+                               (h->dense && one_rank) ? (double*)nullptr : h->rhsrec.as<double>());   // (read by k_cam_rhs_diag only)
             LAUNCHED(h);
         }
         const bool dense = h->dense && one_rank;               // (sharded: the block pairs would need their own all-reduce)
+        h->pcg_step = !dense && pcg_step_mode(h);
+        h->pcg_cap = pcg_max_iters(h, opt);
         if (!dense) CHK(launch_rhs_and_preconditioner(h));      // reduced rhs term -> acc, preconditioner blocks
                                                                 // (few cameras: both inside launch_dense_solve)
         if (!dense) CHK(pcg_start(h, opt));                     // replaces lsmr, trf.py:477-480
@@ -2102,7 +2178,7 @@ static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt
         } else if (pcg_guess > 0) {
             // speculative: no read-back; surplus launches are no-ops.  Fused launches apply the update of
             // iteration k in launch k + 1, so k iterations need k + 1 launches; one spare either way.
-            CHK(pcg_enqueue(h, pcg_guess + (h->pcg_fused ? 1 : 0) + (guess_exact ? 0 : 1)));
+            CHK(pcg_enqueue(h, pcg_guess + (h->pcg_fused && !h->pcg_step ? 1 : 0) + (guess_exact ? 0 : 1)));
         } else {
             CHK(pcg_finish_polling(h, opt, &hc));
         }
@@ -2174,7 +2250,7 @@ static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt
             return 0;
         };
         const bool speculated = pcg_guess > 0 || dense;         // dense: the control block always says "finished"
-        const int pcg_enqueued = pcg_guess > 0 ? pcg_guess + (h->pcg_fused ? 1 : 0) + (guess_exact ? 0 : 1) : 0;
+        const int pcg_enqueued = pcg_guess > 0 ? pcg_guess + (h->pcg_fused && !h->pcg_step ? 1 : 0) + (guess_exact ? 0 : 1) : 0;
         bool missed = false;
         for (bool speculative = speculated;;) {
             hipLaunchKernelGGL(k_tr_step, dim3(1), dim3(one_rank ? 1024 : 64), 0, h->stream, sc, Delta,

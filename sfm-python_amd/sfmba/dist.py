@@ -142,16 +142,17 @@ class DirectLink:
     ``sfmba_p2p_*``).  Create it AFTER :class:`NativeComm` or :class:`Exchange` (which stay as the
     fallback transport and for vectors larger than a slot).  ``active`` is False when any rank could not
     map a peer or failed the self-test: then every rank has detached and the previous transport serves.
-    ``SFMBA_P2P=0`` disables it."""
+    ``SFMBA_P2P=0`` disables it.  ``allow_single``: also at world size 1 (the rank maps only its own buffer) -- what
+    ``bench.py --force-exchange`` uses to time the sharded code path of one rank's share on one GPU."""
 
-    def __init__(self, backend, group=None):
+    def __init__(self, backend, group=None, allow_single=False):
         import os
         import torch
         import torch.distributed as td
         self.backend = backend
         self.active = False
         rank, world = td.get_rank(group), td.get_world_size(group)
-        if world < 2 or world > 16 or os.environ.get("SFMBA_P2P", "1") == "0":
+        if (world < 2 and not allow_single) or world > 16 or os.environ.get("SFMBA_P2P", "1") == "0":
             return
         dev = "cuda" if td.get_backend(group) == "nccl" else "cpu"
         try:

@@ -95,7 +95,9 @@ def test_growing_reconstruction_matches_recorded_scipy_runs():
                                                     verbose=0)
         reused_any |= be.problem_reuse()[0] > 0
         assert res.success
-        assert abs(res.rmse0 - g["rmse0"]) < 1e-3 * g["rmse0"]          # same stage input up to the previous stages' 1e-6
+        # (stage inputs differ from scipy's: no camera is fixed, so the two solvers drift differently along the
+        # 7-dimensional gauge, while a new camera / new points enter in absolute coordinates -- the minimum they
+        # converge to is the same; the replay from scipy's own x0 below compares like with like)
         assert abs(res.rmse - g["rmse"]) < 1e-6, (k, res.rmse, g["rmse"])
         assert res.cost <= g["cost"] * (1 + 1e-9), (k, res.cost, g["cost"])
         # identical inputs: scipy's own x0 of the stage (its previous results written back) instead of ours

@@ -300,8 +300,7 @@ def lsq_growing(ba):
                            nfev=int(res.nfev), njev=int(res.njev), cost=float(res.cost),
                            rmse=float(np.sqrt(np.mean(res.fun ** 2))), rmse0=float(np.sqrt(np.mean(r0 ** 2))),
                            optimality=float(res.optimality), seconds=dt))
-        arrays[f"s{k:02d}_x0"] = x0
-        arrays[f"s{k:02d}_x"] = res.x
+        arrays[f"s{k:02d}_x0"] = x0          # (stage inputs: a test can replay every stage from scipy's own start)
         print(f"  growing stage {k}: {n_cam}/{n_points}/{n_obs} status {res.status} njev {res.njev} "
               f"rmse {stages[-1]['rmse0']:.6f} -> {stages[-1]['rmse']:.9f} in {dt:.0f}s", flush=True)
         cp = res.x[:n_cam * 6].reshape((n_cam, 6))
