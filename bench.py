@@ -289,6 +289,23 @@ def main():
         # outside the timed region: the same residual+Jacobian kernel compiled WITHOUT the point-block sums (another
         # symbol, so its launches do not mix with the solver's in a rocprofv3 trace of this command), back to back
         k1_plain_us = be.time_kernel(pb.x0, 7, 50) if world == 1 else None
+        # `value` comes from back-to-back solves of the same x0, which replay the previous solve's per-iteration PCG
+        # counts (no spare launch, never a miss).  The other end: the FIRST solve of a fresh handle (no record: one spare
+        # PCG launch per iteration, counts guessed from the previous iteration), same problem resident, x0 crossing PCIe
+        first_solve = None
+        if world == 1:
+            fb = sfmba.Backend(local_rank)
+            fb.set_precision(a.storage_bits)
+            fb.set_problem(*pb.args)
+            opt1 = fb.default_options()
+            opt1.ftol = 1e-10
+            t1 = time.perf_counter()
+            _, r1, _, _ = fb.solve(pb.x0, opt1, want_fun=False, want_grad=False)
+            dt1 = time.perf_counter() - t1
+            first_solve = {"ms": round(1e3 * dt1, 3), "iterations": int(r1.iterations),
+                           "iterations_per_s": round(int(r1.iterations) / dt1, 1),
+                           "note": "first solve on a fresh handle: no PCG record to replay, first-use costs included"}
+            fb.close()
 
     if td is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -300,12 +317,14 @@ def main():
         k1_us = sum(r[3] * r[4] for r in results) / max(1, sum(r[4] for r in results))
         kb = k1_bytes_f32 if a.storage_bits == 32 else k1_bytes
         achieved = kb(Cl, Pl, Nl) / (k1_us * 1e-6) / 1e9 if k1_us > 0 else None
-        traffic = None
+        traffic = traffic_src = None
         tpath = os.path.join(ROOT, "profiles", "k1_traffic.json")
-        if os.path.exists(tpath) and world == 1:
+        if os.path.exists(tpath) and world == 1 and a.shard_of <= 1:
             tj = json.load(open(tpath))
             if str(tj.get("workload", "")).split()[0] == a.workload and a.storage_bits == 64:
                 traffic = tj.get("hbm_bytes_per_launch")
+                traffic_src = ("NOT measured in this run: FETCH_SIZE / WRITE_SIZE of the same kernel and workload from the "
+                               "committed rocprofv3 --pmc passes, profiles/k1_traffic.json")
         full = [r for r in results if r[6] != 0] or results
         strong = scaling == "strong"
         n_total, p_total = (N, P) if strong else (N * world, P * world)
@@ -321,6 +340,8 @@ def main():
             "dtype": "f64" if a.storage_bits == 64 else "f64 arithmetic, f32 storage", "data": "synthetic",
             "transport": None if td is None else (f"direct xGMI all-reduce kernel ({be.p2p_calls()} collectives; "
                                                   f"fallback {a.exchange})" if be.p2p_calls() > 0 else a.exchange),
+            "value_is": "back-to-back solves from the same x0 (each replays the previous solve's PCG iteration record)",
+            "first_solve_fresh_handle": first_solve,
             "launches_per_iteration": round((n_launch1 - n_launch0) / steps, 1),
             "collectives_per_iteration": round((n_coll1 - n_coll0) / steps, 1),
             "config": {"workload": (f"{a.workload}: {C} cameras / {P} points / {N} observations, seed 0 (SURVEY.md 8d "
@@ -343,7 +364,7 @@ def main():
             "roofline": {"kernel": "k_resjac (residual + 2x6/2x3 Jacobian sweep + point blocks V_p, g_p)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                         "traffic": traffic, "avg_launch_us": k1_us,
+                         "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": k1_us,
                          "algorithmic_bytes_per_launch": kb(Cl, Pl, Nl),
                          "note": "bytes = 136 N + 96 P + 48 C of the rank's shard: the 2x3 block d r/d T = -d r/d X is "
                                  "not stored; SURVEY 8d's 184 N figure writes it a second time",

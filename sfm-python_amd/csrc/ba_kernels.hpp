@@ -1306,27 +1306,8 @@ struct PcgFused {
     // with alpha from the summed partials and gamma_new = gamma - 2 alpha (s.u) + alpha^2 (s.m), gamma = sum r.u
     // being the TRUE value of the previous iterate (one recurrence step from an exact anchor: no drift).
     double* __restrict__ part;           // [4][C] partial dot products of the cameras (null: not the local form)
-    // STEPPED form (sharded solves): the whole update of an iteration is done ONCE, by the single workgroup that also
-    // all-reduces the product (k_pcg_step), and the solve is started by k_pcg_begin; the prologue of pass A then only
-    // fetches the new u (6 doubles per camera) for its LDS table.  Both control blocks always hold the same state.
-    int stepped;
 };
 constexpr int kPcgM = kPcgUcm;           // the local form keeps m = Minv s where the two-kernel form keeps its copy of u
-
-// STEPPED prologue of a fused pass-A launch (see PcgFused::stepped): fetch the u of the current iterate
-__device__ __forceinline__ bool pcg_stepped_fetch(const PcgFused& pf, int C, double (&uu)[6]) {
-    const PcgCtrl cs = pf.ctrl2[0];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) uu[k] = 0.0;
-    if (cs.done != 0) return false;                            // grid-uniform
-    const int cam = threadIdx.x;
-    if (cam < C) {
-        const double* __restrict__ us = pf.vecs + (size_t)((cs.iters & 1) * kPcgVecs + kPcgU) * 6 * C;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) uu[k] = us[(size_t)k * C + cam];
-    }
-    return true;
-}
 
 // The PCG update in the prologue of a fused pass-A launch (see PcgFused): returns false when the launch has
 // nothing more to do (the solve had finished or finishes here; grid-uniform).  Otherwise uu = the new u of
@@ -1523,7 +1504,7 @@ __device__ __forceinline__ bool pcg_fused_update(const PcgFused& pf, const doubl
     return done == 0;                                             // grid-uniform
 }
 
-template <bool LDS_VEC, bool FUSED, bool STEPPED = false>
+template <bool LDS_VEC, bool FUSED>
 __global__ __launch_bounds__(kSweepThreads) void k_point_sweep(
     StepTable st, ObsArrays o, const double* __restrict__ vin, const double* __restrict__ Vinv,
     double* __restrict__ zout, const double* __restrict__ acc, int C,
@@ -1543,8 +1524,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_point_sweep(
     if (cur.y <= 64 && lane < cur.y) { c = o.cam_idx[i]; p = o.pt_idx[i]; }
     if (FUSED) {
         double uu[6];
-        if (STEPPED) { if (!pcg_stepped_fetch(pf, C, uu)) return; }
-        else if (!pcg_fused_update(pf, acc, C, L, uu)) return;
+        if (!pcg_fused_update(pf, acc, C, L, uu)) return;
         if ((int)threadIdx.x < C) {
 #pragma unroll
             for (int k = 0; k < 6; ++k) smem[6 * threadIdx.x + k] = uu[k];
@@ -1669,7 +1649,7 @@ __global__ __launch_bounds__(256) void k_rc_table(const double* __restrict__ cam
 
 // GTAB (more cameras than the LDS holds): the table [C][18] was written to global memory by k_rc_table and its rows are
 // gathered from L2 by nine 16-byte loads per observation; `vin` is not used.
-template <bool FUSED, bool GTAB = false, bool STEPPED = false>
+template <bool FUSED, bool GTAB = false>
 __global__ __launch_bounds__(kSweepThreads) void k_point_sweep_rc(
     StepTable st, const int* __restrict__ cam_idx, const int* __restrict__ pt_idx,
     const double* __restrict__ camtab, const double* __restrict__ pts, KMat K, const double* __restrict__ vin,
@@ -1705,8 +1685,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_point_sweep_rc(
     };
     if (FUSED) {
         double uu[6];
-        if (STEPPED) { if (!pcg_stepped_fetch(pf, C, uu)) return; }
-        else if (!pcg_fused_update(pf, acc, C, L, uu)) return;
+        if (!pcg_fused_update(pf, acc, C, L, uu)) return;
         if ((int)threadIdx.x < C) put_au(threadIdx.x, uu);
     } else {
         if (ctrl2 != nullptr) {                               // two-kernel PCG: vin = base of the vector sets
@@ -2933,146 +2912,116 @@ __global__ __launch_bounds__(256) void k_p2p_allreduce(double* __restrict__ vec,
 }
 
 // ---------------------------------------------------------------------------------------------
-// STEPPED PCG (sharded solves): the product of an iteration is complete only after its all-reduce, and the reduced
-// vector is the same on every rank -- so the whole update of the iteration is done ONCE per rank, by the single
-// workgroup that performs the all-reduce, instead of redundantly in the prologue of every workgroup of pass A
-// (12 us of a 20 us launch on an eighth-size shard) or in eight workgroups that each read every vector
-// (k_pcg_update: 49 us at 5000 cameras).  Standard recurrences (those of k_pcg_update and of the oracle):
-//     w = acc + Dc u;  delta = w.u;  beta = gamma / gamma_prev;  alpha = gamma / (delta - beta gamma / alpha_prev)
-//     p = u + beta p;  s = w + beta s;  x += alpha p;  r -= alpha s;  u = Minv r;  gamma' = r.u
-// State: x r p s plane-major in vector set 0 (x in both sets: k_backsub picks one by the iteration count), u of
-// iteration i in set i & 1; BOTH control blocks always hold the same, latest state.
-// k_pcg_begin starts a solve: per camera the preconditioner block (U + Dc - sd)^-1 (what k_cam_prep_schur does), the
-// right-hand side r = -g_c - acc, u = Minv r, and gamma_0 as one partial per 64-camera workgroup (summed, in order, by
-// the first k_pcg_step: ctrl.pad = number of partials, rz = rz0 = 0 until then).
-// ---------------------------------------------------------------------------------------------
-constexpr int kPcgBeginThreads = 64;
-__global__ __launch_bounds__(kPcgBeginThreads) void k_pcg_begin(const double* __restrict__ Ugc, const double* __restrict__ acc,
-                                                                const double* __restrict__ sd, double* __restrict__ Dc,
-                                                                double* __restrict__ Minv, int C, double* __restrict__ vecs,
-                                                                const double* __restrict__ tol_dev, int max_iters,
-                                                                PcgCtrl* __restrict__ ctrl2, double* __restrict__ part0) {
-    const int cam = blockIdx.x * blockDim.x + threadIdx.x;
+// The local form of the PCG when pass B's workgroup does NOT hold the finished product of its camera: sharded solves
+// (the product is complete only after the all-reduce over the ranks) and cameras cut into several chunks.  The
+// per-camera bookkeeping of the iteration -- what the tail of k_cam_schur does on a single rank -- then runs once per
+// camera RIGHT BEHIND the reduction: inside the direct all-reduce kernel (k_p2p_pcg: the workgroup that has just summed
+// a camera's six entries over the ranks carries on with that camera), or in k_pcg_tail behind an RCCL / callback
+// collective or k_cam_combine.  Pass A's prologue is the light one of the local form in every case (16 doubles per
+// camera); nothing is redone per workgroup.  (Round 2 fell back to the general prologue in these cases: every one of
+// the 256 workgroups of pass A redid the whole update, 12 us of a 20 us launch on an eighth-size shard, or, past 1024
+// cameras, k_pcg_update's eight workgroups each read every vector: 49 us at 5000 cameras.)
+// One thread per camera; the arithmetic of the tail of k_cam_schur.
+__device__ __forceinline__ void pcg_tail_camera(int c, int C, const double* __restrict__ acc,
+                                                const double* __restrict__ u_planes, const PcgLocal& pl, const PcgCtrl& cd) {
     const size_t n6 = 6 * (size_t)C;
-    double t = 0.0;
-    if (cam < C) {
-        double m[21], rr[6];
-        cam_prep_regs(Ugc, nullptr, nullptr, C, cam, 0.0, Dc, Minv, sd, m);
+    const double beta = cd.iters == 0 ? 0.0 : cd.rz / cd.rz_prev, ap = cd.alpha_prev;
+    double u[6], sk[6];
+    double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) rr[k] = -Ugc[(size_t)cam * 27 + 21 + k] - acc[(size_t)k * C + cam];
+    for (int k = 0; k < 6; ++k) {
+        const size_t e = (size_t)k * C + c;
+        u[k] = u_planes[e];
+        const double w = acc[e] + pl.Dc[e] * u[k];                  // (S u)_k
+        const double p_old = pl.vecs[kPcgP * n6 + e], s_old = pl.vecs[kPcgS * n6 + e];
+        const double x = pl.vecs[kPcgX * n6 + e] + ap * p_old;      // the deferred updates of the previous iteration
+        const double r = pl.vecs[kPcgR * n6 + e] - ap * s_old;
+        sk[k] = w + beta * s_old;
+        pl.vecs[kPcgS * n6 + e] = sk[k];
+        pl.vecs[kPcgP * n6 + e] = u[k] + beta * p_old;
+        pl.vecs[kPcgR * n6 + e] = r;
+        pl.vecs[kPcgX * n6 + e] = x;
+        pl.vecs[(size_t)kPcgVecs * n6 + kPcgX * n6 + e] = x;        // x lives in both sets (k_backsub)
+        d0 += w * u[k]; d1 += sk[k] * u[k]; d3 += r * u[k];
+    }
+    double m[21];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const size_t e = (size_t)k * C + cam;
-            const double z = minv_row(m, rr, k);
-            t += z * rr[k];
-            vecs[kPcgX * n6 + e] = 0.0; vecs[(size_t)kPcgVecs * n6 + kPcgX * n6 + e] = 0.0;
-            vecs[kPcgP * n6 + e] = 0.0; vecs[kPcgS * n6 + e] = 0.0;
-            vecs[kPcgR * n6 + e] = rr[k];
-            vecs[kPcgU * n6 + e] = z;
-            vecs[kPcgUcm * n6 + 6 * (size_t)cam + k] = z;
-        }
+    for (int n = 0; n < 21; ++n) m[n] = pl.Minv[(size_t)n * C + c];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const double mk = minv_row(m, sk, k);
+        pl.vecs[kPcgM * n6 + (size_t)k * C + c] = mk;
+        d2 += sk[k] * mk;
     }
-    t = wave_sum(t);
-    if (threadIdx.x == 0) part0[blockIdx.x] = t;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        PcgCtrl c0;
-        const double tolv = *tol_dev;
-        c0.rz = 0.0; c0.rz0 = 0.0; c0.tol2 = tolv * tolv; c0.rz_prev = 1.0; c0.alpha_prev = 1.0;
-        c0.iters = 0; c0.max_iters = max_iters; c0.done = 0; c0.pad = (int)gridDim.x;
-        ctrl2[0] = c0; ctrl2[1] = c0;
-    }
+    pl.part[c] = d0; pl.part[(size_t)C + c] = d1; pl.part[2 * (size_t)C + c] = d2; pl.part[3 * (size_t)C + c] = d3;
 }
 
-struct PcgStepArgs {
-    const double* __restrict__ Dc;
-    const double* __restrict__ Minv;
-    double* __restrict__ vecs;
-    PcgCtrl* __restrict__ ctrl2;
-    const double* __restrict__ part0;    // gamma_0 partials of k_pcg_begin (null: ctrl.rz is valid from the start, k_pcg_init)
-    int C;
-};
-template <bool P2P>
-__global__ __launch_bounds__(1024) void k_pcg_step(double* __restrict__ acc, PcgStepArgs ps, P2pArgs a) {
-    __shared__ double slots_a[16];
-    __shared__ double slots_b[16];
-    PcgCtrl ci = ps.ctrl2[0];
-    if (ci.done != 0) return;                                 // identical on all ranks: no collective either
-    const int C = ps.C;
-    const size_t n6 = 6 * (size_t)C;
-    if (P2P) {
-        if (*a.error == 0u) p2p_allreduce_body(acc, 6 * C, 0, a);
+// Behind a collective of another transport, or k_cam_combine: acc holds the finished product.
+//   ctrl: the control block pass A of this launch wrote (k_cam_schur's ctrl_done); set < 0: u's set from ctrl->iters
+__global__ __launch_bounds__(64) void k_pcg_tail(const double* __restrict__ acc, const double* __restrict__ vin, int C,
+                                                 const PcgCtrl* __restrict__ ctrl, int set, PcgLocal pl) {
+    const PcgCtrl cd = *ctrl;
+    if (cd.done != 0) return;                                 // grid-uniform
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    pcg_tail_camera(c, C, acc, vin + (size_t)((set < 0 ? (cd.iters & 1) : set) * kPcgVecs + kPcgU) * 6 * C, pl, cd);
+}
+
+// The direct all-reduce of the product (6 C doubles, plane-major) sliced BY CAMERA, each workgroup carrying on with the
+// bookkeeping of the cameras it has just reduced.  Protocol of k_p2p_allreduce (same staging slots, flags, parity,
+// ticket, time-out).
+constexpr int kP2pPcgThreads = 256;
+__global__ __launch_bounds__(kP2pPcgThreads) void k_p2p_pcg(double* __restrict__ acc, const double* __restrict__ vin, int C,
+                                                            const PcgCtrl* __restrict__ ctrl, int set, PcgLocal pl, P2pArgs a) {
+    __shared__ unsigned s_last;
+    const PcgCtrl cd = *ctrl;
+    if (cd.done != 0) return;                                 // identical on all ranks: no collective either
+    const int tid = threadIdx.x;
+    const int per = (C + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int lo = (int)blockIdx.x * per, n = max(0, min(C, lo + per) - lo);           // this workgroup's cameras
+    if (*a.error == 0u) {
+        const unsigned long long seq = *a.seq + 1ull;
+        const int par = (int)(seq & 1ull);
+        for (int q = 0; q < a.world; ++q) {
+            double* dst = a.data[q] + ((size_t)par * a.world + a.rank) * a.stride;
+            for (int t = tid; t < 6 * n; t += blockDim.x) {
+                const int k = t / n, e = k * C + lo + (t - k * n);
+                __hip_atomic_store(dst + e, acc[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        __threadfence_system();
         __syncthreads();
-    }
-    const bool writer = threadIdx.x == 0;
-    if (ci.iters == 0 && ps.part0 != nullptr) {               // gamma_0: k_pcg_begin's partials, in order
-        double g0 = 0.0;
-        for (int b = 0; b < ci.pad; ++b) g0 += ps.part0[b];
-        ci.rz = g0; ci.rz0 = g0;
-        if (!(g0 > 0.0)) {                                    // zero right-hand side (x = 0 is the solution) / NaN
-            ci.done = g0 == 0.0 ? 1 : 3;
-            if (writer) { ps.ctrl2[0] = ci; ps.ctrl2[1] = ci; }
-            return;
+        if (tid == 0) s_last = (atomicAdd(a.ticket, 1u) == gridDim.x - 1) ? 1u : 0u;
+        __syncthreads();
+        if (s_last != 0u) {
+            __threadfence_system();
+            if (tid < a.world)
+                __hip_atomic_store(a.flags[tid] + ((size_t)par * a.world + a.rank) * kP2pFlagStride, seq,
+                                   __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (tid == 0) { *a.ticket = 0u; *a.seq = seq; }
+        }
+        if (tid < a.world) {
+            const unsigned long long* f = a.flags[a.rank] + ((size_t)par * a.world + tid) * kP2pFlagStride;
+            const long long t0 = wall_clock64();
+            while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+                if (wall_clock64() - t0 > a.timeout) { atomicExch(a.error, 1u); break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        __syncthreads();
+        __threadfence_system();
+        const double* slots = a.data[a.rank] + (size_t)par * a.world * a.stride;
+        for (int t = tid; t < 6 * n; t += blockDim.x) {
+            const int k = t / n, e = k * C + lo + (t - k * n);
+            double s = __hip_atomic_load(slots + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            for (int q = 1; q < a.world; ++q)                  // rank order: bitwise the same sum on every rank
+                s += __hip_atomic_load(slots + (size_t)q * a.stride + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            acc[e] = s;
         }
     }
-    const int set = ci.iters & 1;
-    const double* __restrict__ u_in = ps.vecs + ((size_t)set * kPcgVecs + kPcgU) * n6;
-    double* __restrict__ u_out = ps.vecs + ((size_t)(set ^ 1) * kPcgVecs + kPcgU) * n6;
-    double* __restrict__ ucm_out = ps.vecs + ((size_t)(set ^ 1) * kPcgVecs + kPcgUcm) * n6;
-    double* __restrict__ X0 = ps.vecs + kPcgX * n6;
-    double* __restrict__ X1 = ps.vecs + (size_t)kPcgVecs * n6 + kPcgX * n6;
-    double* __restrict__ R = ps.vecs + kPcgR * n6;
-    double* __restrict__ Pv = ps.vecs + kPcgP * n6;
-    double* __restrict__ Sv = ps.vecs + kPcgS * n6;
-    double d = 0.0;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const size_t e = (size_t)k * C + c;
-            const double ue = u_in[e];
-            d += (acc[e] + ps.Dc[e] * ue) * ue;
-        }
-    }
-    const double delta = block_sum_all(d, slots_a);
-    const double gamma = ci.rz;
-    const double beta = ci.iters == 0 ? 0.0 : gamma / ci.rz_prev;
-    const double den = delta - (ci.iters == 0 ? 0.0 : beta * gamma / ci.alpha_prev);
-    const double alpha = gamma / den;
-    if (!(den > 0.0) || !isfinite(alpha)) {                    // S not SPD / NaN: x stays the last good iterate
-        if (writer) { ci.done = 3; ps.ctrl2[0] = ci; ps.ctrl2[1] = ci; }
-        return;
-    }
-    double t = 0.0;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        double rr[6], m[21];
-#pragma unroll
-        for (int n = 0; n < 21; ++n) m[n] = ps.Minv[(size_t)n * C + c];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const size_t e = (size_t)k * C + c;
-            const double ue = u_in[e];
-            const double we = acc[e] + ps.Dc[e] * ue;
-            const double pk = ue + beta * Pv[e];
-            const double sk = we + beta * Sv[e];
-            const double xk = X0[e] + alpha * pk;
-            rr[k] = R[e] - alpha * sk;
-            Pv[e] = pk; Sv[e] = sk; X0[e] = xk; X1[e] = xk; R[e] = rr[k];
-        }
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const double z = minv_row(m, rr, k);
-            t += z * rr[k];
-            u_out[(size_t)k * C + c] = z;
-            ucm_out[6 * (size_t)c + k] = z;
-        }
-    }
-    const double rz = block_sum_all(t, slots_b);
-    if (writer) {
-        PcgCtrl co = ci;
-        co.rz_prev = gamma; co.alpha_prev = alpha; co.rz = rz; co.iters = ci.iters + 1;
-        if (!(rz > ci.tol2 * ci.rz0)) co.done = 1;            // also catches NaN
-        else if (co.iters >= ci.max_iters) co.done = 2;
-        ps.ctrl2[0] = co; ps.ctrl2[1] = co;
-    }
+    __syncthreads();                                          // this workgroup's entries of acc are final
+    if (tid < n)
+        pcg_tail_camera(lo + tid, C, acc, vin + (size_t)((set < 0 ? (cd.iters & 1) : set) * kPcgVecs + kPcgU) * 6 * C, pl, cd);
 }
 
 __global__ __launch_bounds__(1024) void k_fill16(double* __restrict__ a, int64_t n2, double v) {

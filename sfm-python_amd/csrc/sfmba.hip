@@ -231,8 +231,9 @@ struct sfmba_handle {
         int dense = -1;                      // 0: PCG although the dense reduced-camera path would apply
         int precond = -1;                    // 0: block-Jacobi preconditioner from U + Dc instead of the Schur diagonal
         int pcg_local = -1;                  // 0: the fused PCG keeps its whole update in pass A's prologue
-        int pcg_step = -1;                   // 1: the stepped PCG (k_pcg_begin / k_pcg_step) on a single rank too;
-                                             // 0: sharded solves keep the round-2 forms (update in every workgroup)
+        int pcg_split = -1;                  // 1: the local form with its tail in a kernel of its own (k_pcg_tail) on a
+                                             // single rank too; 0: sharded / multi-chunk solves keep the round-2 forms
+                                             // (whole update in every workgroup of pass A, or k_pcg_update)
         int cam_chunk = 0;                   // > 0: chunk length of the camera-major kernels
         int pcg_guess_bias = 0;              // added to the number of speculatively enqueued PCG iterations
         int trace_pcg = 0, trace_stalls = 0, trace_timing = 0;   // stderr diagnostics
@@ -298,13 +299,15 @@ struct sfmba_handle {
     bool pcg_fused = false;               // PCG update fused into the launch of pass A (v in LDS, C <= 1024)
     bool pcg_local = false;               // ... with the per-camera bookkeeping in pass B (one rank, single-chunk cameras)
     bool pcg_local2 = false;              // the same bookkeeping with the light update as a kernel of its own (> 1024 cameras)
-    bool pcg_step = false;                // stepped form: the update once per iteration in the collective's workgroup (sharded solves)
+    bool pcg_split = false;               // local form whose per-camera tail runs behind the reduction (k_p2p_pcg / k_pcg_tail)
+                                          // instead of inside pass B: sharded solves, cameras of several chunks
     DevBuf pcg_part;                      // [4][C] partial dot products of the local form
     int pcg_hint = 0;                     // largest PCG iteration count a solve on this handle has needed
     std::vector<int> pcg_hist;            // PCG iterations of outer iteration k in the previous solve on this handle: the
                                           // reference solves a slightly grown problem from a nearby start call after
                                           // call (sfm.py:59-71), and the counts repeat; with a record the speculative
                                           // batch is that count (+1 launch for the fused update), without the spare
+    int64_t hist_C = 0, hist_P = 0, hist_N = 0;   // the problem pcg_hist was recorded on
     bool solved = false;
     bool transport_dropped = false;          // sfmba_set_problem tore down an active transport: the next compute call
                                              // fails until one is set up again (or single-rank use is acknowledged)
@@ -376,8 +379,6 @@ bool multi_rank(const sfmba_handle* h) { return h->p2p.ready || h->comm != nullp
 const unsigned* p2p_error_word(const sfmba_handle* h) { return h->p2p.ready ? h->p2p.words + 1 : nullptr; }
 
 constexpr size_t kP2pFlagBytes = sizeof(unsigned long long) * 2 * kP2pMaxRanks * kP2pFlagStride;
-
-constexpr int64_t kPcgStepP2pMax = 6 * 1024;   // k_pcg_step<true> copies the vector to every rank with ONE workgroup
 
 void p2p_fill_args(sfmba_handle* h, P2pArgs& a) {
     auto& p = h->p2p;
@@ -704,10 +705,10 @@ int launch_pcg_fused(sfmba_handle* h, int L) {
     const int grid = (h->n_ranges + kWavesPerSweepBlock - 1) / kWavesPerSweepBlock;
     PcgFused pf{h->Dc.as<double>(), h->Minv.as<double>(), h->Ugc(), h->vecs.as<double>(), h->ctrl.as<PcgCtrl>(),
                 h->pcg_tol, h->pcg_cap, (const double*)(h->scal() + kEtaSlot),
-                h->pcg_local ? h->pcg_part.as<double>() : (double*)nullptr, h->pcg_step ? 1 : 0};
+                h->pcg_local ? h->pcg_part.as<double>() : (double*)nullptr};
     if (h->sweep_rc) {
         const size_t lds_rc = sizeof(double) * kRcRow * (size_t)h->C;
-        auto kern_rc = h->pcg_step ? k_point_sweep_rc<true, false, true> : k_point_sweep_rc<true, false, false>;
+        auto kern_rc = k_point_sweep_rc<true>;
         CHK(set_lds(h, kern_rc, lds_rc));
         hipLaunchKernelGGL(kern_rc, dim3(grid), dim3(kSweepThreads), lds_rc, h->stream, step_table(h),
                            (const int*)h->cam_idx.as<int>(), (const int*)h->pt_idx.as<int>(), (const double*)h->tab,
@@ -718,7 +719,7 @@ int launch_pcg_fused(sfmba_handle* h, int L) {
         return 0;
     }
     const size_t lds = sizeof(double) * 6 * (size_t)h->C;
-    auto kern = h->pcg_step ? k_point_sweep<true, true, true> : k_point_sweep<true, true, false>;
+    auto kern = k_point_sweep<true, true>;
     CHK(set_lds(h, kern, lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), lds, h->stream, step_table(h), obs_arrays(h),
                        (const double*)h->vecs.as<double>(), vinv_ptr(h), h->rec,
@@ -745,14 +746,13 @@ int launch_cam_schur(sfmba_handle* h, const double* vin, const PcgCtrl* ctrl_don
     return launch_cam_combine(h, 6, h->acc(), 1, (int)h->C, nullptr, ctrl_done ? &ctrl_done->done : nullptr);
 }
 
-// Stepped PCG (k_pcg_begin / k_pcg_step): every sharded solve, and single-rank solves on request (debug option).
-bool pcg_step_mode(const sfmba_handle* h) {
-    if (h->dbg.precond == 0) return false;                   // (the block-Jacobi-of-U debug form keeps the old kernels)
-    return multi_rank(h) ? h->dbg.pcg_step != 0 : h->dbg.pcg_step == 1;
+// The local form with its tail split off (k_p2p_pcg / k_pcg_tail): sharded solves and cameras of several chunks; on a
+// single rank with single-chunk cameras only on request (debug option, tests).
+bool pcg_split_mode(const sfmba_handle* h) {
+    if (h->dbg.pcg_local == 0 || h->dbg.precond == 0) return false;
+    if (!(h->pcg_fused || h->sweep_rc_g)) return false;         // (the forms that have a local prologue / k_pcg_update_local)
+    return (multi_rank(h) || h->cam_multi) ? h->dbg.pcg_split != 0 : h->dbg.pcg_split == 1;
 }
-// k_pcg_begin leaves one gamma_0 partial per 64 cameras in pcg_part ([4][C] doubles): always fits
-bool pcg_begin_fits(const sfmba_handle* h) { return (h->C + kPcgBeginThreads - 1) / kPcgBeginThreads <= 4 * h->C; }
-int pcg_max_iters_of(const sfmba_handle* h) { return h->pcg_cap > 0 ? h->pcg_cap : (int)std::max<int64_t>(20, 2 * 6 * h->C); }
 
 // Reduced right-hand side term -> acc and, with the Schur-diagonal preconditioner, the diagonal blocks of
 // W Vinv W^T -> sd in the same pass; all-reduce; block inverses.  (k_prep has written e into the records and, for
@@ -764,7 +764,7 @@ int launch_rhs_and_preconditioner(sfmba_handle* h) {
         return exchange(h, h->acc(), 6 * C, 0);
     }
     // one rank and single-chunk cameras: every workgroup inverts its own preconditioner block (RhsPrecond)
-    const bool own_inverse = !multi_rank(h) && !h->cam_multi && !pcg_step_mode(h);
+    const bool own_inverse = !multi_rank(h) && !h->cam_multi;
     const RhsPrecond mp = own_inverse ? RhsPrecond{h->Ugc(), h->Dc.as<double>(), h->Minv.as<double>()} : RhsPrecond{nullptr, nullptr, nullptr};
     if (h->f32 && !h->sweep_rc && !h->sweep_rc_g)
         hipLaunchKernelGGL((k_cam_rhs_diag<true>), dim3(h->n_chunks), dim3(kRhsThreads), 0, h->stream, cam_major(h),
@@ -778,14 +778,6 @@ int launch_rhs_and_preconditioner(sfmba_handle* h) {
     if (own_inverse) return 0;
     CHK(launch_cam_combine(h, 27, h->acc(), 1, (int)C, nullptr, nullptr));
     CHK(exchange(h, h->acc(), 27 * C, 0));                  // acc | sd: one contiguous plane-major vector
-    if (pcg_step_mode(h) && pcg_begin_fits(h)) {            // block inverses AND the start of the PCG in one launch
-        hipLaunchKernelGGL(k_pcg_begin, dim3((unsigned)((C + kPcgBeginThreads - 1) / kPcgBeginThreads)), dim3(kPcgBeginThreads), 0,
-                           h->stream, (const double*)h->Ugc(), (const double*)h->acc(), (const double*)h->sd(), h->Dc.as<double>(),
-                           h->Minv.as<double>(), (int)C, h->vecs.as<double>(), (const double*)(h->scal() + kEtaSlot),
-                           pcg_max_iters_of(h), h->ctrl.as<PcgCtrl>(), h->pcg_part.as<double>());
-        LAUNCHED(h);
-        return 0;
-    }
     hipLaunchKernelGGL(k_cam_prep_schur, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, h->stream, (const double*)h->Ugc(),
                        (const double*)h->sd(), (int)C, h->Dc.as<double>(), h->Minv.as<double>());
     LAUNCHED(h);
@@ -994,13 +986,9 @@ int pcg_max_iters(const sfmba_handle* h, const sfmba_options& opt) {
 // x = 0, r = rhs, u = Minv r (acc holds the reduced right-hand side term of pass B, MODE 1)
 int pcg_start(sfmba_handle* h, const sfmba_options& opt) {
     h->pcg_L = 0;
-    if (h->pcg_step) {                    // k_pcg_begin (launched with the preconditioner) has started the solve
-        h->pcg_local = h->pcg_local2 = false;
-        h->pcg_tol = opt.pcg_tol;
-        return 0;
-    }
-    h->pcg_local = h->pcg_fused && !multi_rank(h) && !h->cam_multi && h->dbg.pcg_local != 0;
-    h->pcg_local2 = !h->pcg_fused && h->sweep_rc_g && !multi_rank(h) && !h->cam_multi && h->dbg.pcg_local != 0;
+    h->pcg_split = pcg_split_mode(h);
+    h->pcg_local = h->pcg_fused && h->dbg.pcg_local != 0 && ((!multi_rank(h) && !h->cam_multi) || h->pcg_split);
+    h->pcg_local2 = !h->pcg_fused && h->sweep_rc_g && h->dbg.pcg_local != 0 && ((!multi_rank(h) && !h->cam_multi) || h->pcg_split);
     if (h->pcg_fused) {                   // launch 0 of the fused form initialises the solve itself
         h->pcg_tol = opt.pcg_tol;
         h->pcg_cap = pcg_max_iters(h, opt);
@@ -1013,49 +1001,51 @@ int pcg_start(sfmba_handle* h, const sfmba_options& opt) {
     return 0;
 }
 
+// The product of pass B (camera chunks already combined) summed over the ranks, and the per-camera tail of the local form
+// behind it: one launch on the direct path (k_p2p_pcg), else the collective of the transport and k_pcg_tail.
+int launch_reduce_and_tail(sfmba_handle* h, const PcgCtrl* cd, int set) {
+    const int C = (int)h->C;
+    const PcgLocal pl{h->Dc.as<double>(), h->Minv.as<double>(), h->vecs.as<double>(), h->pcg_part.as<double>()};
+    const int grid = std::max((C + kP2pPcgThreads - 1) / kP2pPcgThreads, std::min(kP2pMaxBlocks, (C + 63) / 64));
+    if (h->p2p.ready && 6 * h->C <= h->p2p.stride && grid <= kP2pMaxBlocks) {
+        P2pArgs a{};
+        p2p_fill_args(h, a);
+        hipLaunchKernelGGL(k_p2p_pcg, dim3(grid), dim3(kP2pPcgThreads), 0, h->stream, h->acc(), (const double*)h->vecs.as<double>(),
+                           C, cd, set, pl, a);
+        LAUNCHED(h);
+        ++h->p2p.calls;
+        ++h->n_collectives;
+        return 0;
+    }
+    CHK(exchange(h, h->acc(), 6 * h->C, 0, &cd->done));
+    hipLaunchKernelGGL(k_pcg_tail, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, h->stream, (const double*)h->acc(),
+                       (const double*)h->vecs.as<double>(), C, cd, set, pl);
+    LAUNCHED(h);
+    return 0;
+}
+
 // enqueue `count` PCG iterations (pass A [+ update], pass B, all-reduce [, update]); iterations after
 // convergence are device-side no-ops, so over-enqueueing is harmless and deterministic
 int pcg_enqueue(sfmba_handle* h, int count) {
     PcgCtrl* ctrl2 = h->ctrl.as<PcgCtrl>();
     for (int k = 0; k < count; ++k) {
         const int L = h->pcg_L;
-        if (h->pcg_step) {
-            // pass A (prologue: fetch u), pass B, then ONE single-workgroup launch that all-reduces the product over the
-            // ranks and performs the whole update of the iteration (k_pcg_step); a finished solve voids all three
-            if (h->pcg_fused) CHK(launch_pcg_fused(h, L));
-            else CHK(launch_point_sweep(h, h->vecs.as<double>(), ctrl2, L));
-            CHK(launch_cam_schur<0>(h, h->vecs.as<double>(), ctrl2, -1, false));
-            const PcgStepArgs ps{h->Dc.as<double>(), h->Minv.as<double>(), h->vecs.as<double>(), ctrl2,
-                                 (const double*)h->pcg_part.as<double>(), (int)h->C};
-            if (h->p2p.ready && 6 * h->C <= h->p2p.stride && 6 * h->C <= kPcgStepP2pMax) {
-                P2pArgs a{};
-                p2p_fill_args(h, a);
-                hipLaunchKernelGGL(k_pcg_step<true>, dim3(1), dim3(1024), 0, h->stream, h->acc(), ps, a);
-                LAUNCHED(h);
-                ++h->p2p.calls;
-                ++h->n_collectives;
-            } else {
-                CHK(exchange(h, h->acc(), 6 * h->C, 0, &ctrl2->done));
-                hipLaunchKernelGGL(k_pcg_step<false>, dim3(1), dim3(1024), 0, h->stream, h->acc(), ps, P2pArgs{});
-                LAUNCHED(h);
-            }
-            h->pcg_L = L + 1;
-            continue;
-        }
         if (h->pcg_fused) {
             CHK(launch_pcg_fused(h, L));
             // a launch that found the solve finished (or finished it) produced no z: its control block (written
             // to slot (L+1)&1) says so, and pass B and the collective behind it are void as well
             const PcgCtrl* cd = ctrl2 + ((L + 1) & 1);
-            CHK(launch_cam_schur<0>(h, h->vecs.as<double>(), cd, L & 1, h->pcg_local));
-            CHK(exchange(h, h->acc(), 6 * h->C, 0, &cd->done));
+            CHK(launch_cam_schur<0>(h, h->vecs.as<double>(), cd, L & 1, h->pcg_local && !h->pcg_split));
+            if (h->pcg_split) CHK(launch_reduce_and_tail(h, cd, L & 1));
+            else CHK(exchange(h, h->acc(), 6 * h->C, 0, &cd->done));
             h->pcg_L = L + 1;
             continue;
         }
         const PcgCtrl* cd = ctrl2 + (L & 1);                     // current until k_pcg_update writes the other one
         CHK(launch_point_sweep(h, h->vecs.as<double>(), ctrl2, L));
-        CHK(launch_cam_schur<0>(h, h->vecs.as<double>(), cd, -1, h->pcg_local2));
-        if (h->pcg_local2) {                                    // pass B did the bookkeeping: the light update
+        CHK(launch_cam_schur<0>(h, h->vecs.as<double>(), cd, -1, h->pcg_local2 && !h->pcg_split));
+        if (h->pcg_local2 && h->pcg_split) CHK(launch_reduce_and_tail(h, cd, -1));
+        if (h->pcg_local2) {                                    // pass B / the tail did the bookkeeping: the light update
             hipLaunchKernelGGL(k_pcg_update_local, dim3((unsigned)((h->C + 1023) / 1024)), dim3(1024), 0, h->stream,
                                h->vecs.as<double>(), (const double*)h->pcg_part.as<double>(), ctrl2, L, (int)h->C);
             LAUNCHED(h);
@@ -1207,7 +1197,7 @@ int sfmba_debug_option(sfmba_handle* h, const char* name, int64_t value) {
     else if (n == "dense") h->dbg.dense = v;
     else if (n == "precond") h->dbg.precond = v;
     else if (n == "pcg_local") h->dbg.pcg_local = v;
-    else if (n == "pcg_step") h->dbg.pcg_step = v;
+    else if (n == "pcg_split") h->dbg.pcg_split = v;
     else if (n == "tab_lds") h->dbg.tab_lds = v;
     else if (n == "vec_lds") h->dbg.vec_lds = v;
     else if (n == "cam_chunk") h->dbg.cam_chunk = v;
@@ -2109,7 +2099,13 @@ static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt
     int pcg_guess = h->pcg_hint;                                // iterations to enqueue without reading back
     std::vector<int> pcg_hist_new;
     bool guess_exact = false;                                   // pcg_guess comes from the record: no spare launch
-    if (!h->pcg_hist.empty() && h->pcg_hist[0] > 0) { pcg_guess = h->pcg_hist[0]; guess_exact = true; }
+    // The record is trusted count for count only on the problem it was recorded on; on a neighbouring problem (the
+    // reference's growing reconstruction: a camera or a few hundred observations more) it is a guess with a spare
+    // launch; on an unrelated problem it is dropped together with the running hint.
+    const bool hist_same = h->hist_C == C && h->hist_P == P && h->hist_N == h->N;
+    const bool hist_near = hist_same || (h->hist_N > 0 && std::llabs(h->hist_C - C) <= 1 && 2 * h->N >= h->hist_N && h->N <= 2 * h->hist_N);
+    if (!hist_near) { h->pcg_hist.clear(); h->pcg_hint = 0; pcg_guess = 0; }
+    if (!h->pcg_hist.empty() && h->pcg_hist[0] > 0) { pcg_guess = h->pcg_hist[0]; guess_exact = hist_same; }
     int64_t pcg_breakdowns = 0;
     bool nb_valid = true;                                       // V, g_p, [U|g_c] (and, single-buffered, J and r) belong to h->x
     // Single-buffered Jacobian: the trial point is evaluated into the SAME J / r buffers the sweeps of
@@ -2165,8 +2161,6 @@ static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt
             LAUNCHED(h);
         }
         const bool dense = h->dense && one_rank;               // (sharded: the block pairs would need their own all-reduce)
-        h->pcg_step = !dense && pcg_step_mode(h);
-        h->pcg_cap = pcg_max_iters(h, opt);
         if (!dense) CHK(launch_rhs_and_preconditioner(h));      // reduced rhs term -> acc, preconditioner blocks
                                                                 // (few cameras: both inside launch_dense_solve)
         if (!dense) CHK(pcg_start(h, opt));                     // replaces lsmr, trf.py:477-480
@@ -2178,7 +2172,7 @@ static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt
         } else if (pcg_guess > 0) {
             // speculative: no read-back; surplus launches are no-ops.  Fused launches apply the update of
             // iteration k in launch k + 1, so k iterations need k + 1 launches; one spare either way.
-            CHK(pcg_enqueue(h, pcg_guess + (h->pcg_fused && !h->pcg_step ? 1 : 0) + (guess_exact ? 0 : 1)));
+            CHK(pcg_enqueue(h, pcg_guess + (h->pcg_fused ? 1 : 0) + (guess_exact ? 0 : 1)));
         } else {
             CHK(pcg_finish_polling(h, opt, &hc));
         }
@@ -2250,7 +2244,7 @@ static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt
             return 0;
         };
         const bool speculated = pcg_guess > 0 || dense;         // dense: the control block always says "finished"
-        const int pcg_enqueued = pcg_guess > 0 ? pcg_guess + (h->pcg_fused && !h->pcg_step ? 1 : 0) + (guess_exact ? 0 : 1) : 0;
+        const int pcg_enqueued = pcg_guess > 0 ? pcg_guess + (h->pcg_fused ? 1 : 0) + (guess_exact ? 0 : 1) : 0;
         bool missed = false;
         for (bool speculative = speculated;;) {
             hipLaunchKernelGGL(k_tr_step, dim3(1), dim3(one_rank ? 1024 : 64), 0, h->stream, sc, Delta,
@@ -2303,7 +2297,7 @@ static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt
         pcg_hist_new.push_back(hc.iters);
         {
             const int rec = (iteration + 1 < (int64_t)h->pcg_hist.size()) ? h->pcg_hist[iteration + 1] : 0;
-            guess_exact = rec > 0 && pcg_bias == 0;
+            guess_exact = rec > 0 && pcg_bias == 0 && hist_same;
             pcg_guess = std::max(1, (guess_exact ? rec : h->pcg_hint) + pcg_bias);
         }
         reg_term = h->h_scal[kRegSlot];
@@ -2395,6 +2389,7 @@ static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt
         out->resjac_launches = (int64_t)evs.size();
     }
     h->pcg_hist.swap(pcg_hist_new);
+    h->hist_C = C; h->hist_P = P; h->hist_N = h->N;
     out->cost = cost;
     out->optimality = g_norm;
     out->rmse = std::sqrt(2.0 * cost / m_total);

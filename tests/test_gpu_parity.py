@@ -221,7 +221,7 @@ def dbg():
             touched.append((b, name))
     yield set_
     defaults = dict(pcg_fused=-1, tab_lds=-1, vec_lds=-1, cam_chunk=0, pcg_guess_bias=0, sweep_rc=-1, dense=-1, precond=-1, pcg_local=-1,
-                    pcg_step=-1)
+                    pcg_split=-1)
     for b, name in touched:
         b.debug_option(name, defaults[name])
 
@@ -405,16 +405,16 @@ def test_fused_pcg_launch_equals_sweep_plus_update(dbg):
             dbg((tls,), "sweep_rc", rc)
             runs = []
             # fused with the per-camera bookkeeping in pass B (default on one rank), fused with the whole update in
-            # pass A's prologue, two kernels, and the stepped form of the sharded solves (k_pcg_begin / k_pcg_step: the
+            # pass A's prologue, two kernels, and the stepped form of the sharded solves (k_pcg_begin / k_pcg_split: the
             # whole update once per iteration in one workgroup; here without ranks to reduce over) with the fused and
             # the plain pass A
             for fused, local, step in ((-1, -1, -1), (-1, 0, -1), (0, -1, -1), (-1, -1, 1), (0, -1, 1)):
                 dbg((tls,), "pcg_fused", fused)
                 dbg((tls,), "pcg_local", local)
-                dbg((tls,), "pcg_step", step)
+                dbg((tls,), "pcg_split", step)
                 runs.append(sfmba.least_squares(sfmba.compute_residuals, pb.x0, x_scale="jac", ftol=1e-10,
                                                 method="trf", args=pb.args))
-            dbg((tls,), "pcg_step", -1)
+            dbg((tls,), "pcg_split", -1)
             a = runs[0]
             for b in runs[1:]:
                 # the last trial step of a converged run changes the cost in its 13th digit: whether it counts as
@@ -446,8 +446,8 @@ def test_full_solves_with_many_cameras_vs_oracle(orc, dbg):
         r = sfmba.compute_residuals(res.x, *pb.args)
         assert np.abs(r - res.fun).max() < 1e-8
         if C == 1300:
-            for name in ("pcg_local", "sweep_rc", "pcg_step"):
-                dbg((tls,), name, 1 if name == "pcg_step" else 0)
+            for name in ("pcg_local", "sweep_rc", "pcg_split"):
+                dbg((tls,), name, 1 if name == "pcg_split" else 0)
                 alt = sfmba.least_squares(sfmba.compute_residuals, pb.x0, x_scale="jac", ftol=1e-10, method="trf",
                                           args=pb.args)
                 dbg((tls,), name, -1)
