@@ -77,6 +77,7 @@ __device__ __forceinline__ size_t jaddr(int64_t ld, int i, int m) {
 constexpr int kPcgVecs = 6;     // x r p s u (plane-major [k][C]) and u once more camera-major [C][6]
 constexpr int kPcgX = 0, kPcgR = 1, kPcgP = 2, kPcgS = 3, kPcgU = 4, kPcgUcm = 5;
 constexpr int kPcgUpdateBlocks = 8;
+constexpr int kPcgInitDeferred = 7;   // PcgCtrl::pad of a solve started by k_pcg_init_local: gamma_0 comes with the first update
 
 struct PcgCtrl {
     double rz;        // gamma_i = r^T M^-1 r of the current iterate
@@ -721,6 +722,35 @@ __device__ __forceinline__ void load_blocks(const ObsArrays& o, int i, double* j
         }
 }
 
+//
+// Mailbox: the hand-off of an outer iteration.  One wave copies the 32 exchange scalars and the PCG
+// control block into coherent host memory and raises a sequence number behind them; the host polls
+// that word instead of waiting on an event behind two blit copies.  mbox = [0..31] scalars,
+// [32..] control block, [63] sequence number.
+constexpr int kMboxCtrl = 32, kMboxErr = 62, kMboxSeq = 63;
+struct Mailbox {
+    double* __restrict__ host;            // device-visible address of the pinned block; null: no post
+    const double* __restrict__ sc;
+    const PcgCtrl* __restrict__ ctrl;
+    unsigned long long seq;
+    const unsigned* __restrict__ err;     // error word of the direct all-reduce (null: none): travels with every post,
+};                                        // so that a collective that timed out aborts the solve at the next hand-off
+static_assert(kMboxCtrl + (int)((sizeof(PcgCtrl) + 7) / 8) <= kMboxErr, "mailbox layout");
+
+__device__ __forceinline__ void post_mailbox(const Mailbox& mb) {     // one full wave
+    const int lane = threadIdx.x & 63;
+    if (lane < kMboxCtrl) mb.host[lane] = mb.sc[lane];
+    constexpr int nc = (int)((sizeof(PcgCtrl) + 7) / 8);
+    if (mb.ctrl != nullptr && lane >= kMboxCtrl && lane < kMboxCtrl + nc)
+        mb.host[lane] = reinterpret_cast<const double*>(mb.ctrl)[lane - kMboxCtrl];
+    if (lane == kMboxErr) mb.host[lane] = (mb.err != nullptr && *mb.err != 0u) ? 1.0 : 0.0;
+    __threadfence_system();                       // every lane's element is out before lane 0 raises the number
+    if (lane == 0)
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(mb.host + kMboxSeq), mb.seq, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+
 // ---------------------------------------------------------------------------------------------
 // Camera-major side.  Per-camera sums (U_c, g_c, the reduced right-hand side, the camera half of the
 // implicit Schur product) are NOT scattered from the point-major sweeps with atomics: set_problem builds,
@@ -769,14 +799,24 @@ __global__ __launch_bounds__(kCamThreads) void k_cam_blocks(CamMajor cm, const d
                                                             const double* __restrict__ rec, KMat K,
                                                             double* __restrict__ Ugc, double* __restrict__ partial,
                                                             const double* __restrict__ skip, int n_chunks,
-                                                            const int* __restrict__ pt_idx, int N, PointBlocksOut pb) {
+                                                            const int* __restrict__ pt_idx, int N, PointBlocksOut pb,
+                                                            Piggyback fin, Mailbox mb) {
     __shared__ double red[kCamWaves][27];
-    if (skip != nullptr && *skip != 0.0) return;   // speculative launch cancelled by k_tr_step
-    if ((int)blockIdx.x >= n_chunks) {             // riders: the point rows K1's tiles cut (see k_resjac)
-        point_edge_fixup(((int)blockIdx.x - n_chunks) * kCamThreads + (int)threadIdx.x, pt_idx, N, pb);
+    // One more rider (fin.part != null: the FIRST workgroup of the grid): the sum of the cost partials the residual
+    // launch in front of this one left, and the hand-off post behind it -- k_finish's work without its launch; the host
+    // has the trial cost while this launch is still building the blocks it speculates on.
+    const int bid = (int)blockIdx.x - (fin.part != nullptr ? 1 : 0);        // (the FIRST workgroup: dispatched at once)
+    if (bid < 0) {
+        if (!(skip != nullptr && *skip != 0.0)) { finish_in_block(fin); __syncthreads(); }
+        if (mb.host != nullptr && threadIdx.x < 64) post_mailbox(mb);      // (also when the trial was cancelled)
         return;
     }
-    const int4 ch = cm.chunks[blockIdx.x];
+    if (skip != nullptr && *skip != 0.0) return;   // speculative launch cancelled by k_tr_step
+    if (bid >= n_chunks) {                         // riders: the point rows K1's tiles cut (see k_resjac)
+        point_edge_fixup((bid - n_chunks) * kCamThreads + (int)threadIdx.x, pt_idx, N, pb);
+        return;
+    }
+    const int4 ch = cm.chunks[bid];
     double t[kCamTab];
 #pragma unroll
     for (int k = 0; k < kCamTab; ++k) t[k] = camtab[(size_t)ch.x * kCamRow + k];      // wave-uniform: scalar loads
@@ -821,7 +861,7 @@ __global__ __launch_bounds__(kCamThreads) void k_cam_blocks(CamMajor cm, const d
     const double s = cam_block_total<27>(a, red);
     if (threadIdx.x < 27) {
         if (ch.w == 1) Ugc[(size_t)ch.x * 27 + threadIdx.x] = s;
-        else partial[(size_t)blockIdx.x * 27 + threadIdx.x] = s;
+        else partial[(size_t)bid * 27 + threadIdx.x] = s;
     }
 }
 
@@ -941,34 +981,6 @@ __global__ __launch_bounds__(256) void k_update_scale(const double* __restrict__
     write_partials(q, part);
 }
 
-
-//
-// Mailbox: the hand-off of an outer iteration.  One wave copies the 32 exchange scalars and the PCG
-// control block into coherent host memory and raises a sequence number behind them; the host polls
-// that word instead of waiting on an event behind two blit copies.  mbox = [0..31] scalars,
-// [32..] control block, [63] sequence number.
-constexpr int kMboxCtrl = 32, kMboxErr = 62, kMboxSeq = 63;
-struct Mailbox {
-    double* __restrict__ host;            // device-visible address of the pinned block; null: no post
-    const double* __restrict__ sc;
-    const PcgCtrl* __restrict__ ctrl;
-    unsigned long long seq;
-    const unsigned* __restrict__ err;     // error word of the direct all-reduce (null: none): travels with every post,
-};                                        // so that a collective that timed out aborts the solve at the next hand-off
-static_assert(kMboxCtrl + (int)((sizeof(PcgCtrl) + 7) / 8) <= kMboxErr, "mailbox layout");
-
-__device__ __forceinline__ void post_mailbox(const Mailbox& mb) {     // one full wave
-    const int lane = threadIdx.x & 63;
-    if (lane < kMboxCtrl) mb.host[lane] = mb.sc[lane];
-    constexpr int nc = (int)((sizeof(PcgCtrl) + 7) / 8);
-    if (mb.ctrl != nullptr && lane >= kMboxCtrl && lane < kMboxCtrl + nc)
-        mb.host[lane] = reinterpret_cast<const double*>(mb.ctrl)[lane - kMboxCtrl];
-    if (lane == kMboxErr) mb.host[lane] = (mb.err != nullptr && *mb.err != 0u) ? 1.0 : 0.0;
-    __threadfence_system();
-    if (lane == 0)
-        __hip_atomic_store(reinterpret_cast<unsigned long long*>(mb.host + kMboxSeq), mb.seq, __ATOMIC_RELEASE,
-                           __HIP_MEMORY_SCOPE_SYSTEM);
-}
 
 __global__ void k_post(Mailbox mb) { post_mailbox(mb); }
 
@@ -1875,20 +1887,28 @@ __global__ __launch_bounds__(1024) void k_pcg_update_local(double* __restrict__ 
         for (int k = 0; k < 4; ++k) tot[k] += red4[w][k];
     }
     const double delta = tot[0], su = tot[1], sm = tot[2], gamma = tot[3];     // w.u, s.u, s.m, r.u (true gamma_i)
+    double rz0 = ci.rz0;
+    if (ci.iters == 0 && ci.pad == kPcgInitDeferred) {        // started by k_pcg_init_local: gamma_0 is found here
+        rz0 = gamma;
+        if (!(gamma > 0.0)) {                                 // zero right-hand side (x = 0 is the solution) / NaN
+            if (writer) { PcgCtrl co = ci; co.rz = gamma; co.rz0 = gamma; co.done = gamma == 0.0 ? 1 : 3; *cout = co; }
+            return;
+        }
+    }
     const double beta = ci.iters == 0 ? 0.0 : ci.rz / ci.rz_prev;             // the beta pass B built s and p with
     const double den = delta - (ci.iters == 0 ? 0.0 : beta * gamma / ci.alpha_prev);
     const double alpha = gamma / den;
     if (!(den > 0.0) || !isfinite(alpha)) {                    // S not SPD / NaN: x stays the last good iterate
-        if (writer) { PcgCtrl co = ci; co.done = 3; *cout = co; }
+        if (writer) { PcgCtrl co = ci; co.rz0 = rz0; co.done = 3; *cout = co; }
         return;
     }
     const double rz = gamma - 2.0 * alpha * su + alpha * alpha * sm;          // gamma_{i+1}
     int done = 0;
-    if (!(rz > ci.tol2 * ci.rz0)) done = 1;                   // also catches NaN and a cancelled-out (<= 0) value
+    if (!(rz > ci.tol2 * rz0)) done = 1;                      // also catches NaN and a cancelled-out (<= 0) value
     else if (ci.iters + 1 >= ci.max_iters) done = 2;
     if (writer) {
         PcgCtrl co = ci;
-        co.rz_prev = gamma; co.alpha_prev = alpha; co.rz = rz; co.iters = ci.iters + 1; co.done = done;
+        co.rz_prev = gamma; co.alpha_prev = alpha; co.rz = rz; co.rz0 = rz0; co.iters = ci.iters + 1; co.done = done;
         *cout = co;
     }
     const int cam = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2553,6 +2573,43 @@ __global__ __launch_bounds__(1024) void k_pcg_init(const double* __restrict__ Ug
     }
 }
 
+// The same start for the LOCAL form whose update is k_pcg_update_local (more than 1024 cameras), on as many workgroups as
+// the cameras need and without any reduction: that form takes gamma from the true r.u of the iterate every iteration,
+// so gamma_0 = rz0 is simply what its first update finds (ctrl.pad = kPcgInitDeferred says so).  The single-workgroup
+// k_pcg_init took 58 us at 5000 cameras -- a tenth of an outer iteration of an eighth-size shard.
+__global__ __launch_bounds__(64) void k_pcg_init_local(const double* __restrict__ Ugc, const double* __restrict__ acc,
+                                                       const double* __restrict__ Minv, int C, double* __restrict__ vecs,
+                                                       const double* __restrict__ tol_dev, int max_iters,
+                                                       PcgCtrl* __restrict__ ctrl2) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n6 = 6 * (size_t)C;
+    if (c < C) {
+        double rr[6], m[21];
+#pragma unroll
+        for (int n = 0; n < 21; ++n) m[n] = Minv[(size_t)n * C + c];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) rr[k] = -Ugc[(size_t)c * 27 + 21 + k] - acc[(size_t)k * C + c];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const size_t e = (size_t)k * C + c;
+            const double z = minv_row(m, rr, k);
+            vecs[kPcgX * n6 + e] = 0.0; vecs[(size_t)kPcgVecs * n6 + kPcgX * n6 + e] = 0.0;
+            vecs[kPcgP * n6 + e] = 0.0; vecs[kPcgS * n6 + e] = 0.0;
+            vecs[kPcgR * n6 + e] = rr[k];
+            vecs[kPcgU * n6 + e] = z;
+            vecs[kPcgUcm * n6 + 6 * (size_t)c + k] = z;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        PcgCtrl c0;
+        const double tol = *tol_dev;
+        c0.rz = 0.0; c0.rz0 = 0.0; c0.tol2 = tol * tol; c0.rz_prev = 1.0; c0.alpha_prev = 1.0;
+        c0.iters = 0; c0.max_iters = max_iters; c0.done = 0; c0.pad = kPcgInitDeferred;
+        ctrl2[0] = c0;
+        ctrl2[1] = c0;
+    }
+}
+
 // One PCG step after passes A and B of launch L produced acc = (S - Dc) u.  A finished solve turns every
 // later sweep/update into a no-op (done is copied forward), so the host may enqueue iterations without
 // reading back.
@@ -2843,6 +2900,11 @@ struct P2pArgs {
     const double* skip;                       // speculative trial cancelled: no collective, but still post
 };
 
+#ifdef SFMBA_P2P_NOFENCE      // experiment only: what the system-scope fences of the collectives cost
+#define P2P_FENCE() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#else
+#define P2P_FENCE() __threadfence_system()
+#endif
 // The collective itself, for the workgroups of one launch (any block size; slices by blockIdx).
 __device__ __forceinline__ void p2p_allreduce_body(double* __restrict__ vec, int count, int op, const P2pArgs& a) {
     __shared__ unsigned s_last;
@@ -2856,27 +2918,26 @@ __device__ __forceinline__ void p2p_allreduce_body(double* __restrict__ vec, int
         for (int e = lo + tid; e < hi; e += blockDim.x)
             __hip_atomic_store(dst + e, vec[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    __threadfence_system();
+    P2P_FENCE();
     __syncthreads();
     if (tid == 0) s_last = (atomicAdd(a.ticket, 1u) == gridDim.x - 1) ? 1u : 0u;
     __syncthreads();
-    if (s_last != 0u) {
-        __threadfence_system();
-        if (tid < a.world)
+    if (s_last != 0u) {                          // (every workgroup fenced its stores before its ticket; the flag's
+        if (tid < a.world)                       // release store is the last workgroup's own fence)
             __hip_atomic_store(a.flags[tid] + ((size_t)par * a.world + a.rank) * kP2pFlagStride, seq,
                                __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         if (tid == 0) { *a.ticket = 0u; *a.seq = seq; }
     }
-    if (tid < a.world) {
+    if (tid < a.world) {                         // relaxed polls; ONE acquire fence for all threads behind the barrier
         const unsigned long long* f = a.flags[a.rank] + ((size_t)par * a.world + tid) * kP2pFlagStride;
         const long long t0 = wall_clock64();
-        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
             if (wall_clock64() - t0 > a.timeout) { atomicExch(a.error, 1u); break; }
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(1);
         }
     }
     __syncthreads();
-    __threadfence_system();
+    P2P_FENCE();
     const double* slots = a.data[a.rank] + (size_t)par * a.world * a.stride;
     for (int e = lo + tid; e < hi; e += blockDim.x) {
         double s = __hip_atomic_load(slots + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -2989,12 +3050,11 @@ __global__ __launch_bounds__(kP2pPcgThreads) void k_p2p_pcg(double* __restrict__
                 __hip_atomic_store(dst + e, acc[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
-        __threadfence_system();
+        P2P_FENCE();
         __syncthreads();
         if (tid == 0) s_last = (atomicAdd(a.ticket, 1u) == gridDim.x - 1) ? 1u : 0u;
         __syncthreads();
         if (s_last != 0u) {
-            __threadfence_system();
             if (tid < a.world)
                 __hip_atomic_store(a.flags[tid] + ((size_t)par * a.world + a.rank) * kP2pFlagStride, seq,
                                    __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -3003,13 +3063,13 @@ __global__ __launch_bounds__(kP2pPcgThreads) void k_p2p_pcg(double* __restrict__
         if (tid < a.world) {
             const unsigned long long* f = a.flags[a.rank] + ((size_t)par * a.world + tid) * kP2pFlagStride;
             const long long t0 = wall_clock64();
-            while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+            while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
                 if (wall_clock64() - t0 > a.timeout) { atomicExch(a.error, 1u); break; }
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(1);
             }
         }
         __syncthreads();
-        __threadfence_system();
+        P2P_FENCE();
         const double* slots = a.data[a.rank] + (size_t)par * a.world * a.stride;
         for (int t = tid; t < 6 * n; t += blockDim.x) {
             const int k = t / n, e = k * C + lo + (t - k * n);
@@ -3022,6 +3082,16 @@ __global__ __launch_bounds__(kP2pPcgThreads) void k_p2p_pcg(double* __restrict__
     __syncthreads();                                          // this workgroup's entries of acc are final
     if (tid < n)
         pcg_tail_camera(lo + tid, C, acc, vin + (size_t)((set < 0 ? (cd.iters & 1) : set) * kPcgVecs + kPcgU) * 6 * C, pl, cd);
+}
+
+// Zero up to eight device arrays in one launch (set_problem's initialisations: seven hipMemsetAsync calls cost the host
+// more than the whole set-up of a SceauxCastle-scale problem).  Sizes in 16-byte units; blockIdx.y = array.
+struct ZeroJob { void* p[8]; int64_t n16[8]; };
+__global__ __launch_bounds__(256) void k_zero_many(ZeroJob z) {
+    double2* __restrict__ a = static_cast<double2*>(z.p[blockIdx.y]);
+    const int64_t n = z.n16[blockIdx.y];
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+        a[e] = make_double2(0.0, 0.0);
 }
 
 __global__ __launch_bounds__(1024) void k_fill16(double* __restrict__ a, int64_t n2, double v) {

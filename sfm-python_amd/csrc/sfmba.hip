@@ -82,6 +82,12 @@ struct DevBuf {
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
+// a piece of a larger device allocation (the structure tables of a problem share one buffer and one upload)
+struct DevView {
+    void* p = nullptr;
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
 // pinned host memory, grow-only, optionally keeping a prefix across a reallocation
 struct PinnedBuf {
     void* p = nullptr;
@@ -221,7 +227,9 @@ struct sfmba_handle {
     bool sweep_rc_g = false;                 // ... from a table in global memory (more cameras than the LDS holds)
     DevBuf rctab;                            // [C][18], k_rc_table
     bool dense = false;                      // reduced camera matrix formed and factorised (6 C <= kDenseMaxN) instead of PCG
-    DevBuf cov_ptr, cov_pt, blk_ab, Sblk;    // dense path: per block pair (a <= b) the points both cameras see
+    DevView cov_ptr, cov_pt, blk_ab;         // dense path: per block pair (a <= b) the points both cameras see
+    DevBuf Sblk;
+    DevBuf tables;                           // ranges | wsteps | steps | chunk table | chunk offsets | pair lists: ONE upload
     int n_blk = 0;
     // test / diagnostic hooks, set through sfmba_debug_option only (nothing reads the environment)
     struct Debug {
@@ -231,6 +239,7 @@ struct sfmba_handle {
         int dense = -1;                      // 0: PCG although the dense reduced-camera path would apply
         int precond = -1;                    // 0: block-Jacobi preconditioner from U + Dc instead of the Schur diagonal
         int pcg_local = -1;                  // 0: the fused PCG keeps its whole update in pass A's prologue
+        int cost_rider = -1;                 // 0: the trial cost is summed and posted by a k_finish launch of its own
         int pcg_split = -1;                  // 1: the local form with its tail in a kernel of its own (k_pcg_tail) on a
                                              // single rank too; 0: sharded / multi-chunk solves keep the round-2 forms
                                              // (whole update in every workgroup of pass A, or k_pcg_update)
@@ -242,10 +251,12 @@ struct sfmba_handle {
         int p2p_timeout_ms = 0;              // test: > 0 overrides both time-outs of the direct all-reduce
     } dbg;
 
-    DevBuf cam_idx, pt_idx, pt_ptr, uv, ranges, wsteps, steps;
+    DevBuf cam_idx, pt_idx, pt_ptr, uv;
+    DevView ranges, wsteps, steps;
     int n_steps = 0;
     // camera-major order of the same observations (structure only): per-camera sums without atomics
-    DevBuf cm_perm, cm_pt, cm_uv, cam_chunks, cam_chunk_ptr, cam_partial;
+    DevBuf cm_perm, cm_pt, cm_uv, cam_partial;
+    DevView cam_chunks, cam_chunk_ptr;
     int n_chunks = 0;
     bool cam_multi = false;                  // some camera has more than one chunk: k_cam_combine runs
     DevBuf xa, xb, tabA, tabB, r, J, t1;     // ONE Jacobian / residual buffer set
@@ -281,7 +292,7 @@ struct sfmba_handle {
     double* h_scal = nullptr;                // pinned
     // set_problem: converted arrays of the current problem in pinned memory (upload source, and what the next
     // call is compared with), host copies of the structure tables, worker threads
-    struct Stage { PinnedBuf uv, ci, pi, perm, ptr, uvf; } stage;
+    struct Stage { PinnedBuf uv, ci, pi, perm, ptr, uvf, tables; } stage;
     struct Prev { bool valid = false; bool f32 = false; int64_t N = 0, P = 0; } prev;
     std::vector<int2> host_ranges, host_wsteps, host_steps;
     std::vector<int4> host_chunks;
@@ -640,19 +651,30 @@ int launch_cam_combine(sfmba_handle* h, int ncols, double* out, int cs, int ks, 
 // K3 at (x, tab): [U_c | g_c] over the camera-major order, blocks recomputed from the camera table and the point
 // records.  V_p, g_p were left by the residual+Jacobian launch at the same x (launch_resjac with `blocks`), except
 // for the runs its 64-observation tiles cut: their pieces are added by a few extra workgroups of this launch.
+// `cost_parts` > 0: the launch also sums that many cost partials (left in `part` by the residual launch before it) into
+// scalar slot 0 and posts the hand-off `mb` (one more rider workgroup instead of a k_finish launch)
 template <bool F32>
-int launch_normal_blocks_v(sfmba_handle* h, const double* x, const double* tab, const double* rec) {
+int launch_normal_blocks_v(sfmba_handle* h, const double* x, const double* tab, const double* rec, int cost_parts,
+                           const Mailbox& mb) {
     (void)x;
     const int tiles = (int)((h->N + 63) / 64);
     const int riders = (tiles + kCamThreads - 1) / kCamThreads;
-    hipLaunchKernelGGL((k_cam_blocks<F32>), dim3(h->n_chunks + riders), dim3(kCamThreads), 0, h->stream, cam_major(h), tab,
-                       rec, h->K, h->Ugc(), h->cam_partial.as<double>(), h->skip, (int)h->n_chunks,
-                       (const int*)h->pt_idx.as<int>(), (int)h->N, point_blocks_out(h));
+    Piggyback fin{};
+    if (cost_parts > 0) {
+        fin = Piggyback{h->part.as<double>(), h->scal(), FinishJob{}, 1, 1, 0};
+        fin.job.row0[0] = 0; fin.job.nrows[0] = cost_parts;
+        for (int k = 0; k < kFinishCols; ++k) { fin.job.slot[0][k] = k; fin.job.slot[1][k] = -1; }
+    }
+    hipLaunchKernelGGL((k_cam_blocks<F32>), dim3(h->n_chunks + riders + (cost_parts > 0 ? 1 : 0)), dim3(kCamThreads), 0, h->stream,
+                       cam_major(h), tab, rec, h->K, h->Ugc(), h->cam_partial.as<double>(), h->skip, (int)h->n_chunks,
+                       (const int*)h->pt_idx.as<int>(), (int)h->N, point_blocks_out(h), fin, mb);
     LAUNCHED(h);
     return launch_cam_combine(h, 27, h->Ugc(), 27, 1, h->skip, nullptr);
 }
-int launch_normal_blocks(sfmba_handle* h, const double* x, const double* tab, const double* rec) {
-    return h->f32 ? launch_normal_blocks_v<true>(h, x, tab, rec) : launch_normal_blocks_v<false>(h, x, tab, rec);
+int launch_normal_blocks(sfmba_handle* h, const double* x, const double* tab, const double* rec, int cost_parts = 0,
+                         const Mailbox& mb = Mailbox{}) {
+    return h->f32 ? launch_normal_blocks_v<true>(h, x, tab, rec, cost_parts, mb)
+                  : launch_normal_blocks_v<false>(h, x, tab, rec, cost_parts, mb);
 }
 
 // Pass A of the implicit Schur product (z_p for every point).  Inside the two-kernel PCG: vin = base of the
@@ -994,9 +1016,14 @@ int pcg_start(sfmba_handle* h, const sfmba_options& opt) {
         h->pcg_cap = pcg_max_iters(h, opt);
         return 0;
     }
-    hipLaunchKernelGGL(k_pcg_init, dim3(1), dim3(1024), 0, h->stream, h->Ugc(), (const double*)h->acc(),
-                       h->Minv.as<double>(), (int)h->C, h->vecs.as<double>(), (const double*)(h->scal() + kEtaSlot),
-                       pcg_max_iters(h, opt), h->ctrl.as<PcgCtrl>());
+    if (h->pcg_local2)                    // its update takes gamma from the iterate: no reduction at the start
+        hipLaunchKernelGGL(k_pcg_init_local, dim3((unsigned)((h->C + 63) / 64)), dim3(64), 0, h->stream, (const double*)h->Ugc(),
+                           (const double*)h->acc(), (const double*)h->Minv.as<double>(), (int)h->C, h->vecs.as<double>(),
+                           (const double*)(h->scal() + kEtaSlot), pcg_max_iters(h, opt), h->ctrl.as<PcgCtrl>());
+    else
+        hipLaunchKernelGGL(k_pcg_init, dim3(1), dim3(1024), 0, h->stream, h->Ugc(), (const double*)h->acc(),
+                           h->Minv.as<double>(), (int)h->C, h->vecs.as<double>(), (const double*)(h->scal() + kEtaSlot),
+                           pcg_max_iters(h, opt), h->ctrl.as<PcgCtrl>());
     LAUNCHED(h);
     return 0;
 }
@@ -1198,6 +1225,7 @@ int sfmba_debug_option(sfmba_handle* h, const char* name, int64_t value) {
     else if (n == "precond") h->dbg.precond = v;
     else if (n == "pcg_local") h->dbg.pcg_local = v;
     else if (n == "pcg_split") h->dbg.pcg_split = v;
+    else if (n == "cost_rider") h->dbg.cost_rider = v;
     else if (n == "tab_lds") h->dbg.tab_lds = v;
     else if (n == "vec_lds") h->dbg.vec_lds = v;
     else if (n == "cam_chunk") h->dbg.cam_chunk = v;
@@ -1689,9 +1717,23 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     // (entries up to the point of the last unchanged observation are determined by unchanged positions alone)
     const int64_t p_keep = keep == 0 ? 0 : std::min<int64_t>(std::min<int64_t>(prev.P, P), (int64_t)pi[fdiff - 1] + 1);
     HIPCHK(h, h->pt_ptr.ensure_keep(sizeof(int) * ((size_t)P + 1), sizeof(int) * (size_t)p_keep));
-    HIPCHK(h, h->ranges.ensure(sizeof(int2) * std::max<size_t>(1, ranges.size())));
-    HIPCHK(h, h->wsteps.ensure(sizeof(int2) * std::max<size_t>(1, wsteps.size())));
-    HIPCHK(h, h->steps.ensure(sizeof(int2) * std::max<size_t>(1, steps.size())));
+    // the structure tables: one device buffer, one pinned staging buffer, one copy
+    struct Piece { const void* src; size_t bytes; DevView* view; size_t off; };
+    Piece pieces[8] = {
+        {ranges.data(), sizeof(int2) * ranges.size(), &h->ranges, 0}, {wsteps.data(), sizeof(int2) * wsteps.size(), &h->wsteps, 0},
+        {steps.data(), sizeof(int2) * steps.size(), &h->steps, 0}, {chunks.data(), sizeof(int4) * chunks.size(), &h->cam_chunks, 0},
+        {chunk_ptr.data(), sizeof(int) * chunk_ptr.size(), &h->cam_chunk_ptr, 0},
+        {cov_ptr.data(), h->dense ? sizeof(int) * cov_ptr.size() : 0, &h->cov_ptr, 0},
+        {cov_pt.data(), h->dense ? sizeof(int) * cov_pt.size() : 0, &h->cov_pt, 0},
+        {blk_ab.data(), h->dense ? sizeof(int2) * blk_ab.size() : 0, &h->blk_ab, 0}};
+    size_t tables_bytes = 0;
+    for (auto& pc : pieces) { pc.off = tables_bytes; tables_bytes += (pc.bytes + 255) / 256 * 256; }
+    HIPCHK(h, h->tables.ensure(tables_bytes + 256));
+    HIPCHK(h, sg.tables.ensure(tables_bytes + 256, 0));
+    for (auto& pc : pieces) {
+        if (pc.bytes) memcpy(sg.tables.as<char>() + pc.off, pc.src, pc.bytes);
+        pc.view->p = h->tables.as<char>() + pc.off;
+    }
     HIPCHK(h, h->xa.ensure(sizeof(double) * h->n));
     HIPCHK(h, h->xb.ensure(sizeof(double) * h->n));
     HIPCHK(h, h->tabA.ensure(sizeof(double) * cam_table_doubles((int)C)));
@@ -1701,28 +1743,23 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     HIPCHK(h, h->cm_perm.ensure(sizeof(int) * ldz));
     HIPCHK(h, h->cm_pt.ensure(sizeof(int) * ldz));
     HIPCHK(h, h->cm_uv.ensure(esz * 2 * ldz));
-    HIPCHK(h, h->cam_chunks.ensure(sizeof(int4) * chunks.size()));
-    HIPCHK(h, h->cam_chunk_ptr.ensure(sizeof(int) * chunk_ptr.size()));
     HIPCHK(h, h->cam_partial.ensure(sizeof(double) * 27 * chunks.size()));
     HIPCHK(h, h->recA.ensure(sizeof(double) * kRec * P));
     HIPCHK(h, h->recB.ensure(sizeof(double) * kRec * P));
     HIPCHK(h, h->rhsrec.ensure(sizeof(double) * kRhsRec * P));
     if (h->dense) {
-        HIPCHK(h, h->cov_ptr.ensure(sizeof(int) * cov_ptr.size()));
-        HIPCHK(h, h->cov_pt.ensure(sizeof(int) * cov_pt.size()));
-        HIPCHK(h, h->blk_ab.ensure(sizeof(int2) * blk_ab.size()));
         HIPCHK(h, h->Sblk.ensure(sizeof(double) * 36 * blk_ab.size()));
     }
     HIPCHK(h, h->t1.ensure(esz * 2 * ldz));
     HIPCHK(h, h->V.ensure(sizeof(double) * 6 * P));
     HIPCHK(h, h->Vinv.ensure(sizeof(double) * (kVinvInRec < 0 ? kVinvRow * P : 8)));
-    HIPCHK(h, h->gp.ensure(sizeof(double) * 3 * P));
+    HIPCHK(h, h->gp.ensure(sizeof(double) * 3 * P + 16));      // (+16: zeroed in 16-byte units)
     HIPCHK(h, h->edge.ensure(sizeof(double) * 2 * kEdgeRow * (size_t)((N + 63) / 64)));
     HIPCHK(h, h->e.ensure(sizeof(double) * 3 * P));
     HIPCHK(h, h->g.ensure(sizeof(double) * h->n));
     HIPCHK(h, h->si.ensure(sizeof(double) * h->n));
     HIPCHK(h, h->sg.ensure(sizeof(double) * h->n));
-    HIPCHK(h, h->p.ensure(sizeof(double) * h->n));
+    HIPCHK(h, h->p.ensure(sizeof(double) * h->n + 16));
     HIPCHK(h, h->Dc.ensure(sizeof(double) * 6 * C));
     HIPCHK(h, h->Minv.ensure(sizeof(double) * 21 * C));
     HIPCHK(h, h->vecs.ensure(sizeof(double) * 2 * kPcgVecs * 6 * C));
@@ -1753,27 +1790,24 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     HIPCHK(h, up(h->pt_ptr.p, ptr, sizeof(int), (size_t)p_keep, (size_t)P + 1));
     h->obs_reused = fdiff;
     h->obs_uploaded = ld - fdiff;
-    if (!ranges.empty()) {
-        HIPCHK(h, hipMemcpyAsync(h->ranges.p, ranges.data(), sizeof(int2) * ranges.size(), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipMemcpyAsync(h->wsteps.p, wsteps.data(), sizeof(int2) * wsteps.size(), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipMemcpyAsync(h->steps.p, steps.data(), sizeof(int2) * steps.size(), hipMemcpyHostToDevice, h->stream));
-    }
-    HIPCHK(h, hipMemsetAsync(h->arena, 0, sizeof(double) * (size_t)sfmba_exchange_doubles(C), h->stream));
-    // points without observations are never written by the normal-block kernel: their blocks must be 0
-    HIPCHK(h, hipMemsetAsync(h->V.p, 0, sizeof(double) * 6 * P, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->gp.p, 0, sizeof(double) * 3 * P, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->p.p, 0, sizeof(double) * h->n, h->stream));      // ... and their step is 0
-    HIPCHK(h, hipMemsetAsync(h->r.p, 0, esz * 2 * ldz, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->recA.p, 0, sizeof(double) * kRec * P, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->recB.p, 0, sizeof(double) * kRec * P, h->stream));
-    if (h->dense) {      // pageable sources: these copies are synchronous, the vectors may go out of scope afterwards
-        HIPCHK(h, hipMemcpyAsync(h->cov_ptr.p, cov_ptr.data(), sizeof(int) * cov_ptr.size(), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipMemcpyAsync(h->cov_pt.p, cov_pt.data(), sizeof(int) * cov_pt.size(), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipMemcpyAsync(h->blk_ab.p, blk_ab.data(), sizeof(int2) * blk_ab.size(), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->tables.p, sg.tables.p, tables_bytes, hipMemcpyHostToDevice, h->stream));
+    {   // every zero-initialised array in ONE launch: the exchange arena; V, g_p (points without observations are never
+        // written by the normal-block kernels: their blocks must be 0) and p (... and their step is 0); r; the point records
+        ZeroJob z{};
+        auto put = [&](int k, void* ptr_, size_t bytes) { z.p[k] = ptr_; z.n16[k] = (int64_t)(bytes / 16); };
+        put(0, h->arena, sizeof(double) * (size_t)sfmba_exchange_doubles(C));
+        put(1, h->V.p, sizeof(double) * 6 * P);
+        put(2, h->gp.p, (sizeof(double) * 3 * P + 15) / 16 * 16);
+        put(3, h->p.p, (sizeof(double) * h->n + 15) / 16 * 16);
+        put(4, h->r.p, esz * 2 * ldz);
+        put(5, h->recA.p, sizeof(double) * kRec * P);
+        put(6, h->recB.p, sizeof(double) * kRec * P);
+        int64_t most = 0;
+        for (int k = 0; k < 7; ++k) most = std::max(most, z.n16[k]);
+        hipLaunchKernelGGL(k_zero_many, dim3((unsigned)grid_1d(most, 256 * 4, 2048), 7), dim3(256), 0, h->stream, z);
+        LAUNCHED(h);
     }
     HIPCHK(h, hipMemcpyAsync(h->cm_perm.p, perm, sizeof(int) * ldz, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->cam_chunks.p, chunks.data(), sizeof(int4) * chunks.size(), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->cam_chunk_ptr.p, chunk_ptr.data(), sizeof(int) * chunk_ptr.size(), hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(k_build_cam_major, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, h->stream, h->cm_perm.as<int>(),
                        h->pt_idx.as<int>(), h->uv.as<double>(), f32 ? 1 : 0, (int)N, h->cm_pt.as<int>(),
                        h->cm_uv.as<double>());
@@ -2194,6 +2228,8 @@ static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt
         };
         CHK(tail(true));
 
+        Mailbox trial_post{};
+        bool trial_post_pending = false;
         // ---- the first trial step is decided ON THE DEVICE (k_tr_step) and evaluated right away -------
         // so that an outer iteration hands control to the host ONCE, after the trial cost is known.
         auto enqueue_trial = [&](const double* coef_dev, double c1, double c2) -> int {
@@ -2219,15 +2255,24 @@ static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt
                 ++h->n_collectives;
                 return 0;
             }
-            if (!ranks) h->post = mb;
-            const int rc = eval_jac(h->x_new, h->tab_new, true);
-            h->post = Mailbox{};
-            CHK(rc);
-            CHK(exchange(h, sc, 1, 0));
-            if (ranks) {
-                hipLaunchKernelGGL(k_post, dim3(1), dim3(64), 0, h->stream, mb);
-                LAUNCHED(h);
+            if (!ranks && h->dbg.cost_rider == 0) {
+                h->post = mb;
+                const int rc = eval_jac(h->x_new, h->tab_new, true);
+                h->post = Mailbox{};
+                return rc;
             }
+            if (!ranks) {
+                // single rank: the cost sum and the post ride with the launch that builds the trial point's blocks
+                // (handoff below), one launch less per iteration
+                CHK(eval_jac(h->x_new, h->tab_new, true, /*finish=*/false));
+                trial_post = mb;
+                trial_post_pending = true;
+                return 0;
+            }
+            CHK(eval_jac(h->x_new, h->tab_new, true));
+            CHK(exchange(h, sc, 1, 0));
+            hipLaunchKernelGGL(k_post, dim3(1), dim3(64), 0, h->stream, mb);
+            LAUNCHED(h);
             return 0;
         };
         auto handoff = [&](bool with_ctrl) -> int {
@@ -2235,7 +2280,9 @@ static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt
             // (speculating on acceptance, the common case).  They overwrite V / g_p / [U|g_c], which a
             // rejected step does not need: a retry only re-solves the 2-D model (host scalars) and
             // re-applies k_step_table to x, D^2 g and p, all untouched.
-            CHK(launch_normal_blocks(h, h->x_new, h->tab_new, h->rec_new));
+            if (trial_post_pending) CHK(launch_normal_blocks(h, h->x_new, h->tab_new, h->rec_new, np_cost, trial_post));
+            else CHK(launch_normal_blocks(h, h->x_new, h->tab_new, h->rec_new));
+            trial_post_pending = false;
             CHK(exchange(h, h->Ugc(), 27 * C, 0));
             nb_valid = false;
             CHK(wait_mailbox(h, h->mbox_seq));

@@ -629,7 +629,7 @@ def test_exchange_path_world1_nccl(dbg):
     from sfmba import dist as sdist
     pb = sfmba.make_problem(11, 3000, 10000, seed=0)
     dbg((sfmba.get_backend(0),), "dense", 0)       # with a transport registered the solver takes the PCG path
-    dbg((sfmba.get_backend(0),), "pcg_local", 0)   # ... with the whole update in pass A's prologue: bitwise comparable
+    dbg((sfmba.get_backend(0),), "pcg_split", 1)   # ... in the form sharded solves run (tail behind the reduction): bitwise comparable
     ref = sfmba.least_squares(sfmba.compute_residuals, pb.x0, x_scale="jac", ftol=1e-10, method="trf",
                               args=pb.args)
     with socket.socket() as s:
@@ -676,7 +676,7 @@ def test_exchange_path_world1_nccl(dbg):
         be2.set_problem(*pb.args)
         be2.set_exchange(0, 0, None, 0)                              # acknowledged: single-rank
         be2.debug_option("dense", 0)                                 # (the forms `ref` was computed with)
-        be2.debug_option("pcg_local", 0)
+        be2.debug_option("pcg_split", 1)
         be2.set_problem(*pb.args)
         assert np.array_equal(be2.solve(pb.x0, opt)[0], ref.x)
         be2.comm_destroy()
@@ -795,7 +795,7 @@ def test_two_rank_solve_on_one_gpu_gloo(dbg):
     rec = json.load(open(os.path.join(GOLDEN, "scipy_cfg2_run.json")))
     pb = sfmba.make_problem(11, 3000, 10000, seed=0)
     dbg((sfmba.get_backend(0),), "dense", 0)       # with a transport registered the solver takes the PCG path
-    dbg((sfmba.get_backend(0),), "pcg_local", 0)   # ... with the whole update in pass A's prologue: bitwise comparable
+    dbg((sfmba.get_backend(0),), "pcg_split", 1)   # ... in the form sharded solves run
     ref = sfmba.least_squares(sfmba.compute_residuals, pb.x0, x_scale="jac", ftol=1e-10, method="trf",
                               args=pb.args)
     with socket.socket() as s:

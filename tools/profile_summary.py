@@ -2,6 +2,7 @@
 
     python tools/profile_summary.py stats  <rocprof_dir> <out.md>     # --kernel-trace --stats run
     python tools/profile_summary.py pmc    <fetch_dir> <write_dir> <out.json> <workload>
+    python tools/profile_summary.py counters <out.json> <label> <dir> [<dir> ...]   # any --pmc passes: per-kernel averages
 """
 import csv, glob, json, sys, collections
 
@@ -64,8 +65,29 @@ def pmc(dfetch, dwrite, out, workload):
     print(json.dumps({k: summary[k] for k in summary if k != "kernels"}, indent=1))
 
 
+def counters(out, label, dirs):
+    """Per-kernel average of every counter found in the given --pmc output directories (one pass each), over the
+    launches that did work (a launch whose value is below half the kernel's maximum is a device-cancelled one)."""
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for d in dirs:
+        for r in csv.DictReader(open(find(d, "counter_collection.csv"))):
+            acc[r["Kernel_Name"][:100]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    res = {}
+    for k, cs in acc.items():
+        if not k.startswith(("void sfmba", "sfmba")):
+            continue
+        res[k] = {}
+        for c, v in cs.items():
+            real = [t for t in v if t >= 0.5 * max(v)] or [0.0]
+            res[k][c] = dict(avg=sum(real) / len(real), launches=len(real))
+    json.dump(dict(label=label, note="per-launch averages over launches that did work", kernels=res), open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1)[:3000])
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "counters":
+        counters(sys.argv[2], sys.argv[3], sys.argv[4:])
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5])

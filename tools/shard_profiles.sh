@@ -21,7 +21,7 @@ for W in cfg4 cfg5; do
   rm -rf $OUT/${TAG}_shard8_${W}
   for f in local sharded; do python3 - <<PY
 import json
-d=json.load(open("$OUT/${TAG}_shard8_${W}_$f.json"))
+d=json.loads(open("$OUT/${TAG}_shard8_${W}_$f.json").read().strip().split("\n")[-1])   # (RCCL prints a banner first)
 print("$W $f", round(d["value"],1), "it/s", round(1e3*d["ms_per_step"],1), "us/iteration", "launches", d["launches_per_iteration"], "collectives", d["collectives_per_iteration"], d.get("transport"))
 PY
   done

@@ -13,6 +13,9 @@ else:
     pb = sfmba.make_config(cfg)
 be = sfmba.Backend(0)
 be.set_precision(bits)
+for kv in os.environ.get("SFMBA_DEBUG", "").split(","):      # e.g. SFMBA_DEBUG=cost_rider=0,pcg_split=1 (tool-level, not the library)
+    if "=" in kv:
+        be.debug_option(kv.split("=")[0], int(kv.split("=")[1]))
 be.set_problem(*pb.args)
 opt = be.default_options()
 opt.ftol = 1e-10
