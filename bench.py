@@ -215,6 +215,9 @@ def main():
     with torch.cuda.stream(stream):
         be.set_stream(stream.cuda_stream)
         be.set_precision(a.storage_bits)
+        for kv in os.environ.get("SFMBA_DEBUG", "").split(","):      # A/B of solver forms (tool-level; the library reads no environment)
+            if "=" in kv:
+                be.debug_option(kv.split("=")[0], int(kv.split("=")[1]))
         be.set_problem(*pb.args)
         ex = None
         if td is not None:

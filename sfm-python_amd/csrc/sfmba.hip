@@ -239,6 +239,7 @@ struct sfmba_handle {
         int dense = -1;                      // 0: PCG although the dense reduced-camera path would apply
         int precond = -1;                    // 0: block-Jacobi preconditioner from U + Dc instead of the Schur diagonal
         int pcg_local = -1;                  // 0: the fused PCG keeps its whole update in pass A's prologue
+        int rhsrec = -1;                     // 1 / 0: the rhs + preconditioner pass gathers its own 128-byte records whatever the size
         int cost_rider = -1;                 // 0: the trial cost is summed and posted by a k_finish launch of its own
         int pcg_split = -1;                  // 1: the local form with its tail in a kernel of its own (k_pcg_tail) on a
                                              // single rank too; 0: sharded / multi-chunk solves keep the round-2 forms
@@ -319,6 +320,7 @@ struct sfmba_handle {
                                           // call (sfm.py:59-71), and the counts repeat; with a record the speculative
                                           // batch is that count (+1 launch for the fused update), without the spare
     int64_t hist_C = 0, hist_P = 0, hist_N = 0;   // the problem pcg_hist was recorded on
+    bool use_rhsrec = false;                 // the rhs + preconditioner pass gathers its own 128-byte records (many points)
     bool solved = false;
     bool transport_dropped = false;          // sfmba_set_problem tore down an active transport: the next compute call
                                              // fails until one is set up again (or single-rank use is acknowledged)
@@ -791,11 +793,11 @@ int launch_rhs_and_preconditioner(sfmba_handle* h) {
     if (h->f32 && !h->sweep_rc && !h->sweep_rc_g)
         hipLaunchKernelGGL((k_cam_rhs_diag<true>), dim3(h->n_chunks), dim3(kRhsThreads), 0, h->stream, cam_major(h),
                            (const double*)h->tab, (const double*)h->rec, (const double*)vinv_ptr(h), h->K, (int)C,
-                           h->acc(), h->cam_partial.as<double>(), mp, (const double*)h->rhsrec.as<double>());
+                           h->acc(), h->cam_partial.as<double>(), mp, h->use_rhsrec ? (const double*)h->rhsrec.as<double>() : (const double*)nullptr);
     else
         hipLaunchKernelGGL((k_cam_rhs_diag<false>), dim3(h->n_chunks), dim3(kRhsThreads), 0, h->stream, cam_major(h),
                            (const double*)h->tab, (const double*)h->rec, (const double*)vinv_ptr(h), h->K, (int)C,
-                           h->acc(), h->cam_partial.as<double>(), mp, (const double*)h->rhsrec.as<double>());
+                           h->acc(), h->cam_partial.as<double>(), mp, h->use_rhsrec ? (const double*)h->rhsrec.as<double>() : (const double*)nullptr);
     LAUNCHED(h);
     if (own_inverse) return 0;
     CHK(launch_cam_combine(h, 27, h->acc(), 1, (int)C, nullptr, nullptr));
@@ -1226,6 +1228,7 @@ int sfmba_debug_option(sfmba_handle* h, const char* name, int64_t value) {
     else if (n == "pcg_local") h->dbg.pcg_local = v;
     else if (n == "pcg_split") h->dbg.pcg_split = v;
     else if (n == "cost_rider") h->dbg.cost_rider = v;
+    else if (n == "rhsrec") h->dbg.rhsrec = v;
     else if (n == "tab_lds") h->dbg.tab_lds = v;
     else if (n == "vec_lds") h->dbg.vec_lds = v;
     else if (n == "cam_chunk") h->dbg.cam_chunk = v;
@@ -1746,7 +1749,11 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     HIPCHK(h, h->cam_partial.ensure(sizeof(double) * 27 * chunks.size()));
     HIPCHK(h, h->recA.ensure(sizeof(double) * kRec * P));
     HIPCHK(h, h->recB.ensure(sizeof(double) * kRec * P));
-    HIPCHK(h, h->rhsrec.ensure(sizeof(double) * kRhsRec * P));
+    // One 128-byte gather record per point for k_cam_rhs_diag pays once the point tables no longer sit in the L2s
+    // (1M points: 432 -> 188 us); at 100k points the two 4.8 MB tables it replaces are L2-resident and k_prep's 11 MB of
+    // extra writes cost what the pass gains
+    h->use_rhsrec = h->dbg.rhsrec == 1 || (h->dbg.rhsrec != 0 && P >= 250000);
+    if (h->use_rhsrec) HIPCHK(h, h->rhsrec.ensure(sizeof(double) * kRhsRec * P));
     if (h->dense) {
         HIPCHK(h, h->Sblk.ensure(sizeof(double) * 36 * blk_ab.size()));
     }
@@ -1766,8 +1773,12 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     HIPCHK(h, h->vtmp.ensure(sizeof(double) * 6 * C));
     HIPCHK(h, h->vcm.ensure(sizeof(double) * 6 * C));
     if (h->sweep_rc_g) HIPCHK(h, h->rctab.ensure(sizeof(double) * kRcRow * (size_t)C));
-    h->red_bc = grid_1d(6 * C, 256, 32);
-    h->red_grid = h->red_bc + grid_1d(3 * P, 256, 992);   // <= 1024 partial rows, summed by k_jdot's rider workgroup
+    // k_update_scale: a few elements per thread, so that the nine block reductions behind the loop are paid by 256
+    // workgroups instead of 1024 (8.8 -> ~5 us at 306k parameters)
+    // (small problems keep one element per thread: there the launch is latency, not reductions)
+    const int ept = 3 * P > 150000 ? 5 : 1;
+    h->red_bc = grid_1d(6 * C, 256 * (ept > 1 ? 4 : 1), 32);
+    h->red_grid = h->red_bc + grid_1d(3 * P, 256 * ept, 992);   // <= 1024 partial rows, summed by k_jdot's rider workgroup
     HIPCHK(h, h->part.ensure(sizeof(double) * (size_t)(2 * kPartRows * kNQ)));
     HIPCHK(h, h->ctrl.ensure(2 * sizeof(PcgCtrl)));
     HIPCHK(h, h->pcg_part.ensure(sizeof(double) * 4 * C));
@@ -1983,7 +1994,8 @@ int sfmba_time_kernel(sfmba_handle* h, const double* x, int32_t which, int32_t r
         CHK(launch_update_scale(h, 1));
         hipLaunchKernelGGL(k_point_prep, dim3((h->P + 255) / 256), dim3(256), 0, h->stream, h->V.as<double>(),
                            h->gp.as<double>(), h->si.as<double>() + 6 * h->C, (const double*)nullptr, (int)h->P,
-                           1e-6, vinv_ptr(h), h->rec + 3, (const double*)(h->x + 6 * h->C), h->rhsrec.as<double>());
+                           1e-6, vinv_ptr(h), h->rec + 3, (const double*)(h->x + 6 * h->C),
+                           h->use_rhsrec ? h->rhsrec.as<double>() : (double*)nullptr);
         LAUNCHED(h);
         // v = the camera slice of the gradient, as plane-major planes (and camera-major when v is not staged in LDS)
         hipLaunchKernelGGL(k_transpose, dim3((unsigned)((6 * h->C + 255) / 256)), dim3(256), 0, h->stream,
@@ -2013,7 +2025,7 @@ int sfmba_time_kernel(sfmba_handle* h, const double* x, int32_t which, int32_t r
                 hipLaunchKernelGGL((k_cam_rhs_diag<false>), dim3(h->n_chunks), dim3(kRhsThreads), 0, h->stream, cam_major(h),
                                    (const double*)h->tab, (const double*)h->rec, (const double*)vinv_ptr(h), h->K, (int)h->C,
                                    h->acc(), h->cam_partial.as<double>(), RhsPrecond{nullptr, nullptr, nullptr},
-                                   (const double*)h->rhsrec.as<double>());
+                                   h->use_rhsrec ? (const double*)h->rhsrec.as<double>() : (const double*)nullptr);
                 LAUNCHED(h);
                 break;
             case 10:   // streaming-store ceiling: fill the Jacobian planes, 16 B per lane, one stream
@@ -2191,7 +2203,7 @@ static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt
                                vinv_ptr(h), h->rec + 3,
                                one_rank ? (const double*)h->partB() : (const double*)nullptr, np, opt.pcg_tol,
                                std::max(opt.pcg_tol, opt.pcg_tol_max), (const double*)(h->x + 6 * C),
-                               (h->dense && one_rank) ? (double*)nullptr : h->rhsrec.as<double>());   // (read by k_cam_rhs_diag only)
+                               (h->use_rhsrec && !(h->dense && one_rank)) ? h->rhsrec.as<double>() : (double*)nullptr);   // (read by k_cam_rhs_diag only)
             LAUNCHED(h);
         }
         const bool dense = h->dense && one_rank;               // (sharded: the block pairs would need their own all-reduce)

@@ -221,7 +221,7 @@ def dbg():
             touched.append((b, name))
     yield set_
     defaults = dict(pcg_fused=-1, tab_lds=-1, vec_lds=-1, cam_chunk=0, pcg_guess_bias=0, sweep_rc=-1, dense=-1, precond=-1, pcg_local=-1,
-                    pcg_split=-1)
+                    pcg_split=-1, rhsrec=-1, cost_rider=-1)
     for b, name in touched:
         b.debug_option(name, defaults[name])
 
@@ -235,9 +235,11 @@ def test_operand_placements_and_camera_chunking(be, orc, dbg):
     pb = sfmba.make_problem(40, 400, 5000, seed=3)
     tls = sfmba.get_backend(0)
     ref = None
-    for tab_lds, vec_lds, chunk, rc in ((-1, -1, 0, -1), (-1, -1, 0, 0), (0, -1, 0, 0), (-1, 0, 0, 0), (-1, -1, 64, -1),
-                                        (0, 0, 50, 0)):
-        for name, v in (("tab_lds", tab_lds), ("vec_lds", vec_lds), ("cam_chunk", chunk), ("sweep_rc", rc)):
+    # (rhsrec: the rhs + preconditioner pass gathering one 128-byte record per observation instead of the point record
+    # and the inverse block -- the form problems of >= 250k points run; tab_lds = 0: camera rows through LDS-DMA slabs)
+    for tab_lds, vec_lds, chunk, rc, rr in ((-1, -1, 0, -1, -1), (-1, -1, 0, 0, -1), (0, -1, 0, 0, 1), (-1, 0, 0, 0, -1),
+                                            (-1, -1, 64, -1, 1), (0, 0, 50, 0, -1), (-1, -1, 0, -1, 1)):
+        for name, v in (("tab_lds", tab_lds), ("vec_lds", vec_lds), ("cam_chunk", chunk), ("sweep_rc", rc), ("rhsrec", rr)):
             dbg((be, tls), name, v)
         nb = _blocks_case(be, orc, pb)
         y = _matvec_case(be, orc, pb, nb)
