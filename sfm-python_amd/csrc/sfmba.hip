@@ -1463,7 +1463,7 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     CHK(enter(h));
     const bool timing = h->dbg.trace_timing != 0;
     const double tp0 = now_s();
-    double tp1 = tp0, tp2 = tp0, tp3 = tp0;
+    double tp1 = tp0, tp2 = tp0, tp3 = tp0, ts1 = tp0, ts2 = tp0, ts3 = tp0;
     h->have_problem = false;
     h->solved = false;
     if (C <= 0 || P <= 0 || N <= 0) return fail(h, -1, "n_cameras, n_points, n_obs must be positive");
@@ -1597,6 +1597,7 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
         }
     });
     for (int64_t q = (int64_t)pi[N - 1] + 1; q <= P; ++q) ptr[q] = (int)N;
+    ts1 = now_s();
     for (size_t k = (size_t)N; k < ldz; ++k) perm[k] = 0;
 
     for (int k = 0; k < 9; ++k) h->K.k[k] = K[k];
@@ -1620,33 +1621,56 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
         }
     }
     h->n_ranges = (int)ranges.size();
+    ts2 = now_s();
     // step table of the sweeps: per wave range, batches of <= 64 observations that end on a point
     // boundary; a point with more than 64 observations is one step of its own
     std::vector<int2>& wsteps = h->host_wsteps;
     std::vector<int2>& steps = h->host_steps;
     wsteps.resize(ranges.size());
     steps.clear();
-    for (size_t w = 0; w < ranges.size(); ++w) {
-        const int first = (int)steps.size();
-        int64_t pos = ranges[w].x;
-        const int64_t end = ranges[w].y;
-        while (pos < end) {
-            const int64_t pfirst = pi[pos];
-            if (ptr[pfirst + 1] - pos > 64) {                    // long run (pos is always a run start)
-                steps.push_back(make_int2((int)pos, (int)(ptr[pfirst + 1] - pos)));
-                pos = ptr[pfirst + 1];
-                continue;
+    {   // the ranges are independent: every worker walks a slice of them into its own list (the walk is a chain of
+        // dependent reads of pi / ptr -- 1.2-1.4 ms of a 3.6 ms call at 1M observations when one thread did all of it),
+        // the lists are concatenated in range order afterwards
+        const int sparts = (int)std::max<size_t>(1, std::min<size_t>((size_t)parts, ranges.size() / 64));
+        std::vector<std::vector<int2>> local((size_t)sparts);
+        const size_t rper = (ranges.size() + (size_t)sparts - 1) / (size_t)sparts;
+        h->pool.run(sparts, [&](int t) {
+            std::vector<int2>& out = local[(size_t)t];
+            const size_t w0 = std::min(ranges.size(), (size_t)t * rper), w1 = std::min(ranges.size(), w0 + rper);
+            out.reserve((w1 - w0) * 6);
+            for (size_t w = w0; w < w1; ++w) {
+                const int first = (int)out.size();                       // (relative to the slice; rebased below)
+                int64_t pos = ranges[w].x;
+                const int64_t end = ranges[w].y;
+                while (pos < end) {
+                    const int64_t pfirst = pi[pos];
+                    if (ptr[pfirst + 1] - pos > 64) {                    // long run (pos is always a run start)
+                        out.push_back(make_int2((int)pos, (int)(ptr[pfirst + 1] - pos)));
+                        pos = ptr[pfirst + 1];
+                        continue;
+                    }
+                    // largest run boundary <= pos + 64
+                    int64_t lim = std::min<int64_t>(pos + 64, end), cut;
+                    if (lim == end) cut = end;
+                    else { const int64_t pl = pi[lim]; cut = (ptr[pl] == lim) ? lim : ptr[pl]; }   // lim inside a run -> its start
+                    out.push_back(make_int2((int)pos, (int)(cut - pos)));
+                    pos = cut;
+                }
+                wsteps[w] = make_int2(first, (int)out.size() - first);
             }
-            // largest run boundary <= pos + 64
-            int64_t lim = std::min<int64_t>(pos + 64, end), cut;
-            if (lim == end) cut = end;
-            else { const int64_t pl = pi[lim]; cut = (ptr[pl] == lim) ? lim : ptr[pl]; }   // lim inside a run -> its start
-            steps.push_back(make_int2((int)pos, (int)(cut - pos)));
-            pos = cut;
+        });
+        size_t total = 0;
+        for (auto& v : local) total += v.size();
+        steps.reserve(total);
+        for (int t = 0; t < sparts; ++t) {
+            const int base = (int)steps.size();
+            const size_t w0 = std::min(ranges.size(), (size_t)t * rper), w1 = std::min(ranges.size(), w0 + rper);
+            for (size_t w = w0; w < w1; ++w) wsteps[w].x += base;
+            steps.insert(steps.end(), local[(size_t)t].begin(), local[(size_t)t].end());
         }
-        wsteps[w] = make_int2(first, (int)steps.size() - first);
     }
     h->n_steps = (int)steps.size();
+    ts3 = now_s();
     // chunk table of the camera-major kernels: every camera gets at least one chunk (an empty one writes its
     // zeros), runs longer than chunk_len are cut; one 256-thread workgroup per chunk
     std::vector<int4>& chunks = h->host_chunks;
@@ -1680,10 +1704,16 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
         const int nblk = (int)(C * (C + 1) / 2);
         cov_ptr.assign((size_t)nblk + 1, 0);
         int64_t total = 0;
+        // (unordered pairs i <= j: a pair of different cameras is one entry of its block, two observations of the same
+        // camera by the same point are two, an observation with itself one -- what the ordered double loop counted)
         for (int64_t p = 0; p < P && total <= ((int64_t)1 << 26); ++p)
             for (int i = ptr[p]; i < ptr[p + 1]; ++i)
-                for (int j = ptr[p]; j < ptr[p + 1]; ++j)
-                    if (ci[i] <= ci[j]) { ++cov_ptr[(size_t)dense_block_index(ci[i], ci[j], (int)C) + 1]; ++total; }
+                for (int j = i; j < ptr[p + 1]; ++j) {
+                    const int a = std::min(ci[i], ci[j]), b = std::max(ci[i], ci[j]);
+                    const int n_e = (i == j || a != b) ? 1 : 2;
+                    cov_ptr[(size_t)dense_block_index(a, b, (int)C) + 1] += n_e;
+                    total += n_e;
+                }
         if (total > ((int64_t)1 << 26)) h->dense = false;      // very long tracks: the pair lists would not pay
         else {
             for (int b = 0; b < nblk; ++b) cov_ptr[(size_t)b + 1] += cov_ptr[b];
@@ -1691,9 +1721,12 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
             std::vector<int> fill(cov_ptr.begin(), cov_ptr.end() - 1);
             for (int64_t p = 0; p < P; ++p)
                 for (int i = ptr[p]; i < ptr[p + 1]; ++i)
-                    for (int j = ptr[p]; j < ptr[p + 1]; ++j)
-                        if (ci[i] <= ci[j])           // an observation paired with itself is marked (~p): the term of
-                            cov_pt[(size_t)fill[dense_block_index(ci[i], ci[j], (int)C)]++] = i == j ? ~(int)p : (int)p;   // the right-hand side
+                    for (int j = i; j < ptr[p + 1]; ++j) {
+                        const int a = std::min(ci[i], ci[j]), b = std::max(ci[i], ci[j]);
+                        int& f = fill[(size_t)dense_block_index(a, b, (int)C)];
+                        cov_pt[(size_t)f++] = i == j ? ~(int)p : (int)p;           // (~p: the term of the right-hand side)
+                        if (i != j && a == b) cov_pt[(size_t)f++] = (int)p;
+                    }
             blk_ab.resize((size_t)nblk);
             for (int a = 0; a < (int)C; ++a)
                 for (int b = a; b < (int)C; ++b) blk_ab[(size_t)dense_block_index(a, b, (int)C)] = make_int2(a, b);
@@ -1825,6 +1858,9 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     LAUNCHED(h);
     tp3 = now_s();
     HIPCHK(h, hipStreamSynchronize(h->stream));     // the host tables are rebuilt by the next call
+    if (timing)
+        fprintf(stderr, "sfmba: set_problem  structure = run offsets + camera-major permutation %.2f ms, wave ranges %.2f ms, step table %.2f ms, "
+                        "chunks + pair lists %.2f ms\n", 1e3 * (ts1 - tp1), 1e3 * (ts2 - ts1), 1e3 * (ts3 - ts2), 1e3 * (tp2 - ts3));
     if (timing)
         fprintf(stderr, "sfmba: set_problem  convert+compare %.2f ms  structure %.2f ms  allocate+enqueue %.2f ms  upload wait %.2f ms"
                         "  (%lld of %lld observations re-used)\n",
