@@ -189,3 +189,41 @@ def test_pack_unpack_round_trip():
     for k in range(6):
         assert np.allclose(H2[k], H[k], atol=1e-12)
     assert np.array_equal(X2, X3d)
+
+
+def test_growing_reconstruction_fixture_and_oracle_on_its_first_stages():
+    """tests/golden/scipy_growing_run.json (scipy + the reference's residual on a 2 -> 11 camera growing reconstruction,
+    /root/reference/sfm_lite/sfm.py:59-71): the stage structure regenerates from the seeded generator, and the oracle,
+    started from scipy's recorded x0 of a stage, reaches scipy's RMSE (1e-6 px) with a cost not above scipy's."""
+    import json
+    import sfmba
+    from sfmba.synthetic import growing_reconstruction, make_problem
+    path = os.path.join(GOLDEN, "scipy_growing_run.json")
+    if not os.path.exists(path):
+        pytest.skip("scipy_growing_run.json not generated")
+    rec = json.load(open(path))
+    arrs = np.load(os.path.join(GOLDEN, "scipy_growing_x.npz"))
+    base = rec["base"]
+    pb = make_problem(base["n_cameras"], base["n_points"], base["n_obs"], seed=base["seed"])
+    stages = list(growing_reconstruction(pb, rec["order"]))
+    assert len(stages) == len(rec["stages"]) == pb.n_cameras - 1
+    for k, (st, g) in enumerate(zip(stages, rec["stages"])):
+        assert (sum(st["registered"]), len(st["cloud"]), len(st["observations"])) == (g["n_cameras"], g["n_points"], g["n_obs"])
+        obs = st["observations"]
+        assert all(obs[i][0] <= obs[i + 1][0] for i in range(len(obs) - 1))          # point-major, as Graph.pt3ds_pt2ds
+        assert g["status"] > 0 and g["rmse"] < 0.5 < g["rmse0"]
+        if k > 1:
+            continue                                                                   # (oracle runs: the two smallest stages)
+        reg = [c for c in range(pb.n_cameras) if st["registered"][c]]
+        cmap = {c: i for i, c in enumerate(reg)}
+        ci = np.array([cmap[o[1]] for o in obs])
+        pi = np.array([o[0] for o in obs])
+        uv = np.array([o[2] for o in obs])
+        x0 = arrs[f"s{k:02d}_x0"]
+        assert x0.shape == (6 * g["n_cameras"] + 3 * g["n_points"],)
+        r0 = orc.compute_residuals(x0, g["n_cameras"], g["n_points"], ci, pi, uv, pb.K)
+        assert abs(np.sqrt(np.mean(r0 ** 2)) - g["rmse0"]) < 1e-9
+        res = orc.trf_schur(x0, g["n_cameras"], g["n_points"], ci, pi, uv, pb.K, ftol=1e-10, linear="pcg", pcg_tol=1e-3,
+                            precond="schur_exact")
+        assert res.status > 0
+        assert abs(np.sqrt(np.mean(res.fun ** 2)) - g["rmse"]) < 1e-6 and res.cost <= g["cost"] * (1 + 1e-9)
