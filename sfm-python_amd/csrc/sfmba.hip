@@ -239,6 +239,7 @@ struct sfmba_handle {
         int dense = -1;                      // 0: PCG although the dense reduced-camera path would apply
         int precond = -1;                    // 0: block-Jacobi preconditioner from U + Dc instead of the Schur diagonal
         int pcg_local = -1;                  // 0: the fused PCG keeps its whole update in pass A's prologue
+        int xcd_chunks = -1;                 // 1 / 0: camera lists cut at the eight point-range boundaries (one chunk per XCD) whatever the size
         int rhsrec = -1;                     // 1 / 0: the rhs + preconditioner pass gathers its own 128-byte records whatever the size
         int cost_rider = -1;                 // 0: the trial cost is summed and posted by a k_finish launch of its own
         int pcg_split = -1;                  // 1: the local form with its tail in a kernel of its own (k_pcg_tail) on a
@@ -259,6 +260,13 @@ struct sfmba_handle {
     DevBuf cm_perm, cm_pt, cm_uv, cam_partial;
     DevView cam_chunks, cam_chunk_ptr;
     int n_chunks = 0;
+    // a second chunk table for pass B of the Schur product alone (many points): every camera's list cut at the eight
+    // point-range boundaries, chunk 8 c + k on XCD k (see set_problem)
+    DevView cam_chunks_b, cam_chunk_ptr_b;
+    int n_chunks_b = 0;
+    bool xcd_b = false;
+    std::vector<int4> host_chunks_b;
+    std::vector<int> host_chunk_ptr_b;
     bool cam_multi = false;                  // some camera has more than one chunk: k_cam_combine runs
     DevBuf xa, xb, tabA, tabB, r, J, t1;     // ONE Jacobian / residual buffer set
     DevBuf rhsrec;                           // [P][kRhsRec]: what k_cam_rhs_diag gathers (written by k_prep)
@@ -642,10 +650,12 @@ CamMajor cam_major(const sfmba_handle* h) {
 }
 
 // chunk rows of cameras with several chunks -> out[c * cs + col * ks]
-int launch_cam_combine(sfmba_handle* h, int ncols, double* out, int cs, int ks, const double* skip, const int* done) {
-    if (!h->cam_multi) return 0;
+int launch_cam_combine(sfmba_handle* h, int ncols, double* out, int cs, int ks, const double* skip, const int* done,
+                       bool table_b = false) {
+    if (!(table_b ? h->xcd_b : h->cam_multi)) return 0;
     hipLaunchKernelGGL(k_cam_combine, dim3((int)((h->C * ncols + 255) / 256)), dim3(256), 0, h->stream,
-                       h->cam_chunk_ptr.as<int>(), h->cam_partial.as<double>(), (int)h->C, ncols, out, cs, ks, skip, done);
+                       (table_b ? h->cam_chunk_ptr_b : h->cam_chunk_ptr).as<int>(), h->cam_partial.as<double>(), (int)h->C, ncols,
+                       out, cs, ks, skip, done);
     LAUNCHED(h);
     return 0;
 }
@@ -758,16 +768,20 @@ template <int MODE>
 int launch_cam_schur(sfmba_handle* h, const double* vin, const PcgCtrl* ctrl_done, int set, bool local = false) {
     const PcgLocal pl{h->Dc.as<double>(), h->Minv.as<double>(), h->vecs.as<double>(),
                       local ? h->pcg_part.as<double>() : (double*)nullptr};
+    // MODE 0 with the XCD-aware table: chunk 8 c + k runs on XCD k and gathers records of point range k only
+    const bool tb = MODE == 0 && h->xcd_b;
+    const CamMajor cm = tb ? CamMajor{h->cam_chunks_b.as<int4>(), h->cm_pt.as<int>(), h->cm_uv.as<double>()} : cam_major(h);
+    const int grid = tb ? h->n_chunks_b : h->n_chunks;
     if (h->f32 && !h->sweep_rc && !h->sweep_rc_g)   // pass A applies the stored fp32 blocks: pass B rounds its own the same way
-        hipLaunchKernelGGL((k_cam_schur<MODE, true>), dim3(h->n_chunks), dim3(kCamThreads), 0, h->stream, cam_major(h),
+        hipLaunchKernelGGL((k_cam_schur<MODE, true>), dim3(grid), dim3(kCamThreads), 0, h->stream, cm,
                            (const double*)h->tab, (const double*)h->rec, h->K, vin, (int)h->C, h->acc(),
                            h->cam_partial.as<double>(), ctrl_done, set, pl);
     else
-        hipLaunchKernelGGL((k_cam_schur<MODE, false>), dim3(h->n_chunks), dim3(kCamThreads), 0, h->stream, cam_major(h),
+        hipLaunchKernelGGL((k_cam_schur<MODE, false>), dim3(grid), dim3(kCamThreads), 0, h->stream, cm,
                            (const double*)h->tab, (const double*)h->rec, h->K, vin, (int)h->C, h->acc(),
                            h->cam_partial.as<double>(), ctrl_done, set, pl);
     LAUNCHED(h);
-    return launch_cam_combine(h, 6, h->acc(), 1, (int)h->C, nullptr, ctrl_done ? &ctrl_done->done : nullptr);
+    return launch_cam_combine(h, 6, h->acc(), 1, (int)h->C, nullptr, ctrl_done ? &ctrl_done->done : nullptr, tb);
 }
 
 // The local form with its tail split off (k_p2p_pcg / k_pcg_tail): sharded solves and cameras of several chunks; on a
@@ -775,7 +789,7 @@ int launch_cam_schur(sfmba_handle* h, const double* vin, const PcgCtrl* ctrl_don
 bool pcg_split_mode(const sfmba_handle* h) {
     if (h->dbg.pcg_local == 0 || h->dbg.precond == 0) return false;
     if (!(h->pcg_fused || h->sweep_rc_g)) return false;         // (the forms that have a local prologue / k_pcg_update_local)
-    return (multi_rank(h) || h->cam_multi) ? h->dbg.pcg_split != 0 : h->dbg.pcg_split == 1;
+    return (multi_rank(h) || h->cam_multi || h->xcd_b) ? h->dbg.pcg_split != 0 : h->dbg.pcg_split == 1;
 }
 
 // Reduced right-hand side term -> acc and, with the Schur-diagonal preconditioner, the diagonal blocks of
@@ -1011,8 +1025,8 @@ int pcg_max_iters(const sfmba_handle* h, const sfmba_options& opt) {
 int pcg_start(sfmba_handle* h, const sfmba_options& opt) {
     h->pcg_L = 0;
     h->pcg_split = pcg_split_mode(h);
-    h->pcg_local = h->pcg_fused && h->dbg.pcg_local != 0 && ((!multi_rank(h) && !h->cam_multi) || h->pcg_split);
-    h->pcg_local2 = !h->pcg_fused && h->sweep_rc_g && h->dbg.pcg_local != 0 && ((!multi_rank(h) && !h->cam_multi) || h->pcg_split);
+    h->pcg_local = h->pcg_fused && h->dbg.pcg_local != 0 && ((!multi_rank(h) && !h->cam_multi && !h->xcd_b) || h->pcg_split);
+    h->pcg_local2 = !h->pcg_fused && h->sweep_rc_g && h->dbg.pcg_local != 0 && ((!multi_rank(h) && !h->cam_multi && !h->xcd_b) || h->pcg_split);
     if (h->pcg_fused) {                   // launch 0 of the fused form initialises the solve itself
         h->pcg_tol = opt.pcg_tol;
         h->pcg_cap = pcg_max_iters(h, opt);
@@ -1229,6 +1243,7 @@ int sfmba_debug_option(sfmba_handle* h, const char* name, int64_t value) {
     else if (n == "pcg_split") h->dbg.pcg_split = v;
     else if (n == "cost_rider") h->dbg.cost_rider = v;
     else if (n == "rhsrec") h->dbg.rhsrec = v;
+    else if (n == "xcd_chunks") h->dbg.xcd_chunks = v;
     else if (n == "tab_lds") h->dbg.tab_lds = v;
     else if (n == "vec_lds") h->dbg.vec_lds = v;
     else if (n == "cam_chunk") h->dbg.cam_chunk = v;
@@ -1693,6 +1708,41 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
         }
         chunk_ptr[C] = (int)chunks.size();
         h->n_chunks = (int)chunks.size();
+        // XCD-aware chunks for pass B of the Schur product (many points).  Every camera-major pass gathers one record
+        // per observation from a table of P x 48 bytes; workgroup i runs on XCD i mod 8 and each XCD has its own 4 MiB
+        // L2: with one chunk per camera every L2 sees the WHOLE table (48 MB at a million points).  A camera's list is
+        // ascending in the point index, so it is cut at the eight point-range boundaries P k / 8: chunk 8 c + k runs on
+        // XCD k and touches points of range k only, each L2 serves an eighth of the table (pass B at 5000 / 1M / 10M:
+        // 201 -> 134 us); the eight partial rows of a camera are added by k_cam_combine and the PCG tail runs behind
+        // it (k_pcg_tail).  Pass B only: the passes with 27 sums per workgroup (K3, rhs + preconditioner) lose more to
+        // eight times as many block reductions than they gain (208 -> 320 us, 188 -> 257 us).
+        std::vector<int4>& chunks_b = h->host_chunks_b;
+        std::vector<int>& chunk_ptr_b = h->host_chunk_ptr_b;
+        chunks_b.clear();
+        chunk_ptr_b.clear();
+        h->xcd_b = h->dbg.xcd_chunks == 1 || (h->dbg.xcd_chunks != 0 && P >= 250000);
+        if (h->xcd_b) {
+            constexpr int kX = 8;
+            chunk_ptr_b.resize((size_t)C + 1);
+            for (int64_t c = 0; c < C; ++c) {
+                chunk_ptr_b[c] = (int)chunks_b.size();
+                const int b = cam_ptr[c], e = cam_ptr[c + 1];
+                int prev = b;
+                for (int k = 0; k < kX; ++k) {
+                    int bound = e;
+                    if (k + 1 < kX) {
+                        const int64_t p_hi = P * (int64_t)(k + 1) / kX;          // first point of the next range
+                        int lo = prev, hi = e;                                   // lower bound over pi[perm[.]] (ascending)
+                        while (lo < hi) { const int mid = (lo + hi) >> 1; if (pi[perm[mid]] < p_hi) lo = mid + 1; else hi = mid; }
+                        bound = lo;
+                    }
+                    chunks_b.push_back(make_int4((int)c, prev, bound, kX));
+                    prev = bound;
+                }
+            }
+            chunk_ptr_b[C] = (int)chunks_b.size();
+        }
+        h->n_chunks_b = (int)chunks_b.size();
     }
     // few cameras: for every block pair (a <= b) the points seen by both cameras, with multiplicity (a point seen
     // m_a, m_b times contributes m_a m_b times); two counting passes over the runs.  The diagonal pairs' workgroups
@@ -1755,13 +1805,15 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     HIPCHK(h, h->pt_ptr.ensure_keep(sizeof(int) * ((size_t)P + 1), sizeof(int) * (size_t)p_keep));
     // the structure tables: one device buffer, one pinned staging buffer, one copy
     struct Piece { const void* src; size_t bytes; DevView* view; size_t off; };
-    Piece pieces[8] = {
+    Piece pieces[10] = {
         {ranges.data(), sizeof(int2) * ranges.size(), &h->ranges, 0}, {wsteps.data(), sizeof(int2) * wsteps.size(), &h->wsteps, 0},
         {steps.data(), sizeof(int2) * steps.size(), &h->steps, 0}, {chunks.data(), sizeof(int4) * chunks.size(), &h->cam_chunks, 0},
         {chunk_ptr.data(), sizeof(int) * chunk_ptr.size(), &h->cam_chunk_ptr, 0},
         {cov_ptr.data(), h->dense ? sizeof(int) * cov_ptr.size() : 0, &h->cov_ptr, 0},
         {cov_pt.data(), h->dense ? sizeof(int) * cov_pt.size() : 0, &h->cov_pt, 0},
-        {blk_ab.data(), h->dense ? sizeof(int2) * blk_ab.size() : 0, &h->blk_ab, 0}};
+        {blk_ab.data(), h->dense ? sizeof(int2) * blk_ab.size() : 0, &h->blk_ab, 0},
+        {h->host_chunks_b.data(), sizeof(int4) * h->host_chunks_b.size(), &h->cam_chunks_b, 0},
+        {h->host_chunk_ptr_b.data(), sizeof(int) * h->host_chunk_ptr_b.size(), &h->cam_chunk_ptr_b, 0}};
     size_t tables_bytes = 0;
     for (auto& pc : pieces) { pc.off = tables_bytes; tables_bytes += (pc.bytes + 255) / 256 * 256; }
     HIPCHK(h, h->tables.ensure(tables_bytes + 256));
@@ -1779,7 +1831,7 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     HIPCHK(h, h->cm_perm.ensure(sizeof(int) * ldz));
     HIPCHK(h, h->cm_pt.ensure(sizeof(int) * ldz));
     HIPCHK(h, h->cm_uv.ensure(esz * 2 * ldz));
-    HIPCHK(h, h->cam_partial.ensure(sizeof(double) * 27 * chunks.size()));
+    HIPCHK(h, h->cam_partial.ensure(sizeof(double) * std::max<size_t>(27 * chunks.size(), 6 * h->host_chunks_b.size())));
     HIPCHK(h, h->recA.ensure(sizeof(double) * kRec * P));
     HIPCHK(h, h->recB.ensure(sizeof(double) * kRec * P));
     // One 128-byte gather record per point for k_cam_rhs_diag pays once the point tables no longer sit in the L2s
