@@ -285,9 +285,8 @@ constexpr int kCamRT = 12, kCamWbc = 5;
 __host__ __device__ constexpr size_t cam_rt_offset(int C) { return (size_t)C * kCamRow; }
 __host__ __device__ constexpr size_t cam_wbc_offset(int C) { return cam_rt_offset(C) + (size_t)C * kCamRT; }
 __host__ __device__ constexpr size_t cam_table_doubles(int C) { return cam_wbc_offset(C) + (size_t)C * kCamWbc; }
-__device__ __forceinline__ void cam_table_row(const double* __restrict__ prm, double* __restrict__ tab, int C, int c) {
-    double* __restrict__ t = tab + (size_t)c * kCamRow;
-    t[kCamTab] = 0.0;
+// the 17 entries of one camera's row: R (9), T (3), w (3), b, c  (t may be global or LDS)
+__device__ __forceinline__ void cam_row_values(const double* __restrict__ prm, double* __restrict__ t) {
     const double wx = prm[0], wy = prm[1], wz = prm[2];
     const double th2 = wx * wx + wy * wy + wz * wz;
     const double th = sqrt(th2);
@@ -313,6 +312,11 @@ __device__ __forceinline__ void cam_table_row(const double* __restrict__ prm, do
     t[9] = prm[3]; t[10] = prm[4]; t[11] = prm[5];
     t[12] = wx; t[13] = wy; t[14] = wz;
     t[15] = b; t[16] = cc;
+}
+__device__ __forceinline__ void cam_table_row(const double* __restrict__ prm, double* __restrict__ tab, int C, int c) {
+    double* __restrict__ t = tab + (size_t)c * kCamRow;
+    t[kCamTab] = 0.0;
+    cam_row_values(prm, t);
     double* __restrict__ rt = tab + cam_rt_offset(C) + (size_t)c * kCamRT;
 #pragma unroll
     for (int k = 0; k < kCamRT; ++k) rt[k] = t[k];
@@ -1061,10 +1065,8 @@ __device__ __forceinline__ void chol3_inverse(const double* a /*upper 6*/, doubl
 
 // Regularisation of the damped Gauss-Newton step from the 1-D Cauchy problem along -g_h
 // (SCIPY trf.py:471-475, common.py:251-322), evaluated from the exchange scalars by whoever needs it.
-__device__ __forceinline__ double reg_from_scalars(const double* __restrict__ sc, double G11, double Delta,
-                                                   double reg_min) {
-    const double a11 = sc[8] + sc[16 + 1];          // |g_h|^2: point slice (summed over ranks) + cameras
-    const double a = 0.5 * G11, b = -a11;           // G11 = |J_h g_h|^2
+__device__ __forceinline__ double reg_from_a11(double a11, double G11, double Delta, double reg_min) {
+    const double a = 0.5 * G11, b = -a11;           // G11 = |J_h g_h|^2, a11 = |g_h|^2
     double reg = reg_min;
     if (a11 > 0.0) {
         const double to_tr = Delta / sqrt(a11);
@@ -1078,6 +1080,10 @@ __device__ __forceinline__ double reg_from_scalars(const double* __restrict__ sc
         reg = fmax(-best / (Delta * Delta), reg_min);
     }
     return reg;
+}
+__device__ __forceinline__ double reg_from_scalars(const double* __restrict__ sc, double G11, double Delta,
+                                                   double reg_min) {
+    return reg_from_a11(sc[8] + sc[16 + 1], G11, Delta, reg_min);      // |g_h|^2: point slice (summed over ranks) + cameras
 }
 
 __device__ __forceinline__ void point_prep_one(const double* __restrict__ V, const double* __restrict__ gp,
@@ -2347,11 +2353,14 @@ __device__ __forceinline__ double dense_rcp(double d) {         // v_rcp_f64 + o
     const double y = __builtin_amdgcn_rcp(d);
     return fma(fma(-d, y, 1.0), y, y);
 }
-__global__ __launch_bounds__(kDenseThreads) void k_dense_pcg(const double* __restrict__ Sblk, const double* __restrict__ Ugc,
-                                                             const double* __restrict__ Dc, const double* __restrict__ acc,
-                                                             int C, double tol, int max_iters, double* __restrict__ vecs,
-                                                             PcgCtrl* __restrict__ ctrl2) {
-    extern __shared__ __align__(16) double A[];
+// The solve itself, shared by k_dense_pcg and the one-launch solver of small problems (small_solve.hpp): A = the
+// workgroup's LDS region (matrix | r u | 6x6 inverses | reduction slots), blk_load(e) = entry e of the block list,
+// x_store(camera, k, value) takes the step; Ugc / Dc / acc may live in global memory or in LDS.  Every thread of the
+// 512 returns the same control block.
+template <class BlkLoad, class XStore>
+__device__ __forceinline__ PcgCtrl dense_pcg_body(double* __restrict__ A, BlkLoad blk_load, const double* __restrict__ Ugc,
+                                                  const double* __restrict__ Dc, const double* __restrict__ acc, int C,
+                                                  double tol, int max_iters, XStore x_store) {
     constexpr int kWaves = kDenseThreads / 64;
     const int n = 6 * C, ld = n | 1;
     double* rv = A + (size_t)n * ld;            // behind the matrix: r, u, the 6x6 inverses, reduction slots
@@ -2395,7 +2404,7 @@ __global__ __launch_bounds__(kDenseThreads) void k_dense_pcg(const double* __res
                     int a, b, u, v;
                     decode(e, a, b, u, v);
                     if (a == b && u > v) continue;
-                    val[q] = Sblk[e];
+                    val[q] = blk_load(e);
                     if (a == b) {
                         add[q] = Ugc[(size_t)a * 27 + (u * 6 - u * (u - 1) / 2 + (v - u))];
                         if (u == v) add[q] += Dc[(size_t)u * C + a];
@@ -2499,18 +2508,25 @@ __global__ __launch_bounds__(kDenseThreads) void k_dense_pcg(const double* __res
         }
         __syncthreads();
     }
-    if (owner) {
-        const double xo = isfinite(x) ? x : 0.0;
-        vecs[kPcgX * (size_t)n + (size_t)kk * C + cam] = xo;                         // both vector sets: the back
-        vecs[(kPcgVecs + kPcgX) * (size_t)n + (size_t)kk * C + cam] = xo;            // substitution picks one by count
-    }
-    if (tid == 0) {
-        PcgCtrl c0;
-        c0.rz = gamma; c0.rz0 = gamma0; c0.tol2 = tol2; c0.rz_prev = 1.0 / inv_gamma_prev; c0.alpha_prev = 1.0 / inv_alpha_prev;
-        c0.iters = it; c0.max_iters = max_iters; c0.done = done; c0.pad = 2;
-        ctrl2[0] = c0;
-        ctrl2[1] = c0;
-    }
+    if (owner) x_store(cam, kk, isfinite(x) ? x : 0.0);
+    PcgCtrl c0;
+    c0.rz = gamma; c0.rz0 = gamma0; c0.tol2 = tol2; c0.rz_prev = 1.0 / inv_gamma_prev; c0.alpha_prev = 1.0 / inv_alpha_prev;
+    c0.iters = it; c0.max_iters = max_iters; c0.done = done; c0.pad = 2;
+    return c0;
+}
+
+__global__ __launch_bounds__(kDenseThreads) void k_dense_pcg(const double* __restrict__ Sblk, const double* __restrict__ Ugc,
+                                                             const double* __restrict__ Dc, const double* __restrict__ acc,
+                                                             int C, double tol, int max_iters, double* __restrict__ vecs,
+                                                             PcgCtrl* __restrict__ ctrl2) {
+    extern __shared__ __align__(16) double A[];
+    const int n = 6 * C;
+    const PcgCtrl c0 = dense_pcg_body(
+        A, [&](int e) { return Sblk[e]; }, Ugc, Dc, acc, C, tol, max_iters, [&](int cam, int kk, double xo) {
+            vecs[kPcgX * (size_t)n + (size_t)kk * C + cam] = xo;                         // both vector sets: the back
+            vecs[(kPcgVecs + kPcgX) * (size_t)n + (size_t)kk * C + cam] = xo;            // substitution picks one by count
+        });
+    if (threadIdx.x == 0) { ctrl2[0] = c0; ctrl2[1] = c0; }
 }
 
 // PCG on the reduced camera system S dc = rhs in the single-reduction (Chronopoulos-Gear) form, so

@@ -120,7 +120,47 @@ __global__ void k_probe(Bar* bar, double* buf, unsigned* seen, size_t per_wg, in
     if (threadIdx.x == 0 && bad) atomicAdd(seen, bad);
 }
 
-int main() {
+
+// ---- one XCD only -------------------------------------------------------------------------------------------------
+// Workgroups are dealt to the XCDs round-robin (blockIdx % 8), so the workgroups with blockIdx % 8 == 0 of an 8 G-wide
+// launch share ONE L2.  Among them a barrier needs no L2 write-back and no L2 invalidation: stores are in the L2 once
+// vmcnt == 0 (the vector L1 is write-through), and the reader only has to drop its own L1 (buffer_inv sc0).
+// MODE 2: that barrier.  MODE 3: the same workgroups with the agent-scope central barrier (what the data pay for
+// an L2 write-back + invalidate).  After the barrier every workgroup reads the WHOLE 32 KB another one wrote, with
+// plain loads, and checks every value.
+__device__ __forceinline__ bool barrier_one_xcd(Bar* b, unsigned round, unsigned G) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    bool ok = true;
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(b->central, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = spin_until(b->central, round * G, b->err);
+    }
+    __syncthreads();
+    asm volatile("buffer_inv sc0" ::: "memory");
+    return ok;
+}
+
+template <int MODE>                             // 2 one-XCD barrier, 3 agent-scope central barrier on the same workgroups
+__global__ void k_probe_one_xcd(Bar* bar, double* buf, unsigned* seen, size_t per_wg, int rounds, unsigned* xcc_seen) {
+    if ((blockIdx.x & 7) != 0) return;
+    const unsigned G = gridDim.x / 8, me = blockIdx.x / 8;
+    if (threadIdx.x == 0) xcc_seen[me] = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7;
+    double* mine = buf + (size_t)me * per_wg;
+    unsigned bad = 0;
+    for (int r = 1; r <= rounds; ++r) {
+        for (size_t i = threadIdx.x; i < per_wg; i += blockDim.x) mine[i] = (double)r + (double)i;
+        const bool ok = MODE == 2 ? barrier_one_xcd(bar, 2u * r - 1u, G) : barrier_central(bar, 2u * r - 1u, G);
+        if (!ok) return;
+        const double* other = buf + (size_t)((me + G / 2 + 1) % G) * per_wg;
+        for (size_t i = threadIdx.x; i < per_wg; i += blockDim.x) bad += other[i] != (double)r + (double)i;
+        // nobody may overwrite what a neighbour is still reading
+        if (!(MODE == 2 ? barrier_one_xcd(bar, 2u * r, G) : barrier_central(bar, 2u * r, G))) return;
+    }
+    if (bad) atomicAdd(seen, bad);
+}
+
+int main(int argc, char**) {
     hipSetDevice(0);
     hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
     printf("device: %s, %d CUs\n", p.name, p.multiProcessorCount);
@@ -130,7 +170,7 @@ int main() {
     double* buf; hipMalloc(&buf, sizeof(double) * per_wg * 256); hipMemset(buf, 0, sizeof(double) * per_wg * 256);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     printf("%-8s %5s %8s %6s %12s %8s %6s\n", "barrier", "G", "threads", "touch", "us/barrier", "stale", "err");
-    for (int mode = 0; mode < 2; ++mode)
+    for (int mode = argc > 1 ? 2 : 0; mode < 2; ++mode)      // any argument: the one-XCD part only
         for (int G : {8, 32, 64, 256})
             for (int threads : {256, 1024})
                 for (int touch = 0; touch < 2; ++touch) {
@@ -154,5 +194,32 @@ int main() {
                            per_round, stale, err);
                     fflush(stdout);
                 }
+    unsigned* xcc_seen; hipMalloc(&xcc_seen, 4 * 64);
+    printf("%-8s %5s %8s %14s %8s %6s  %s\n", "barrier", "G", "threads", "us/round(2 bar)", "bad", "err", "XCC ids of the participants");
+    for (int mode = 2; mode < 4; ++mode)
+        for (int G : {8, 16, 32})
+            for (int threads : {256, 512, 1024}) {
+                float t[2] = {0, 0};
+                unsigned stale = 0, err = 0;
+                const int rr[2] = {1, 201};
+                for (int k = 0; k < 2; ++k) {
+                    hipMemset(bar, 0, sizeof(Bar)); hipMemset(seen, 0, 4); hipMemset(xcc_seen, 0xff, 4 * 64);
+                    hipDeviceSynchronize();
+                    hipEventRecord(a);
+                    if (mode == 2) hipLaunchKernelGGL(k_probe_one_xcd<2>, dim3(8 * G), dim3(threads), 0, 0, bar, buf, seen, per_wg, rr[k], xcc_seen);
+                    else hipLaunchKernelGGL(k_probe_one_xcd<3>, dim3(8 * G), dim3(threads), 0, 0, bar, buf, seen, per_wg, rr[k], xcc_seen);
+                    hipEventRecord(b); hipEventSynchronize(b);
+                    hipEventElapsedTime(&t[k], a, b);
+                    Bar hb; hipMemcpy(&hb, bar, sizeof hb, hipMemcpyDeviceToHost);
+                    unsigned s; hipMemcpy(&s, seen, 4, hipMemcpyDeviceToHost);
+                    stale += s; err += hb.err[0];
+                }
+                unsigned xs[64]; hipMemcpy(xs, xcc_seen, 4 * 64, hipMemcpyDeviceToHost);
+                unsigned mask = 0;
+                for (int i = 0; i < G; ++i) mask |= 1u << (xs[i] & 7);
+                printf("%-8s %5d %8d %14.2f %8u %6u  mask 0x%02x\n", mode == 2 ? "one-xcd" : "agent", G, threads,
+                       1e3 * (t[1] - t[0]) / (rr[1] - rr[0]), stale, err, mask);
+                fflush(stdout);
+            }
     return 0;
 }
