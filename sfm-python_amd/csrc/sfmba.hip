@@ -2257,9 +2257,10 @@ static int solve_small(sfmba_handle* h, double* x_inout, const sfmba_options& op
                         "nfev %g  iterations %g  pcg %g  %.3f ms\n", h->small_G, h->small_E, h->sm_nsegP, h->sm_nsegC, h->sm_nsegS,
                 o[15], o[13], o[14], o[0], o[1], o[3], o[4], 1e3 * (now_s() - t_begin));
     if (h->dbg.trace_timing) {
-        fprintf(stderr, "sfmba:   pcg / cost per iteration:");
-        for (int k = 0; k < std::min(8, (int)o[11]); ++k) fprintf(stderr, "  %g / %.12g", o[kSmallOutHead + k], o[kSmallOutHead + kSmallHist / 2 + k]);
-        fprintf(stderr, "\n");
+        fprintf(stderr, "sfmba:   us per phase (workgroup 0): eval0 %.1f | lin %.1f +bar %.1f | jdot %.1f | prep %.1f | schur %.1f +bar %.1f | pcg %.1f | "
+                        "back1 %.1f | back2 %.1f | gram %.1f | tr %.1f | trial %.1f +bar %.1f\n", o[kSmallOutHead + 56], o[kSmallOutHead + 57],
+                o[kSmallOutHead + 58], o[kSmallOutHead + 59], o[kSmallOutHead + 60], o[kSmallOutHead + 61], o[kSmallOutHead + 62], o[kSmallOutHead + 63],
+                o[kSmallOutHead + 64], o[kSmallOutHead + 65], o[kSmallOutHead + 66], o[kSmallOutHead + 67], o[kSmallOutHead + 68], o[kSmallOutHead + 69]);
     }
     if (o[15] != 1.0) {
         // a grid barrier ran into its spin limit: the participating workgroups were not all resident (another kernel --

@@ -121,8 +121,16 @@ __device__ __forceinline__ void seg_emit(double (&v)[NV], int key, bool valid, i
 }
 template <int NV>
 __device__ __forceinline__ double seg_total(const double* rows, int s0, int s1, int n) {
+    // eight rows requested together (an sc1 load is a round trip to the L2: ~0.7 us each when they wait for one another),
+    // added in row order
     double acc = 0.0;
-    for (int s = s0; s < s1; ++s) acc += ldg(rows + (size_t)s * NV + n);
+    for (int s = s0; s < s1; s += 8) {
+        double v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = s + j < s1 ? ldg(rows + (size_t)(s + j) * NV + n) : 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += v[j];
+    }
     return acc;
 }
 
@@ -218,6 +226,12 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_solve(SmallArgs a) {
     for (int t = tid; t < n6; t += kSmallThreads) { xc[t] = a.xa[t]; sic[t] = 0.0; }
     __syncthreads();
 
+    __shared__ long long s_time[16];                    // (diagnostic) 100 MHz ticks per phase, workgroup 0
+    if (tid < 16) s_time[tid] = 0;
+    long long t_mark = wall_clock64();
+    auto lap = [&](int k) {
+        if (tid == 0) { const long long t = wall_clock64(); s_time[k] += t - t_mark; t_mark = t; }
+    };
     int n_eval = 0;                                     // parity of the cost column (see the hazard note at `evaluate`)
     // Residual + blocks of the owner's observation, point sums (rows of segP), camera sums (rows of segC), the
     // workgroup's part of sum r^2.  trial: the point is x + c1 D^2 g + c2 p, also written to `xnew`.
@@ -280,10 +294,11 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_solve(SmallArgs a) {
             if (me == 0 && tid < n6) xnew[tid] = xcl[tid];
         }
     };
-    auto total = [&](int col) {                         // sum of one column of the partial rows, workgroups in order
-        double s = 0.0;
-        for (int w = 0; w < G; ++w) s += ldg(a.part + (size_t)w * kSmallPartCols + col);
-        return s;
+    // sum of one column of the partial rows: lane w takes workgroup w's row, the wave adds (every wave of every
+    // workgroup the same loads and the same order: the same bits everywhere)
+    auto total = [&](int col) {
+        const double v = lane < G ? ldg(a.part + (size_t)lane * kSmallPartCols + col) : 0.0;
+        return wave_sum(v);
     };
     auto finish = [&](int status, int nfev, int njev, int iteration, int pcg_total, double cost0, double cost, double g_norm,
                       double step_norm, double reg, int n_hist, int breakdowns) {
@@ -293,6 +308,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_solve(SmallArgs a) {
             o[4] = (double)pcg_total; o[5] = cost0; o[6] = cost; o[7] = g_norm; o[8] = step_norm; o[9] = reg;
             o[10] = xcur == a.xa ? 0.0 : 1.0; o[11] = (double)n_hist; o[12] = (double)breakdowns;
             o[13] = sy.same_xcd ? 1.0 : 0.0; o[14] = (double)sy.round; o[15] = 1.0;           // [15]: block is complete
+            for (int k = 0; k < 16; ++k) o[kSmallOutHead + kSmallHist / 2 + k] = 0.01 * (double)s_time[k];   // us
         }
     };
 
@@ -305,6 +321,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_solve(SmallArgs a) {
     for (int k = 0; k < 6; ++k) { jp[k] = 0.0; jpn[k] = 0.0; }
     evaluate(xc, tab, false, 0.0, 0.0, r0, r1, jc, jp);
     if (!small_barrier(sy)) return;
+    lap(0);
     double cost = 0.5 * total(0);
     const double cost0 = cost;
     if (!isfinite(cost)) { finish(-2, 1, 1, 0, 0, cost0, cost, 0.0, 0.0, 0.0, 0, 0); return; }
@@ -324,10 +341,8 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_solve(SmallArgs a) {
                 double s9[9];
 #pragma unroll
                 for (int n = 0; n < 9; ++n) s9[n] = 0.0;
-                for (int s = ps0; s < ps1; ++s) {
 #pragma unroll
-                    for (int n = 0; n < 9; ++n) s9[n] += ldg(a.segP + (size_t)s * 9 + n);
-                }
+                for (int n = 0; n < 9; ++n) s9[n] = seg_total<9>(a.segP, ps0, ps1, n);
 #pragma unroll
                 for (int k = 0; k < 6; ++k) Vr[k] = s9[k];
                 const int dv[3] = {0, 3, 5};
@@ -373,10 +388,10 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_solve(SmallArgs a) {
                 double* row = a.part + (size_t)me * kSmallPartCols;
                 row[2] = qmax; row[3] = q[0]; row[4] = q[1]; row[5] = q[2]; row[6] = q[3];
             }
+            lap(1);
             if (!small_barrier(sy)) return;
-            double m = 0.0;
-            for (int w = 0; w < G; ++w) m = fmax(m, ldg(a.part + (size_t)w * kSmallPartCols + 2));
-            qp[0] = m;
+            lap(2);
+            qp[0] = wave_max(lane < G ? ldg(a.part + (size_t)lane * kSmallPartCols + 2) : 0.0);
 #pragma unroll
             for (int k = 0; k < 4; ++k) qp[1 + k] = total(3 + k);
             if (first) {
@@ -410,6 +425,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_solve(SmallArgs a) {
             if (tid == 0) a.part[(size_t)me * kSmallPartCols + 7] = gl[0];
         }
         if (!small_barrier(sy)) return;
+        lap(3);
         const double G11 = total(7);
         // ---- regularisation (trf.py:471-475), Vinv and e per point, Dc per camera ----------------------------------------
         reg = reg_from_a11(a11, G11, Delta, a.reg_min);
@@ -430,6 +446,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_solve(SmallArgs a) {
         }
         if (tid < n6) { const int c = tid / 6, k = tid - 6 * c; Dc[k * C + c] = reg * sic[tid] * sic[tid]; }
         if (!small_barrier(sy)) return;
+        lap(4);
         // ---- blocks of W Vinv W^T per camera pair (k_schur_blocks' lists), reduced right-hand side per camera ---------------
         for (int k0 = 0; k0 < a.E; k0 += T) {
             const int k = k0 + gt;
@@ -485,7 +502,9 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_solve(SmallArgs a) {
             }
             seg_emit<6>(v6, own ? cmc : -1 - lane, own, wsegC, a.segR, lane);
         }
+        lap(5);
         if (!small_barrier(sy)) return;
+        lap(6);
         // ---- S dc = -g_c - acc by the PCG of k_dense_pcg, in every workgroup (the same bits everywhere) -------------------
         if (tid < n6) {
             const int c = tid / 6, k = tid - 6 * c;
@@ -496,12 +515,10 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_solve(SmallArgs a) {
             A, [&](int e) { const int blk = e / 36; return seg_total<36>(a.segS, a.ss.segptr[blk], a.ss.segptr[blk + 1], e - 36 * blk); },
             Ugc, Dc, accp, C, a.pcg_tol, a.pcg_max_iters, [&](int cam, int kk, double xo) { pc[6 * cam + kk] = xo; });
         __syncthreads();
+        lap(7);
         pcg_total += hc.iters;
         if (hc.done == 3) ++breakdowns;
-        if (me == 0 && tid == 0 && n_hist < kSmallHist / 2) {
-            a.out[kSmallOutHead + n_hist] = (double)hc.iters;
-            a.out[kSmallOutHead + kSmallHist / 2 + n_hist] = cost;        // (diagnostic: cost at the start of the iteration)
-        }
+        if (me == 0 && tid == 0 && n_hist < kSmallHist / 2) a.out[kSmallOutHead + n_hist] = (double)hc.iters;
         ++n_hist;
         // ---- back-substitution dp = Vinv (-g_p - sum W^T dc), model products ---------------------------------------------
         double u0 = 0.0, u1 = 0.0;                      // Jc dc of the owner's observation
@@ -516,6 +533,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_solve(SmallArgs a) {
             seg_emit<3>(y3, own ? pi : -1 - lane, own, wsegP, a.segY, lane);
         }
         if (!small_barrier(sy)) return;
+        lap(8);
         double qb[4] = {0.0, 0.0, 0.0, 0.0}, qbc[4] = {0.0, 0.0, 0.0, 0.0};          // q5..q8: points | cameras
         if (ptv) {
             const double b0 = -gpr[0] - seg_total<3>(a.segY, ps0, ps1, 0), b1 = -gpr[1] - seg_total<3>(a.segY, ps0, ps1, 1),
@@ -541,6 +559,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_solve(SmallArgs a) {
             row[8] = qb[0]; row[9] = qb[1]; row[10] = qb[2]; row[11] = qb[3];
         }
         if (!small_barrier(sy)) return;
+        lap(9);
         {
             double gg[2] = {0.0, 0.0};
             if (own) {
@@ -554,6 +573,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_solve(SmallArgs a) {
             if (tid == 0) { a.part[(size_t)me * kSmallPartCols + 12] = gg[0]; a.part[(size_t)me * kSmallPartCols + 13] = gg[1]; }
         }
         if (!small_barrier(sy)) return;
+        lap(10);
         // ---- the 2-D subspace model (trf.py:481-485) and the step loop (trf.py:488-526) -------------------------------------
         const double G12 = total(12), G22 = total(13);
         const TrModel model = tr_build_model(G11, G12, G22, a11, total(8) + qbc[0], total(9) + qbc[1], qp[4] + qcm[4],
@@ -565,9 +585,12 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_solve(SmallArgs a) {
             const TrStep st = tr_solve_step(model, Delta);
             if (tid < n6) xcn[tid] = trial_coord(xc[tid], sgc[tid], pc[tid], st.c1, st.c2);
             __syncthreads();
+            lap(11);
             const int col = n_eval & 1;
             evaluate(xcn, tabn, true, st.c1, st.c2, rn0, rn1, jcn, jpn);
+            lap(12);
             if (!small_barrier(sy)) return;
+            lap(13);
             ++nfev;
             cost_new = 0.5 * total(col);
             if (!isfinite(cost_new)) {                  // trf.py:504-506

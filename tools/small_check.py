@@ -9,8 +9,7 @@ import sfmba
 with_oracle = len(sys.argv) > 1
 if with_oracle:
     from oracle import ba_oracle as orc
-cases = [("cfg2", None), ("2,300,700", 1), ("3,500,1400", 2), ("5,900,3000", 3), ("8,100,400", 3), ("8,2000,7000", 4), ("11,3000,10000", 5),
-         ("16,4000,14000", 6), ("21,5000,16000", 7), ("7,40,200", 8), ("4,16000,16384", 9)]
+cases = [("cfg2", None), ("2,300,700", 1), ("5,900,3000", 3), ("21,5000,16000", 7), ("7,40,200", 8)]
 for name, seed in cases:
     if seed is None:
         pb = sfmba.make_config(name)
@@ -25,12 +24,11 @@ for name, seed in cases:
         be.set_problem(*pb.args)
         opt = be.default_options(); opt.ftol = 1e-10
         if small: be.debug_option("trace_timing", 1)
-        for mi in ():                     # the first iterations one by one
+        for mi in (0,):                     # the first iterations one by one
             opt.max_iter = mi
             x, res, _, _ = be.solve(pb.x0, opt, want_fun=False, want_grad=False)
             print(f"   small={small} max_iter={mi}: cost {res.cost:.15g} nfev {res.nfev} pcg {res.pcg_iterations} reg {res.last_reg:.6e} step {res.last_step_norm:.6e}", flush=True)
         opt.max_iter = 0
-        opt.max_nfev = 60
         be.debug_option("trace_timing", 0)
         t = []
         for k in range(6):
