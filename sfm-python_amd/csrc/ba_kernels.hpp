@@ -942,6 +942,11 @@ __device__ __forceinline__ void write_partials(double (&q)[kNQ], double* __restr
 // Column scale of x_scale='jac' (SCIPY common.py:598-610): si = |J col|_2 = sqrt(diag(J^T J)),
 // zeros -> 1 on the first call, running max afterwards; g = J^T f gathered from the blocks;
 // sg = g / si^2 (= D^2 g); and, in the same pass, the partial sums q0..q4 of the new iterate.
+// Blocks [0, bc): the camera slice, one element per thread and trip.  Blocks [bc, grid): the point slice, one POINT per
+// thread and trip with every load of the trip issued before the first use -- V, g_p and x were written by other XCDs a
+// moment ago, so each dependent round trip is an L2 miss (the element-wise loop with its 64-bit divisions took 11.5 us
+// in the solve at 306k parameters where its traffic is worth 3).
+template <int kScalePts>                         // points per thread and trip (2 from 64k points on, else 1)
 __global__ __launch_bounds__(256) void k_update_scale(const double* __restrict__ Ugc,
                                                       const double* __restrict__ V,
                                                       const double* __restrict__ gp,
@@ -949,38 +954,61 @@ __global__ __launch_bounds__(256) void k_update_scale(const double* __restrict__
                                                       int first, int bc, double* __restrict__ si,
                                                       double* __restrict__ g, double* __restrict__ sg,
                                                       double* __restrict__ part) {
-    const int64_t n6 = 6 * (int64_t)C, n = n6 + 3 * (int64_t)P;
-    const int diagU[6] = {0, 6, 11, 15, 18, 20};
-    const int diagV[3] = {0, 3, 5};
-    int64_t e0, e1;
-    int b, nb;
-    slice_of_block(bc, (int)gridDim.x, n6, n, e0, e1, b, nb);
+    const int n6 = 6 * C;
     double q[kNQ];
 #pragma unroll
     for (int k = 0; k < kNQ; ++k) q[k] = 0.0;
-    for (int64_t e = e0 + b * (int64_t)blockDim.x + threadIdx.x; e < e1; e += (int64_t)nb * blockDim.x) {
-        double d, ge;
-        if (e < n6) {
-            const int c = (int)(e / 6), k = (int)(e % 6);
-            d = Ugc[(size_t)c * 27 + diagU[k]];
-            ge = Ugc[(size_t)c * 27 + 21 + k];
-        } else {
-            const int64_t qq = e - n6;
-            const int p = (int)(qq / 3), k = (int)(qq % 3);
-            d = V[(size_t)p * 6 + diagV[k]];
-            ge = gp[qq];
-        }
-        double s = sqrt(d);
-        if (first) { if (s == 0.0) s = 1.0; } else { s = fmax(s, si[e]); }
-        const double sge = ge / (s * s), xe = x[e];
-        si[e] = s;
-        g[e] = ge;
-        sg[e] = sge;
+    auto element = [&](double d, double ge, double s_old, double xe, double& s, double& sge) {
+        s = sqrt(d);
+        if (first) { if (s == 0.0) s = 1.0; } else { s = fmax(s, s_old); }
+        sge = ge / (s * s);
         q[0] = fmax(q[0], fabs(ge));
         q[1] += (ge / s) * (ge / s);
         q[2] += (xe * s) * (xe * s);
         q[3] += xe * xe;
         q[4] += sge * sge;
+    };
+    if ((int)blockIdx.x < bc) {
+        const int diagU[6] = {0, 6, 11, 15, 18, 20};
+        for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n6; e += bc * blockDim.x) {
+            const int c = e / 6, k = e - 6 * c;
+            const double d = Ugc[(size_t)c * 27 + diagU[k]], ge = Ugc[(size_t)c * 27 + 21 + k];
+            double s, sge;
+            element(d, ge, first ? 0.0 : si[e], x[e], s, sge);
+            si[e] = s; g[e] = ge; sg[e] = sge;
+        }
+    } else {
+        const int nb = (int)gridDim.x - bc, b = (int)blockIdx.x - bc;
+        const double* __restrict__ xp = x + n6;
+        double* __restrict__ sip = si + n6;
+        double* __restrict__ gpo = g + n6;
+        double* __restrict__ sgp = sg + n6;
+        for (int p0 = (b * kScalePts) * (int)blockDim.x + (int)threadIdx.x; p0 < P; p0 += nb * kScalePts * (int)blockDim.x) {
+            double d[kScalePts][3], ge[kScalePts][3], so[kScalePts][3], xe[kScalePts][3];
+#pragma unroll
+            for (int u = 0; u < kScalePts; ++u) {
+                const int p = p0 + u * (int)blockDim.x;
+                const size_t pp = (size_t)(p < P ? p : 0);
+                d[u][0] = V[pp * 6 + 0]; d[u][1] = V[pp * 6 + 3]; d[u][2] = V[pp * 6 + 5];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    ge[u][k] = gp[pp * 3 + k];
+                    xe[u][k] = xp[pp * 3 + k];
+                    so[u][k] = first ? 0.0 : sip[pp * 3 + k];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kScalePts; ++u) {
+                const int p = p0 + u * (int)blockDim.x;
+                if (p >= P) continue;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    double s, sge;
+                    element(d[u][k], ge[u][k], so[u][k], xe[u][k], s, sge);
+                    sip[(size_t)p * 3 + k] = s; gpo[(size_t)p * 3 + k] = ge[u][k]; sgp[(size_t)p * 3 + k] = sge;
+                }
+            }
+        }
     }
     write_partials(q, part);
 }

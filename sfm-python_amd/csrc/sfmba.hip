@@ -15,6 +15,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -325,6 +326,15 @@ struct sfmba_handle {
     Mailbox post{};                          // set while the launch that ends a hand-off is enqueued; else empty
     double* h_x = nullptr;                   // pinned staging of the parameter vector
     size_t h_x_doubles = 0;
+    // The result leaves the device while the solve still runs: every trial point is copied to a pinned mirror of its
+    // buffer on a second stream, behind the launch that wrote it and beside the evaluation of that point, so that the
+    // accepted x of the LAST iteration is already on the host when the solve ends (2.4 MB = 45-60 us at 306k
+    // parameters, otherwise in front of the return).
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_written = nullptr, ev_copied[2] = {nullptr, nullptr};
+    PinnedBuf mirror[2];
+    unsigned long long mirror_tag[2] = {0, 0}, copy_count = 0, x_tag = 0;
+    bool mirror_on = false;
     const double* skip = nullptr;         // device flag gating speculative trial launches (sfmba_solve); else null
     double pcg_tol = 0.0; int pcg_cap = 0; // options of the running PCG (fused launch 0 writes the control block)
     bool pcg_fused = false;               // PCG update fused into the launch of pass A (v in LDS, C <= 1024)
@@ -359,6 +369,7 @@ struct sfmba_handle {
     double* scal() const { return arena + 54 * C; }
     int pcg_L = 0;                           // launches (sweep+update pairs) since pcg_start
     int red_bc = 1, red_grid = 2;            // block split of k_update_scale's reduction (cameras | points)
+    int scale_pts = 1;                       // points per thread of k_update_scale
     double* partB() const { return part.as<double>() + (size_t)kPartRows * kNQ; }
     bool pending_scale_sums = false;         // k_update_scale ran, its final sums ride with the next k_jdot
 };
@@ -924,9 +935,14 @@ int launch_backsub(sfmba_handle* h, int* nparts) {
 // column scale + gradient + q0..q4 of the new iterate (after the normal blocks are complete)
 // `defer`: the final sums are left to ride with the next k_jdot launch (flush_scale_sums if none follows)
 int launch_update_scale(sfmba_handle* h, int first, bool defer = false) {
-    hipLaunchKernelGGL(k_update_scale, dim3(h->red_grid), dim3(256), 0, h->stream, h->Ugc(), h->V.as<double>(),
-                       h->gp.as<double>(), h->x, (int)h->C, (int)h->P, first, h->red_bc, h->si.as<double>(),
-                       h->g.as<double>(), h->sg.as<double>(), h->part.as<double>());
+    if (h->scale_pts == 2)
+        hipLaunchKernelGGL(k_update_scale<2>, dim3(h->red_grid), dim3(256), 0, h->stream, h->Ugc(), h->V.as<double>(),
+                           h->gp.as<double>(), h->x, (int)h->C, (int)h->P, first, h->red_bc, h->si.as<double>(),
+                           h->g.as<double>(), h->sg.as<double>(), h->part.as<double>());
+    else
+        hipLaunchKernelGGL(k_update_scale<1>, dim3(h->red_grid), dim3(256), 0, h->stream, h->Ugc(), h->V.as<double>(),
+                           h->gp.as<double>(), h->x, (int)h->C, (int)h->P, first, h->red_bc, h->si.as<double>(),
+                           h->g.as<double>(), h->sg.as<double>(), h->part.as<double>());
     LAUNCHED(h);
     if (defer) { h->pending_scale_sums = true; return 0; }
     return launch_finish_slices(h, 0, 4);
@@ -992,11 +1008,45 @@ int ensure_h_x(sfmba_handle* h) {
     return 0;
 }
 
+// pageable <-> pinned copy of a parameter vector: a few host threads from 1 MB on (one thread moves 2.4 MB in 85-115 us,
+// which was 9 % of a solve at 306k parameters).  `chunk_done(k, offset, bytes)` (optional) is called on the calling
+// thread, in chunk order, as soon as chunk k has arrived: the upload enqueues that chunk's DMA while the others are
+// still being copied.
+template <class Fn>
+void staging_copy(sfmba_handle* h, void* dst, const void* src, size_t bytes, Fn chunk_done) {
+    const int parts = (int)std::min<size_t>(4, bytes >> 19);
+    if (parts <= 1) { memcpy(dst, src, bytes); chunk_done(0, (size_t)0, bytes); return; }
+    const size_t per = ((bytes + parts - 1) / parts + 63) & ~(size_t)63;
+    std::atomic<int> done[8];
+    for (auto& d : done) d.store(0, std::memory_order_relaxed);
+    h->pool.run(parts, [&](int t) {
+        const size_t b = std::min(bytes, (size_t)t * per), e = std::min(bytes, b + per);
+        if (e > b) memcpy(static_cast<char*>(dst) + b, static_cast<const char*>(src) + b, e - b);
+        if (t != 0) { done[t].store(1, std::memory_order_release); return; }
+        chunk_done(0, b, e - b);
+        for (int k = 1; k < parts; ++k) {
+            while (done[k].load(std::memory_order_acquire) == 0) { }
+            const size_t bk = std::min(bytes, (size_t)k * per), ek = std::min(bytes, bk + per);
+            chunk_done(k, bk, ek - bk);
+        }
+    });
+}
+void staging_copy(sfmba_handle* h, void* dst, const void* src, size_t bytes) {
+    staging_copy(h, dst, src, bytes, [](int, size_t, size_t) {});
+}
+
 int upload_x(sfmba_handle* h, const double* x_host) {
     CHK(ensure_h_x(h));
     HIPCHK(h, hipStreamSynchronize(h->stream));      // the staging buffer may still be in flight
-    memcpy(h->h_x, x_host, sizeof(double) * h->n);
-    HIPCHK(h, hipMemcpyAsync(h->x, h->h_x, sizeof(double) * h->n, hipMemcpyHostToDevice, h->stream));
+    const double t0 = now_s();
+    hipError_t err = hipSuccess;
+    staging_copy(h, h->h_x, x_host, sizeof(double) * h->n, [&](int, size_t off, size_t bytes) {
+        if (bytes == 0 || err != hipSuccess) return;
+        err = hipMemcpyAsync(reinterpret_cast<char*>(h->x) + off, reinterpret_cast<const char*>(h->h_x) + off, bytes,
+                             hipMemcpyHostToDevice, h->stream);
+    });
+    HIPCHK(h, err);
+    if (h->dbg.trace_timing) fprintf(stderr, "sfmba: upload_x  staging copy + enqueue %.1f us\n", 1e6 * (now_s() - t0));
     return 0;
 }
 
@@ -1206,6 +1256,14 @@ int sfmba_create(sfmba_handle** out, int device_id) {
         (void)hipStreamDestroy(h->stream); delete h; return -4;
     }
     memset(h->mbox, 0, sizeof(double) * 64);
+    if (hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess) h->copy_stream = nullptr;
+    if (h->copy_stream &&
+        (hipEventCreateWithFlags(&h->ev_written, hipEventDisableTiming) != hipSuccess ||
+         hipEventCreateWithFlags(&h->ev_copied[0], hipEventDisableTiming) != hipSuccess ||
+         hipEventCreateWithFlags(&h->ev_copied[1], hipEventDisableTiming) != hipSuccess)) {
+        (void)hipStreamDestroy(h->copy_stream);            // (the solve then returns x the plain way)
+        h->copy_stream = nullptr;
+    }
     *out = h;
     return 0;
 }
@@ -1216,6 +1274,9 @@ void sfmba_destroy(sfmba_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->comm) { if (RcclApi* api = rccl_api()) (void)api->CommDestroy(h->comm); h->comm = nullptr; }
     p2p_release(h);
+    if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
+    if (h->ev_written) (void)hipEventDestroy(h->ev_written);
+    for (auto& ev : h->ev_copied) if (ev) (void)hipEventDestroy(ev);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     if (h->h_scal) (void)hipHostFree(h->h_scal);
     if (h->mbox) (void)hipHostFree(h->mbox);
@@ -1925,12 +1986,11 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     HIPCHK(h, h->vtmp.ensure(sizeof(double) * 6 * C));
     HIPCHK(h, h->vcm.ensure(sizeof(double) * 6 * C));
     if (h->sweep_rc_g) HIPCHK(h, h->rctab.ensure(sizeof(double) * kRcRow * (size_t)C));
-    // k_update_scale: a few elements per thread, so that the nine block reductions behind the loop are paid by 256
-    // workgroups instead of 1024 (8.8 -> ~5 us at 306k parameters)
-    // (small problems keep one element per thread: there the launch is latency, not reductions)
-    const int ept = 3 * P > 150000 ? 5 : 1;
-    h->red_bc = grid_1d(6 * C, 256 * (ept > 1 ? 4 : 1), 32);
-    h->red_grid = h->red_bc + grid_1d(3 * P, 256 * ept, 992);   // <= 1024 partial rows, summed by k_jdot's rider workgroup
+    // k_update_scale: cameras one element per thread, points kScalePts points per thread (all loads of a thread in flight
+    // together); at most 1024 partial rows, summed by k_jdot's rider workgroup
+    h->scale_pts = P >= 65536 ? 2 : 1;
+    h->red_bc = grid_1d(6 * C, 256, 32);
+    h->red_grid = h->red_bc + grid_1d(P, 256 * h->scale_pts, 992);
     HIPCHK(h, h->part.ensure(sizeof(double) * (size_t)(2 * kPartRows * kNQ)));
     HIPCHK(h, h->ctrl.ensure(2 * sizeof(PcgCtrl)));
     HIPCHK(h, h->pcg_part.ensure(sizeof(double) * 4 * C));
@@ -2301,6 +2361,7 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
         const std::string msg = h->err;
         h->skip = nullptr; h->post = Mailbox{};
         if (h->stream) (void)hipStreamSynchronize(h->stream);
+        if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
         if (rc == -5 && h->p2p.ready) {
             p2p_close_peers(h);
             if (h->p2p.words) (void)hipMemset(h->p2p.words, 0, 4 * sizeof(unsigned));
@@ -2339,6 +2400,12 @@ static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt
     h->tab = h->tabA.as<double>(); h->tab_new = h->tabB.as<double>();
     h->rec = h->recA.as<double>(); h->rec_new = h->recB.as<double>();
     CHK(upload_x(h, x_inout));
+    h->mirror_on = h->copy_stream != nullptr && n >= 150000;            // (below that the copy is shorter than its three host calls)
+    h->x_tag = 0; h->mirror_tag[0] = h->mirror_tag[1] = 0;
+    if (h->mirror_on) {
+        HIPCHK(h, h->mirror[0].ensure(sizeof(double) * n, 0));
+        HIPCHK(h, h->mirror[1].ensure(sizeof(double) * n, 0));
+    }
     HIPCHK(h, hipMemsetAsync(h->scal() + kGhPrevSlot, 0, 2 * sizeof(double), h->stream));   // forcing-term memory of k_prep
     const double t_dev0 = now_s();
     report_stall(h, "upload_x", t_dev0 - t_begin);
@@ -2503,6 +2570,14 @@ static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt
                                h->sg.as<double>(), h->p.as<double>(), c1, c2, coef_dev, (int)C, n, bc, h->x_new,
                                h->tab_new, h->rec_new, h->skip);
             LAUNCHED(h);
+            if (h->mirror_on) {                                 // x_new to its host mirror, beside the evaluation below
+                const int w = h->x_new == h->xa.as<double>() ? 0 : 1;
+                HIPCHK(h, hipEventRecord(h->ev_written, h->stream));
+                HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->ev_written, 0));
+                HIPCHK(h, hipMemcpyAsync(h->mirror[w].p, h->x_new, sizeof(double) * n, hipMemcpyDeviceToHost, h->copy_stream));
+                HIPCHK(h, hipEventRecord(h->ev_copied[w], h->copy_stream));
+                h->mirror_tag[w] = ++h->copy_count;
+            }
             // the trial point is evaluated WITH its Jacobian, into the same buffers: when
             // the step is accepted (the common case) nothing has to be recomputed
             // The cost reduction that ends the evaluation also posts the hand-off (scalars + PCG control
@@ -2651,6 +2726,7 @@ static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt
             std::swap(h->x, h->x_new);
             std::swap(h->tab, h->tab_new);
             std::swap(h->rec, h->rec_new);
+            h->x_tag = h->mirror_tag[h->x == h->xa.as<double>() ? 0 : 1];      // (0 when no mirror copy was made)
             nb_valid = true;                                    // J, f and the normal blocks of the accepted
                                                                 // point are already there / in flight
             cost = cost_new;
@@ -2680,17 +2756,26 @@ static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt
     }
 
     CHK(ensure_h_x(h));
-    HIPCHK(h, hipMemcpyAsync(h->h_x, h->x, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+    const double t_dl0 = now_s();
+    const int xw = h->x == h->xa.as<double>() ? 0 : 1;
+    const bool mirrored = h->mirror_on && h->x_tag != 0 && h->mirror_tag[xw] == h->x_tag;     // x is on the host already
+    if (!mirrored) HIPCHK(h, hipMemcpyAsync(h->h_x, h->x, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
     if (h->p2p.ready)                                           // did a direct all-reduce give up waiting for a peer?
         HIPCHK(h, hipMemcpyAsync(h->h_scal + 62, h->p2p.words + 1, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
     CHK(wait_stream(h));
+    if (mirrored) HIPCHK(h, hipEventSynchronize(h->ev_copied[xw]));
+    const double t_dl1 = now_s();
     if (h->p2p.ready) {
         unsigned err = 0;
         memcpy(&err, h->h_scal + 62, sizeof err);
         if (err != 0) return fail(h, -5, "a direct all-reduce timed out waiting for a peer rank");
     }
-    memcpy(x_inout, h->h_x, sizeof(double) * n);
+    staging_copy(h, x_inout, mirrored ? h->mirror[xw].p : (const void*)h->h_x, sizeof(double) * n);
+    if (h->mirror_on) HIPCHK(h, hipStreamSynchronize(h->copy_stream));     // (a copy of a rejected last trial may still run)
     const double t_end = now_s();
+    if (h->dbg.trace_timing)
+        fprintf(stderr, "sfmba: solve  %.3f ms total, upload %.1f us, result: copy + wait %.1f us, staging copy %.1f us\n", 1e3 * (t_end - t_begin),
+                1e6 * (t_dev0 - t_begin), 1e6 * (t_dl1 - t_dl0), 1e6 * (t_end - t_dl1));
     if (!evs.empty()) {
         double tot = 0.0;
         for (auto& pr : evs) {
