@@ -326,10 +326,13 @@ struct sfmba_handle {
     Mailbox post{};                          // set while the launch that ends a hand-off is enqueued; else empty
     double* h_x = nullptr;                   // pinned staging of the parameter vector
     size_t h_x_doubles = 0;
-    // The result leaves the device while the solve still runs: every trial point is copied to a pinned mirror of its
-    // buffer on a second stream, behind the launch that wrote it and beside the evaluation of that point, so that the
-    // accepted x of the LAST iteration is already on the host when the solve ends (2.4 MB = 45-60 us at 306k
-    // parameters, otherwise in front of the return).
+    // Large problems (>= 2M parameters): the result leaves the device while the solve still runs -- every trial point is
+    // copied to a pinned mirror of its buffer on a second stream, behind the launch that wrote it and beside the
+    // evaluation of that point, so that the accepted x of the LAST iteration is already on the host when the solve ends
+    // (24 MB = 0.45 ms at 3M parameters).  Not below that size: there the runtime performs the copy as a blit KERNEL,
+    // which shares the CUs with the residual + Jacobian kernel it overlaps (K1 30 -> 32 us at 306k parameters, 60 us
+    // under rocprofv3).  (Also tried there: the result in four chunks whose staging copies overlap the later chunks'
+    // DMA -- 145 us against 130-150 us for one copy + a four-thread staging copy: four blit launches, no gain.)
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_written = nullptr, ev_copied[2] = {nullptr, nullptr};
     PinnedBuf mirror[2];
@@ -1256,7 +1259,11 @@ int sfmba_create(sfmba_handle** out, int device_id) {
         (void)hipStreamDestroy(h->stream); delete h; return -4;
     }
     memset(h->mbox, 0, sizeof(double) * 64);
-    if (hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess) h->copy_stream = nullptr;
+    {   // lowest priority: where the copy runs as a kernel its waves yield to the evaluation it overlaps
+        int prio_low = 0, prio_high = 0;
+        if (hipDeviceGetStreamPriorityRange(&prio_low, &prio_high) != hipSuccess) prio_low = 0;
+        if (hipStreamCreateWithPriority(&h->copy_stream, hipStreamNonBlocking, prio_low) != hipSuccess) h->copy_stream = nullptr;
+    }
     if (h->copy_stream &&
         (hipEventCreateWithFlags(&h->ev_written, hipEventDisableTiming) != hipSuccess ||
          hipEventCreateWithFlags(&h->ev_copied[0], hipEventDisableTiming) != hipSuccess ||
@@ -2400,7 +2407,7 @@ static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt
     h->tab = h->tabA.as<double>(); h->tab_new = h->tabB.as<double>();
     h->rec = h->recA.as<double>(); h->rec_new = h->recB.as<double>();
     CHK(upload_x(h, x_inout));
-    h->mirror_on = h->copy_stream != nullptr && n >= 150000;            // (below that the copy is shorter than its three host calls)
+    h->mirror_on = h->copy_stream != nullptr && n >= 2000000;           // (see the note at copy_stream)
     h->x_tag = 0; h->mirror_tag[0] = h->mirror_tag[1] = 0;
     if (h->mirror_on) {
         HIPCHK(h, h->mirror[0].ensure(sizeof(double) * n, 0));
@@ -2759,7 +2766,8 @@ static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt
     const double t_dl0 = now_s();
     const int xw = h->x == h->xa.as<double>() ? 0 : 1;
     const bool mirrored = h->mirror_on && h->x_tag != 0 && h->mirror_tag[xw] == h->x_tag;     // x is on the host already
-    if (!mirrored) HIPCHK(h, hipMemcpyAsync(h->h_x, h->x, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+    const size_t xbytes = sizeof(double) * (size_t)n;
+    if (!mirrored) HIPCHK(h, hipMemcpyAsync(h->h_x, h->x, xbytes, hipMemcpyDeviceToHost, h->stream));
     if (h->p2p.ready)                                           // did a direct all-reduce give up waiting for a peer?
         HIPCHK(h, hipMemcpyAsync(h->h_scal + 62, h->p2p.words + 1, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
     CHK(wait_stream(h));
@@ -2770,7 +2778,7 @@ static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt
         memcpy(&err, h->h_scal + 62, sizeof err);
         if (err != 0) return fail(h, -5, "a direct all-reduce timed out waiting for a peer rank");
     }
-    staging_copy(h, x_inout, mirrored ? h->mirror[xw].p : (const void*)h->h_x, sizeof(double) * n);
+    staging_copy(h, x_inout, mirrored ? h->mirror[xw].p : (const void*)h->h_x, xbytes);
     if (h->mirror_on) HIPCHK(h, hipStreamSynchronize(h->copy_stream));     // (a copy of a rejected last trial may still run)
     const double t_end = now_s();
     if (h->dbg.trace_timing)
