@@ -188,6 +188,9 @@ int  sfmba_residual_jacobian(sfmba_handle* h, const double* x, double* r_out, do
 /* ---- least_squares(method='trf', x_scale='jac') (sfm.py:266-268) ---------------------------- */
 /* x_inout: x0 on entry, result.x on success (untouched on failure). */
 int  sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt, sfmba_result* out);
+/* The same with the start and the result in separate arrays (x_out may be x0): a caller that keeps x0 -- scipy's
+   least_squares does not modify its argument -- saves the copy it would otherwise make for the in/out form. */
+int  sfmba_solve_from(sfmba_handle* h, const double* x0, double* x_out, const sfmba_options* opt, sfmba_result* out);
 /* After a successful sfmba_solve: result.fun (2N) and result.grad (6C+3P); either may be NULL. */
 int  sfmba_get_fun_grad(sfmba_handle* h, double* fun_out, double* grad_out);
 

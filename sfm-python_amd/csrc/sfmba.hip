@@ -2266,17 +2266,17 @@ int sfmba_time_kernel(sfmba_handle* h, const double* x, int32_t which, int32_t r
     return 0;
 }
 
-static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, sfmba_result* out);
+static int solve_impl(sfmba_handle* h, const double* x_start, double* x_inout, const sfmba_options* opt_in, sfmba_result* out);
 
 // The whole solve as one launch (small_solve.hpp): upload x0, one kernel, read back x and one result block.
 constexpr int kSmallRetry = 1000;             // (internal) the launch did not run to its end: use the multi-launch loop
-static int solve_small(sfmba_handle* h, double* x_inout, const sfmba_options& opt, sfmba_result* out) {
+static int solve_small(sfmba_handle* h, const double* x_start, double* x_inout, const sfmba_options& opt, sfmba_result* out) {
     const double t_begin = now_s();
     const int64_t C = h->C, P = h->P, N = h->N, n = h->n;
     h->x = h->xa.as<double>(); h->x_new = h->xb.as<double>();
     h->tab = h->tabA.as<double>(); h->tab_new = h->tabB.as<double>();
     h->rec = h->recA.as<double>(); h->rec_new = h->recB.as<double>();
-    CHK(upload_x(h, x_inout));
+    CHK(upload_x(h, x_start));
     const double t_dev0 = now_s();
     double* part = h->sm_work.as<double>();
     double* outd = part + (size_t)kSmallMaxG * kSmallPartCols;
@@ -2360,7 +2360,11 @@ static int solve_small(sfmba_handle* h, double* x_inout, const sfmba_options& op
 }
 
 int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, sfmba_result* out) {
-    const int rc = solve_impl(h, x_inout, opt_in, out);
+    return sfmba_solve_from(h, x_inout, x_inout, opt_in, out);
+}
+
+int sfmba_solve_from(sfmba_handle* h, const double* x0, double* x_out, const sfmba_options* opt_in, sfmba_result* out) {
+    const int rc = solve_impl(h, x0, x_out, opt_in, out);
     if (rc != 0 && h) {
         // Leave the handle reusable: drain what was enqueued (speculative launches may still be in flight) and,
         // after a collective failure, unmap the peers -- sequence numbers no longer agree across ranks, so the
@@ -2378,9 +2382,10 @@ int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, s
     return rc;
 }
 
-static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, sfmba_result* out) {
+static int solve_impl(sfmba_handle* h, const double* x_start, double* x_inout, const sfmba_options* opt_in, sfmba_result* out) {
     CHK(enter(h));
-    CHK(check_ready(h, x_inout));
+    CHK(check_ready(h, x_start));
+    if (!x_inout) return fail(h, -1, "x_out is NULL");
     if (!out) return fail(h, -1, "result is NULL");
     sfmba_options opt;
     if (opt_in) opt = *opt_in; else sfmba_default_options(&opt);
@@ -2392,7 +2397,7 @@ static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt
     // small problems (the size the reference itself produces): the whole loop below as ONE launch.  The multi-launch loop
     // stays for per-iteration output (verbose = 2), K1 timing events and the PCG trace.
     if (h->small && h->small_fail < 2 && !multi_rank(h) && opt.verbose < 2 && !opt.profile && h->dbg.trace_pcg == 0) {
-        const int rc = solve_small(h, x_inout, opt, out);
+        const int rc = solve_small(h, x_start, x_inout, opt, out);
         if (rc != kSmallRetry) return rc;
         memset(out, 0, sizeof *out);
     }
@@ -2406,7 +2411,7 @@ static int solve_impl(sfmba_handle* h, double* x_inout, const sfmba_options* opt
     h->x = h->xa.as<double>(); h->x_new = h->xb.as<double>();
     h->tab = h->tabA.as<double>(); h->tab_new = h->tabB.as<double>();
     h->rec = h->recA.as<double>(); h->rec_new = h->recB.as<double>();
-    CHK(upload_x(h, x_inout));
+    CHK(upload_x(h, x_start));
     h->mirror_on = h->copy_stream != nullptr && n >= 2000000;           // (see the note at copy_stream)
     h->x_tag = 0; h->mirror_tag[0] = h->mirror_tag[1] = 0;
     if (h->mirror_on) {

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("SFMBA_LIB") or os.path.join(_HERE, "libsfmba.so")   #
 SYMBOLS = (
     "sfmba_create", "sfmba_destroy", "sfmba_last_error", "sfmba_default_options", "sfmba_set_stream",
     "sfmba_set_problem", "sfmba_set_problem_i64", "sfmba_exchange_doubles", "sfmba_set_exchange", "sfmba_residuals",
-    "sfmba_residual_jacobian", "sfmba_solve", "sfmba_get_fun_grad", "sfmba_time_kernel",
+    "sfmba_residual_jacobian", "sfmba_solve", "sfmba_solve_from", "sfmba_get_fun_grad", "sfmba_time_kernel",
     "sfmba_normal_blocks", "sfmba_schur_matvec", "sfmba_comm_get_unique_id", "sfmba_comm_init",
     "sfmba_comm_destroy", "sfmba_set_precision", "sfmba_p2p_export", "sfmba_p2p_attach", "sfmba_p2p_detach",
     "sfmba_p2p_calls", "sfmba_tr2d_solve", "sfmba_debug_option", "sfmba_set_print", "sfmba_get_counters", "sfmba_problem_reuse", "sfmba_dense_schur",
@@ -75,6 +75,7 @@ def load():
     lib.sfmba_residuals.argtypes = [P, P, P]
     lib.sfmba_residual_jacobian.argtypes = [P, P, P, P, P]
     lib.sfmba_solve.argtypes = [P, P, C.POINTER(Options), C.POINTER(Result)]
+    lib.sfmba_solve_from.argtypes = [P, P, P, C.POINTER(Options), C.POINTER(Result)]
     lib.sfmba_get_fun_grad.argtypes = [P, P, P]
     lib.sfmba_time_kernel.argtypes = [P, P, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
     lib.sfmba_normal_blocks.argtypes = [P, P, P, P, P, P]
@@ -101,7 +102,7 @@ def load():
     lib.sfmba_p2p_calls.argtypes = [P]
     lib.sfmba_p2p_calls.restype = C.c_int64
     for name in ("sfmba_set_stream", "sfmba_set_problem", "sfmba_set_problem_i64", "sfmba_set_exchange", "sfmba_residuals",
-                 "sfmba_residual_jacobian", "sfmba_solve", "sfmba_get_fun_grad", "sfmba_time_kernel",
+                 "sfmba_residual_jacobian", "sfmba_solve", "sfmba_solve_from", "sfmba_get_fun_grad", "sfmba_time_kernel",
                  "sfmba_normal_blocks", "sfmba_schur_matvec", "sfmba_tr2d_solve", "sfmba_comm_get_unique_id",
                  "sfmba_comm_init", "sfmba_comm_destroy", "sfmba_set_precision", "sfmba_p2p_export",
                  "sfmba_p2p_attach", "sfmba_p2p_detach", "sfmba_debug_option"):

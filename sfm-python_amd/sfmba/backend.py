@@ -281,9 +281,10 @@ class Backend:
         """-> (x, result struct, fun, grad).  fun / grad not wanted stay on the device: `fetch_fun_grad` gets them
         until the next operation on this handle."""
         self._flush_pending()
-        x = np.array(_f64(x0, (self.n_params,), "x0"), copy=True)
+        x_start = _f64(x0, (self.n_params,), "x0")
+        x = np.empty_like(x_start)               # start and result in separate arrays: no copy of x0 on the way in
         opt = options if options is not None else self.default_options()
         res = _capi.Result()
-        self._check(self._lib.sfmba_solve(self._h, _capi.ptr(x), C.byref(opt), C.byref(res)))
+        self._check(self._lib.sfmba_solve_from(self._h, _capi.ptr(x_start), _capi.ptr(x), C.byref(opt), C.byref(res)))
         fun, grad = self.fetch_fun_grad(want_fun, want_grad)
         return x, res, fun, grad
