@@ -918,12 +918,6 @@ struct StepTable {
 // [0, bc) of the grid cover the cameras, blocks [bc, grid) the points; one partial row per block.
 //   q0 = max|g|   q1 = sum (g/si)^2   q2 = sum (x si)^2   q3 = sum x^2   q4 = sum (g/si^2)^2
 //   q5 = sum g p  q6 = sum (p si)^2   q7 = sum (g/si^2) p q8 = sum p^2
-__device__ __forceinline__ void slice_of_block(int bc, int nblocks, int64_t n6, int64_t n, int64_t& e0,
-                                               int64_t& e1, int& b, int& nb) {
-    if ((int)blockIdx.x < bc) { e0 = 0; e1 = n6; b = blockIdx.x; nb = bc; }
-    else { e0 = n6; e1 = n; b = blockIdx.x - bc; nb = nblocks - bc; }
-}
-
 __device__ __forceinline__ void write_partials(double (&q)[kNQ], double* __restrict__ part) {
     __shared__ double red[4 * kNQ];
     __shared__ double mred[4];
