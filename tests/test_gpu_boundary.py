@@ -366,3 +366,29 @@ def test_result_fun_and_grad_stay_on_the_device_until_read(orc):
     rf = pickle.loads(pickle.dumps(run(pa)))
     assert np.array_equal(rf.fun, fa) and rf.status == ra.status
     assert "fun:" in repr(run(pa))
+
+
+def test_in_out_and_separate_array_forms_of_the_solve_agree():
+    """include/sfmba.h: sfmba_solve(h, x_inout, ...) is sfmba_solve_from(h, x0, x_out, ...) with both pointers equal; the
+    start array of the separate form is left untouched (scipy's least_squares does not modify its x0 either)."""
+    import ctypes as C
+    import sfmba
+    from sfmba import _capi
+    pb = sfmba.make_problem(30, 400, 3000, seed=4)
+    be = sfmba.Backend(0)
+    try:
+        be.set_problem(*pb.args)
+        opt = be.default_options()
+        opt.ftol = 1e-10
+        x0 = pb.x0.copy()
+        x_sep, res_sep, _, _ = be.solve(x0, opt, want_fun=False, want_grad=False)          # separate arrays
+        assert np.array_equal(x0, pb.x0)
+        x_io = pb.x0.copy()
+        res_io = _capi.Result()
+        assert be._lib.sfmba_solve(be._h, _capi.ptr(x_io), C.byref(opt), C.byref(res_io)) == 0      # in/out
+        assert np.array_equal(x_io, x_sep)
+        assert (res_io.status, res_io.nfev, res_io.njev, res_io.cost) == (res_sep.status, res_sep.nfev, res_sep.njev, res_sep.cost)
+        null = _capi.Result()
+        assert be._lib.sfmba_solve_from(be._h, _capi.ptr(x0), None, C.byref(opt), C.byref(null)) == -1      # x_out is NULL
+    finally:
+        be.close()
