@@ -135,6 +135,14 @@ int  sfmba_set_problem_i64(sfmba_handle* h, int64_t n_cameras, int64_t n_points,
                            const int64_t* camera_indices, const int64_t* point_indices,
                            const int64_t* points_2d, const double* K);
 
+/* Cameras held still: the `fixed_camera_indices` of create_sparsity_matrix (bundle_adjustment.py:6,13-14), whose six
+ * Jacobian columns the pattern leaves empty -- scipy's finite differences then never fill them, so the gradient, the
+ * step and hence the parameters of those cameras stay as they are, and x_scale='jac' gives them scale 1
+ * (SCIPY/optimize/_lsq/common.py:598-610).  The list is read at the NEXT sfmba_set_problem and stays in force until
+ * it is replaced (n_fixed = 0 clears it); indices are range-checked there.  Their observations still count in the
+ * residual, the cost and the point blocks. */
+int  sfmba_set_fixed_cameras(sfmba_handle* h, const int64_t* camera_indices, int64_t n_fixed);
+
 /* Observation sharding: this handle holds the local shard (its own points + their observations,
  * all cameras replicated); n_obs_total counts all shards.  `arena` is device memory of at least
  * sfmba_exchange_doubles(n_cameras) doubles that `fn` can all-reduce (e.g. a torch tensor).

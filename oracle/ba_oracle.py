@@ -414,7 +414,8 @@ class TRFResult:
 
 def trf_schur(x0, n_cameras, n_points, camera_indices, point_indices, points_2d, K,
               ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None, linear="dense",
-              pcg_tol=1e-10, precond="block_u", reg_min=1e-6, verbose=0, comm=None, pcg_tol_max=None):
+              pcg_tol=1e-10, precond="block_u", reg_min=1e-6, verbose=0, comm=None, pcg_tol_max=None,
+              fixed_cameras=()):
     """Restatement of trf_no_bounds(tr_solver='lsmr', x_scale='jac', loss='linear').
 
     ``pcg_tol_max`` (> ``pcg_tol``): the forcing term of the PCG adapts to the outer iteration as the HIP path's
@@ -425,6 +426,10 @@ def trf_schur(x0, n_cameras, n_points, camera_indices, point_indices, points_2d,
     is the minimiser of |J_h p + f|^2 + reg |p|^2 through the Schur complement, not an LSMR iterate,
     and J is analytic rather than forward-differenced.  The 2-D subspace of trf.py:481-485 is
     orthonormalised by Gram-Schmidt from dot products (as the HIP path does) instead of numpy's QR.
+
+    ``fixed_cameras``: the ``fixed_camera_indices`` of REF bundle_adjustment.py:6,13-14 -- the pattern handed to
+    scipy leaves their camera columns empty, so its finite-difference Jacobian has zeros there (_numdiff.py:628-705
+    only fills the pattern): restated by zeroing the camera blocks of their observations.
 
     ``comm`` (test infrastructure for the N>1 path): when given, (camera_indices, ...) describe ONE
     SHARD -- all cameras, the shard's own points and observations -- and every reduction the HIP path
@@ -445,8 +450,12 @@ def trf_schur(x0, n_cameras, n_points, camera_indices, point_indices, points_2d,
     def dot(a, b):                   # camera slice is replicated, point slice is summed over shards
         return float(a[:n6] @ b[:n6]) + float(comm.sum(float(a[n6:] @ b[n6:])))
 
+    held = np.isin(ci, np.asarray(list(fixed_cameras), dtype=np.int64))
+
     def linearise(x):
         r, Jc, Jp = jacobian_blocks(x, *args)
+        if held.any():
+            Jc[held] = 0.0
         nb = normal_blocks(r, Jc, Jp, C, P, ci, pi)
         nb.U = comm.sum(nb.U)
         nb.gc = comm.sum(nb.gc)
@@ -593,6 +602,71 @@ def trf_schur(x0, n_cameras, n_points, camera_indices, point_indices, points_2d,
         status = 0
     return TRFResult(x=x, cost=cost, fun=r.ravel(), grad=g, optimality=g_norm, nfev=nfev,
                      njev=njev, status=status, history=history)
+
+
+# --------------------------------------------------------------------------------------------
+# gauge alignment: comparing parameter vectors of two solvers ("gauge-aligned parameters")
+# --------------------------------------------------------------------------------------------
+
+
+def multi_view_points(n_cameras, n_points, camera_indices, point_indices, min_views=2):
+    """Mask of the points seen by at least ``min_views`` DISTINCT cameras.  A point seen by one camera only has no
+    defined depth (its 3x3 block has rank 2: it can slide along its ray at no cost), so two minimisers agree on
+    everything except where such points sit; parameter comparisons are made on the others."""
+    key = np.unique(np.asarray(point_indices, dtype=np.int64) * n_cameras + np.asarray(camera_indices, dtype=np.int64))
+    return np.bincount(key // n_cameras, minlength=n_points) >= min_views
+
+
+def similarity_align(x_src, x_dst, n_cameras, n_points, fit_points=None):
+    """No camera is held fixed in the reference's call (REF bundle_adjustment.py:6, sfm.py:264), so the residual
+    pi(K R_c (X - T_c)) is invariant under the 7-dof similarity X -> s R X + t, T_c -> s R T_c + t, R_c -> R_c R^T:
+    two minimisers of the same problem may differ by one.  Fits (s, R, t) on the POINTS (least squares, Umeyama's
+    closed form; ``fit_points``: bool mask of the points to fit on, see multi_view_points) so that the mapped
+    ``x_src`` is closest to ``x_dst`` and returns the mapped parameter vector together with (s, R, t)."""
+    n6 = 6 * n_cameras
+    A = np.asarray(x_src[n6:], dtype=np.float64).reshape(n_points, 3)
+    B = np.asarray(x_dst[n6:], dtype=np.float64).reshape(n_points, 3)
+    sel = np.ones(n_points, dtype=bool) if fit_points is None else np.asarray(fit_points, dtype=bool)
+    ma, mb = A[sel].mean(axis=0), B[sel].mean(axis=0)
+    A0, B0 = A[sel] - ma, B[sel] - mb
+    n_fit = int(sel.sum())
+    Uu, Sv, Vt = np.linalg.svd(B0.T @ A0 / n_fit)
+    d = np.ones(3)
+    if np.linalg.det(Uu) * np.linalg.det(Vt) < 0:
+        d[2] = -1.0
+    R = Uu @ np.diag(d) @ Vt
+    s = float(np.sum(Sv * d) / (np.sum(A0 * A0) / n_fit))
+    t = mb - s * R @ ma
+    cams = np.asarray(x_src[:n6], dtype=np.float64).reshape(n_cameras, 6)
+    out = np.empty_like(np.asarray(x_src, dtype=np.float64))
+    oc = out[:n6].reshape(n_cameras, 6)
+    Rc = rodrigues(cams[:, :3])
+    for c in range(n_cameras):
+        oc[c, :3] = rotvec_from_matrix(Rc[c] @ R.T)
+        oc[c, 3:] = s * R @ cams[c, 3:] + t
+    out[n6:] = (s * A @ R.T + t).ravel()
+    return out, (s, R, t)
+
+
+def parameter_distance(x_a, x_b, n_cameras, n_points, observed_cameras=None, points=None):
+    """How far apart two parameter vectors of one problem are, in the units a user reads them in: RMS and maximum
+    distance of corresponding points (``points``: bool mask, see multi_view_points), maximum distance of camera
+    centres, maximum angle (degrees) between camera rotations.  Cameras nobody observes carry no information and can be
+    left out (``observed_cameras``: bool mask)."""
+    n6 = 6 * n_cameras
+    ca = np.asarray(x_a[:n6]).reshape(n_cameras, 6)
+    cb = np.asarray(x_b[:n6]).reshape(n_cameras, 6)
+    pa = np.asarray(x_a[n6:]).reshape(n_points, 3)
+    pb = np.asarray(x_b[n6:]).reshape(n_points, 3)
+    keep = np.ones(n_cameras, dtype=bool) if observed_cameras is None else np.asarray(observed_cameras, dtype=bool)
+    dp = np.linalg.norm(pa - pb, axis=1)
+    if points is not None:
+        dp = dp[np.asarray(points, dtype=bool)]
+    dR = np.einsum("cij,ckj->cik", rodrigues(ca[:, :3]), rodrigues(cb[:, :3]))
+    ang = np.degrees(np.arccos(np.clip(0.5 * (np.trace(dR, axis1=1, axis2=2) - 1.0), -1.0, 1.0)))
+    return dict(points_rms=float(np.sqrt(np.mean(dp ** 2))), points_max=float(dp.max()),
+                centres_max=float(np.linalg.norm(ca[keep, 3:] - cb[keep, 3:], axis=1).max()),
+                rot_deg_max=float(ang[keep].max()))
 
 
 # --------------------------------------------------------------------------------------------

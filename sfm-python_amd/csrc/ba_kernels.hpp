@@ -2375,7 +2375,7 @@ __device__ __forceinline__ double dense_rcp(double d) {         // v_rcp_f64 + o
     const double y = __builtin_amdgcn_rcp(d);
     return fma(fma(-d, y, 1.0), y, y);
 }
-// The solve itself, shared by k_dense_pcg and the one-launch solver of small problems (small_solve.hpp): A = the
+// The solve itself (the body of k_dense_pcg): A = the
 // workgroup's LDS region (matrix | r u | 6x6 inverses | reduction slots), blk_load(e) = entry e of the block list,
 // x_store(camera, k, value) takes the step; Ugc / Dc / acc may live in global memory or in LDS.  Every thread of the
 // 512 returns the same control block.
@@ -2939,10 +2939,20 @@ struct P2pArgs {
 };
 
 #ifdef SFMBA_P2P_NOFENCE      // experiment only: what the system-scope fences of the collectives cost
+#ifndef SFMBA_EXPERIMENT
+#error "SFMBA_P2P_NOFENCE builds collectives that are formally unordered: measurement builds only (-DSFMBA_EXPERIMENT)"
+#endif
 #define P2P_FENCE() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
 #else
 #define P2P_FENCE() __threadfence_system()
 #endif
+// Arrival ticket of a collective's workgroups.  Acquire + release (agent scope): every workgroup's slot stores are
+// fenced (system-scope release) BEFORE its ticket, and the last arriver's read of the ticket ACQUIRES them, so that its
+// release store of the peer flag orders all workgroups' slots -- not only its own -- before the flag.  (Round 3 used a
+// relaxed RMW here: correct on gfx950 only because system-scope stores are acknowledged at vmcnt(0).)
+__device__ __forceinline__ unsigned p2p_take_ticket(unsigned* ticket) {
+    return __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+}
 // The collective itself, for the workgroups of one launch (any block size; slices by blockIdx).
 __device__ __forceinline__ void p2p_allreduce_body(double* __restrict__ vec, int count, int op, const P2pArgs& a) {
     __shared__ unsigned s_last;
@@ -2958,10 +2968,10 @@ __device__ __forceinline__ void p2p_allreduce_body(double* __restrict__ vec, int
     }
     P2P_FENCE();
     __syncthreads();
-    if (tid == 0) s_last = (atomicAdd(a.ticket, 1u) == gridDim.x - 1) ? 1u : 0u;
+    if (tid == 0) s_last = (p2p_take_ticket(a.ticket) == gridDim.x - 1) ? 1u : 0u;
     __syncthreads();
-    if (s_last != 0u) {                          // (every workgroup fenced its stores before its ticket; the flag's
-        if (tid < a.world)                       // release store is the last workgroup's own fence)
+    if (s_last != 0u) {                          // (every workgroup fenced its stores before its ticket, the last one
+        if (tid < a.world)                       // ACQUIRES them with its ticket; the flag's release store publishes all)
             __hip_atomic_store(a.flags[tid] + ((size_t)par * a.world + a.rank) * kP2pFlagStride, seq,
                                __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         if (tid == 0) { *a.ticket = 0u; *a.seq = seq; }
@@ -3090,7 +3100,7 @@ __global__ __launch_bounds__(kP2pPcgThreads) void k_p2p_pcg(double* __restrict__
         }
         P2P_FENCE();
         __syncthreads();
-        if (tid == 0) s_last = (atomicAdd(a.ticket, 1u) == gridDim.x - 1) ? 1u : 0u;
+        if (tid == 0) s_last = (p2p_take_ticket(a.ticket) == gridDim.x - 1) ? 1u : 0u;
         __syncthreads();
         if (s_last != 0u) {
             if (tid < a.world)

@@ -32,7 +32,6 @@
 
 #include "ba_kernels.hpp"
 #include "tr2d.hpp"
-#include "small_solve.hpp"
 
 using namespace sfmba;
 
@@ -224,6 +223,8 @@ struct sfmba_handle {
     int n_ranges = 0;
     bool f32 = false;                        // fp32 storage of uv, r, t1 and the Jacobian (arithmetic stays fp64)
     bool f32_next = false;                   // takes effect at the next sfmba_set_problem
+    std::vector<int64_t> fixed_next;         // sfmba_set_fixed_cameras: cameras held still from the next sfmba_set_problem on
+    int64_t n_fixed = 0;                     // ... of the current problem
     bool lds_tab = true, lds_vec = true;     // camera table (K1, K2) / camera vector (sweeps) staged in LDS
     bool sweep_rc = false;                   // pass A recomputes the blocks from an LDS table (k_point_sweep_rc)
     bool sweep_rc_g = false;                 // ... from a table in global memory (more cameras than the LDS holds)
@@ -231,14 +232,6 @@ struct sfmba_handle {
     bool dense = false;                      // reduced camera matrix formed and factorised (6 C <= kDenseMaxN) instead of PCG
     DevView cov_ptr, cov_pt, blk_ab;         // dense path: per block pair (a <= b) the points both cameras see
     DevBuf Sblk;
-    // the whole solve as ONE launch (small_solve.hpp): <= 16384 observations / points, few cameras, one rank, fp64
-    bool small = false;
-    int small_G = 0, small_E = 0;
-    int small_fail = 0;                      // launches whose workgroups did not all become resident (see solve_small)
-    DevView sm_cm_cam, sm_cov_key, sm_wsegP, sm_ptrP, sm_wsegC, sm_ptrC, sm_wsegS, sm_ptrS;
-    int sm_nsegP = 0, sm_nsegC = 0, sm_nsegS = 0;
-    DevBuf sm_rows, sm_work;                 // segment rows | partial rows, barrier words, result block
-    std::vector<int> host_sm[8];             // host copies of the eight tables above (kept for the upload)
     DevBuf tables;                           // ranges | wsteps | steps | chunk table | chunk offsets | pair lists: ONE upload
     int n_blk = 0;
     // test / diagnostic hooks, set through sfmba_debug_option only (nothing reads the environment)
@@ -247,8 +240,6 @@ struct sfmba_handle {
         int tab_lds = -1, vec_lds = -1;      // 0: camera table / camera vector read from L2 although LDS would fit
         int sweep_rc = -1;                   // 0: pass A reads the stored Jacobian although the recomputing form would fit
         int dense = -1;                      // 0: PCG although the dense reduced-camera path would apply
-        int small = -1;                      // 0: the multi-launch loop although the one-launch solver would apply
-        int small_agent = 0;                 // 1: the one-launch solver with agent-scope barriers (test)
         int precond = -1;                    // 0: block-Jacobi preconditioner from U + Dc instead of the Schur diagonal
         int pcg_local = -1;                  // 0: the fused PCG keeps its whole update in pass A's prologue
         int xcd_chunks = -1;                 // 1 / 0: camera lists cut at the eight point-range boundaries (one chunk per XCD) whatever the size
@@ -1253,7 +1244,7 @@ int sfmba_create(sfmba_handle** out, int device_id) {
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) h->n_cu = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return -3; }
     h->own_stream = true;
-    if (hipHostMalloc((void**)&h->h_scal, sizeof(double) * (64 + kSmallOut), hipHostMallocDefault) != hipSuccess ||
+    if (hipHostMalloc((void**)&h->h_scal, sizeof(double) * 64, hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&h->mbox, sizeof(double) * 64, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&h->mbox_dev, h->mbox, 0) != hipSuccess) {
         (void)hipStreamDestroy(h->stream); delete h; return -4;
@@ -1317,8 +1308,6 @@ int sfmba_debug_option(sfmba_handle* h, const char* name, int64_t value) {
     if (n == "pcg_fused") h->dbg.pcg_fused = v;
     else if (n == "sweep_rc") h->dbg.sweep_rc = v;
     else if (n == "dense") h->dbg.dense = v;
-    else if (n == "small") h->dbg.small = v;
-    else if (n == "small_agent") h->dbg.small_agent = v;
     else if (n == "precond") h->dbg.precond = v;
     else if (n == "pcg_local") h->dbg.pcg_local = v;
     else if (n == "pcg_split") h->dbg.pcg_split = v;
@@ -1343,6 +1332,13 @@ int sfmba_set_precision(sfmba_handle* h, int32_t storage_bits) {
     CHK(enter(h));
     if (storage_bits != 64 && storage_bits != 32) return fail(h, -1, "storage_bits must be 64 or 32");
     h->f32_next = storage_bits == 32;
+    return 0;
+}
+
+int sfmba_set_fixed_cameras(sfmba_handle* h, const int64_t* camera_indices, int64_t n_fixed) {
+    CHK(enter(h));
+    if (n_fixed < 0 || (n_fixed > 0 && !camera_indices)) return fail(h, -1, "bad fixed-camera list");
+    h->fixed_next.assign(camera_indices, camera_indices + n_fixed);
     return 0;
 }
 
@@ -1568,6 +1564,20 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
         return fail(h, -1, "problem too large for 32-bit observation indices");
     for (int k = 0; k < 9; ++k)
         if (!std::isfinite(K[k])) return fail(h, -1, "K is not finite");
+    // Cameras held still (create_sparsity_matrix(..., fixed_camera_indices), bundle_adjustment.py:6,13-14: their six
+    // Jacobian columns are structurally zero, so scipy's finite differences leave them zero, the gradient and the
+    // step of those parameters are zero and x_scale='jac' gives them scale 1).  Here: their observations are left out
+    // of the CAMERA-MAJOR lists (and of the block-pair lists of the few-camera path), so every per-camera sum --
+    // U_c, g_c, the reduced right-hand side, the Schur-diagonal block, the product of pass B -- is empty for them,
+    // exactly as for a camera nobody observes; the point-major sweeps keep the observations (residual, cost, V_p,
+    // g_p) and only ever multiply the camera part of their Jacobian with a camera vector that stays zero.
+    std::vector<char> fixed((size_t)C, 0);
+    for (int64_t c : h->fixed_next) {
+        if (c < 0 || c >= C) return fail(h, -1, "fixed camera index %lld out of range [0,%lld)", (long long)c, (long long)C);
+        fixed[(size_t)c] = 1;
+    }
+    h->n_fixed = 0;
+    for (char f : fixed) h->n_fixed += f;
     // A new problem returns the handle to single-process operation: every transport (direct link, RCCL
     // communicator, callback) is torn down and has to be set up again after this call (include/sfmba.h).  The
     // staging buffer of the direct link stays allocated until sfmba_p2p_detach / _export / _destroy, because
@@ -1628,7 +1638,7 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
                 double u0, u1;
                 if (uv) { u0 = uv[2 * s]; u1 = uv[2 * s + 1]; }
                 else { u0 = (double)uv_i64[2 * s]; u1 = (double)uv_i64[2 * s + 1]; }          // as numpy promotes
-                ++hc[cv];
+                if (!fixed[(size_t)cv]) ++hc[cv];
                 if (k < n_compare && ci[k] == (int)cv && pi[k] == (int)pv && uvs[2 * k] == u0 && uvs[2 * k + 1] == u1)
                     continue;
                 if (fd == N) fd = k;
@@ -1689,12 +1699,12 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
         for (int64_t k = b; k < e; ++k) {
             const int lo = k == 0 ? -1 : pi[k - 1];
             for (int q = lo + 1; q <= pi[k]; ++q) ptr[q] = (int)k;
-            perm[off[ci[k]]++] = (int)k;
+            if (!fixed[(size_t)ci[k]]) perm[off[ci[k]]++] = (int)k;
         }
     });
     for (int64_t q = (int64_t)pi[N - 1] + 1; q <= P; ++q) ptr[q] = (int)N;
     ts1 = now_s();
-    for (size_t k = (size_t)N; k < ldz; ++k) perm[k] = 0;
+    for (size_t k = (size_t)cam_ptr[C]; k < ldz; ++k) perm[k] = 0;      // (shorter than N when cameras are held still)
 
     for (int k = 0; k < 9; ++k) h->K.k[k] = K[k];
     h->f32 = f32;
@@ -1841,6 +1851,7 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
             for (int i = ptr[p]; i < ptr[p + 1]; ++i)
                 for (int j = i; j < ptr[p + 1]; ++j) {
                     const int a = std::min(ci[i], ci[j]), b = std::max(ci[i], ci[j]);
+                    if (fixed[(size_t)a] || fixed[(size_t)b]) continue;
                     const int n_e = (i == j || a != b) ? 1 : 2;
                     cov_ptr[(size_t)dense_block_index(a, b, (int)C) + 1] += n_e;
                     total += n_e;
@@ -1854,6 +1865,7 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
                 for (int i = ptr[p]; i < ptr[p + 1]; ++i)
                     for (int j = i; j < ptr[p + 1]; ++j) {
                         const int a = std::min(ci[i], ci[j]), b = std::max(ci[i], ci[j]);
+                        if (fixed[(size_t)a] || fixed[(size_t)b]) continue;
                         int& f = fill[(size_t)dense_block_index(a, b, (int)C)];
                         cov_pt[(size_t)f++] = i == j ? ~(int)p : (int)p;           // (~p: the term of the right-hand side)
                         if (i != j && a == b) cov_pt[(size_t)f++] = (int)p;
@@ -1863,48 +1875,6 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
                 for (int b = a; b < (int)C; ++b) blk_ab[(size_t)dense_block_index(a, b, (int)C)] = make_int2(a, b);
             h->n_blk = nblk;
         }
-    }
-    // ---- the one-launch solver of small problems (small_solve.hpp) ---------------------------------------------------
-    // Thread gt of its G x 512 owns observation gt of the point-major order, observation gt of the camera-major order,
-    // point gt and the pair-list entries gt, gt + T, ...  Every sum over a run (a point's, a camera's, a block pair's
-    // entries) is reduced inside the wave first; a SEGMENT is the part of a run inside one wave, numbered in flat
-    // order: wseg[pass * waves + wave] = first segment of that wave, segptr[run] = first segment of that run.
-    h->small = h->dense && !f32 && N <= (int64_t)kSmallMaxG * kSmallThreads && P <= (int64_t)kSmallMaxG * kSmallThreads &&
-               (int64_t)cov_pt.size() <= 4ll * kSmallMaxG * kSmallThreads && h->dbg.small == 1;     // (opt-in until validated on the GPU)
-    for (auto& v : h->host_sm) v.clear();
-    if (h->small) {
-        const int64_t E = (int64_t)cov_pt.size();
-        const int64_t most = std::max<int64_t>(std::max(N, P), (E + 1) / 2);
-        const int G = (int)std::min<int64_t>(kSmallMaxG, std::max<int64_t>(1, (most + kSmallThreads - 1) / kSmallThreads));
-        const int T = G * kSmallThreads;
-        h->small_G = G; h->small_E = (int)E;
-        std::vector<int>& cm_cam = h->host_sm[0];
-        std::vector<int>& cov_key = h->host_sm[1];
-        cm_cam.resize((size_t)N);
-        for (int64_t c = 0; c < C; ++c)
-            for (int k = cam_ptr[c]; k < cam_ptr[c + 1]; ++k) cm_cam[(size_t)k] = (int)c;
-        cov_key.resize((size_t)std::max<int64_t>(1, E));
-        for (int b = 0; b < h->n_blk; ++b)
-            for (int k = cov_ptr[(size_t)b]; k < cov_ptr[(size_t)b + 1]; ++k) cov_key[(size_t)k] = b;
-        auto build_seg = [&](const int* keys, int64_t L, int64_t R, std::vector<int>& wseg, std::vector<int>& sptr) -> int {
-            const int64_t waves = T / 64, passes = std::max<int64_t>(1, (L + T - 1) / T);
-            wseg.assign((size_t)(passes * waves), 0);
-            sptr.assign((size_t)R + 1, 0);
-            int nseg = 0;
-            int64_t next_run = 0;
-            for (int64_t k = 0; k < L; ++k) {
-                const bool run_start = k == 0 || keys[k] != keys[k - 1];
-                if ((k & 63) == 0) wseg[(size_t)(k >> 6)] = nseg;
-                if (run_start) { for (int64_t q = next_run; q <= keys[k]; ++q) sptr[(size_t)q] = nseg; next_run = (int64_t)keys[k] + 1; }
-                if (run_start || (k & 63) == 0) ++nseg;
-            }
-            for (int64_t q = next_run; q <= R; ++q) sptr[(size_t)q] = nseg;
-            for (int64_t w = (L + 63) / 64; w < passes * waves; ++w) wseg[(size_t)w] = nseg;
-            return nseg;
-        };
-        h->sm_nsegP = build_seg(pi, N, P, h->host_sm[2], h->host_sm[3]);
-        h->sm_nsegC = build_seg(cm_cam.data(), N, C, h->host_sm[4], h->host_sm[5]);
-        h->sm_nsegS = build_seg(cov_key.data(), E, h->n_blk, h->host_sm[6], h->host_sm[7]);
     }
     tp2 = now_s();
     h->lds_tab = (size_t)C * kCamRow * sizeof(double) <= kLdsDynMax;
@@ -1928,7 +1898,7 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     HIPCHK(h, h->pt_ptr.ensure_keep(sizeof(int) * ((size_t)P + 1), sizeof(int) * (size_t)p_keep));
     // the structure tables: one device buffer, one pinned staging buffer, one copy
     struct Piece { const void* src; size_t bytes; DevView* view; size_t off; };
-    Piece pieces[18] = {
+    Piece pieces[10] = {
         {ranges.data(), sizeof(int2) * ranges.size(), &h->ranges, 0}, {wsteps.data(), sizeof(int2) * wsteps.size(), &h->wsteps, 0},
         {steps.data(), sizeof(int2) * steps.size(), &h->steps, 0}, {chunks.data(), sizeof(int4) * chunks.size(), &h->cam_chunks, 0},
         {chunk_ptr.data(), sizeof(int) * chunk_ptr.size(), &h->cam_chunk_ptr, 0},
@@ -1936,15 +1906,7 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
         {cov_pt.data(), h->dense ? sizeof(int) * cov_pt.size() : 0, &h->cov_pt, 0},
         {blk_ab.data(), h->dense ? sizeof(int2) * blk_ab.size() : 0, &h->blk_ab, 0},
         {h->host_chunks_b.data(), sizeof(int4) * h->host_chunks_b.size(), &h->cam_chunks_b, 0},
-        {h->host_chunk_ptr_b.data(), sizeof(int) * h->host_chunk_ptr_b.size(), &h->cam_chunk_ptr_b, 0},
-        {h->host_sm[0].data(), sizeof(int) * h->host_sm[0].size(), &h->sm_cm_cam, 0},
-        {h->host_sm[1].data(), sizeof(int) * h->host_sm[1].size(), &h->sm_cov_key, 0},
-        {h->host_sm[2].data(), sizeof(int) * h->host_sm[2].size(), &h->sm_wsegP, 0},
-        {h->host_sm[3].data(), sizeof(int) * h->host_sm[3].size(), &h->sm_ptrP, 0},
-        {h->host_sm[4].data(), sizeof(int) * h->host_sm[4].size(), &h->sm_wsegC, 0},
-        {h->host_sm[5].data(), sizeof(int) * h->host_sm[5].size(), &h->sm_ptrC, 0},
-        {h->host_sm[6].data(), sizeof(int) * h->host_sm[6].size(), &h->sm_wsegS, 0},
-        {h->host_sm[7].data(), sizeof(int) * h->host_sm[7].size(), &h->sm_ptrS, 0}};
+        {h->host_chunk_ptr_b.data(), sizeof(int) * h->host_chunk_ptr_b.size(), &h->cam_chunk_ptr_b, 0}};
     size_t tables_bytes = 0;
     for (auto& pc : pieces) { pc.off = tables_bytes; tables_bytes += (pc.bytes + 255) / 256 * 256; }
     HIPCHK(h, h->tables.ensure(tables_bytes + 256));
@@ -1972,10 +1934,6 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     if (h->use_rhsrec) HIPCHK(h, h->rhsrec.ensure(sizeof(double) * kRhsRec * P));
     if (h->dense) {
         HIPCHK(h, h->Sblk.ensure(sizeof(double) * 36 * blk_ab.size()));
-    }
-    if (h->small) {
-        HIPCHK(h, h->sm_rows.ensure(sizeof(double) * (12 * (size_t)h->sm_nsegP + 33 * (size_t)h->sm_nsegC + 36 * (size_t)h->sm_nsegS + 8)));
-        HIPCHK(h, h->sm_work.ensure(sizeof(double) * ((size_t)kSmallMaxG * kSmallPartCols + kSmallOut) + sizeof(unsigned) * kSmallBarWords));
     }
     HIPCHK(h, h->t1.ensure(esz * 2 * ldz));
     HIPCHK(h, h->V.ensure(sizeof(double) * 6 * P));
@@ -2268,97 +2226,6 @@ int sfmba_time_kernel(sfmba_handle* h, const double* x, int32_t which, int32_t r
 
 static int solve_impl(sfmba_handle* h, const double* x_start, double* x_inout, const sfmba_options* opt_in, sfmba_result* out);
 
-// The whole solve as one launch (small_solve.hpp): upload x0, one kernel, read back x and one result block.
-constexpr int kSmallRetry = 1000;             // (internal) the launch did not run to its end: use the multi-launch loop
-static int solve_small(sfmba_handle* h, const double* x_start, double* x_inout, const sfmba_options& opt, sfmba_result* out) {
-    const double t_begin = now_s();
-    const int64_t C = h->C, P = h->P, N = h->N, n = h->n;
-    h->x = h->xa.as<double>(); h->x_new = h->xb.as<double>();
-    h->tab = h->tabA.as<double>(); h->tab_new = h->tabB.as<double>();
-    h->rec = h->recA.as<double>(); h->rec_new = h->recB.as<double>();
-    CHK(upload_x(h, x_start));
-    const double t_dev0 = now_s();
-    double* part = h->sm_work.as<double>();
-    double* outd = part + (size_t)kSmallMaxG * kSmallPartCols;
-    unsigned* bar = reinterpret_cast<unsigned*>(outd + kSmallOut);
-    HIPCHK(h, hipMemsetAsync(outd, 0, sizeof(double) * kSmallOut + sizeof(unsigned) * kSmallBarWords, h->stream));
-    SmallArgs a{};
-    a.C = (int)C; a.P = (int)P; a.N = (int)N; a.E = h->small_E; a.G = h->small_G; a.n_blk = h->n_blk;
-    a.cam_idx = h->cam_idx.as<int>(); a.pt_idx = h->pt_idx.as<int>(); a.uv = h->uv.as<double2>();
-    a.cm_cam = h->sm_cm_cam.as<int>(); a.cm_pt = h->cm_pt.as<int>(); a.cm_uv = h->cm_uv.as<double2>();
-    a.cov_key = h->sm_cov_key.as<int>(); a.cov_pt = h->cov_pt.as<int>(); a.blk_ab = h->blk_ab.as<int2>();
-    a.sp = SmallSeg{h->sm_wsegP.as<int>(), h->sm_ptrP.as<int>()};
-    a.sc = SmallSeg{h->sm_wsegC.as<int>(), h->sm_ptrC.as<int>()};
-    a.ss = SmallSeg{h->sm_wsegS.as<int>(), h->sm_ptrS.as<int>()};
-    a.segP = h->sm_rows.as<double>();
-    a.segY = a.segP + 9 * (size_t)h->sm_nsegP;
-    a.segC = a.segY + 3 * (size_t)h->sm_nsegP;
-    a.segR = a.segC + 27 * (size_t)h->sm_nsegC;
-    a.segS = a.segR + 6 * (size_t)h->sm_nsegC;
-    a.xa = h->xa.as<double>(); a.xb = h->xb.as<double>();
-    a.Vinv = h->Vinv.as<double>(); a.e = h->e.as<double>(); a.g = h->g.as<double>(); a.si = h->si.as<double>();
-    a.sg = h->sg.as<double>(); a.p = h->p.as<double>(); a.r = h->r.as<double>();
-    a.part = part; a.bar = bar; a.out = outd;
-    a.K = h->K;
-    a.ftol = opt.ftol; a.xtol = opt.xtol; a.gtol = opt.gtol; a.reg_min = opt.reg_min;
-    a.pcg_tol = kDenseTolFactor * opt.pcg_tol;
-    const int64_t max_nfev = opt.max_nfev > 0 ? opt.max_nfev : 100 * (6 * C + 3 * P);
-    a.max_nfev = (int)std::min<int64_t>(max_nfev, INT32_MAX);
-    a.max_iter = (int)std::min<int64_t>(std::max<int64_t>(opt.max_iter, 0), INT32_MAX);
-    a.pcg_max_iters = pcg_max_iters(h, opt);
-    a.force_agent = h->dbg.small_agent;
-    const size_t lds = sizeof(double) * small_lds_doubles((int)C);
-    CHK(set_lds(h, k_small_solve, lds));
-    // one resident grid at a time per process: two of them could each hold some CUs of the XCD and wait for the rest
-    static std::mutex small_launch_mutex;
-    std::unique_lock<std::mutex> lock(small_launch_mutex);
-    hipLaunchKernelGGL(k_small_solve, dim3(8 * (unsigned)h->small_G), dim3(kSmallThreads), lds, h->stream, a);
-    LAUNCHED(h);
-    HIPCHK(h, hipMemcpyAsync(h->h_x, h->xa.p, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->h_scal + 64, outd, sizeof(double) * kSmallOut, hipMemcpyDeviceToHost, h->stream));
-    CHK(wait_stream(h));
-    lock.unlock();
-    const double* o = h->h_scal + 64;
-    if (h->dbg.trace_timing)
-        fprintf(stderr, "sfmba: one-launch solve  G %d  E %d  segments %d / %d / %d  complete %g  one XCD %g  barriers %g  status %g  "
-                        "nfev %g  iterations %g  pcg %g  %.3f ms\n", h->small_G, h->small_E, h->sm_nsegP, h->sm_nsegC, h->sm_nsegS,
-                o[15], o[13], o[14], o[0], o[1], o[3], o[4], 1e3 * (now_s() - t_begin));
-    if (h->dbg.trace_timing) {
-        fprintf(stderr, "sfmba:   us per phase (workgroup 0): eval0 %.1f | lin %.1f +bar %.1f | jdot %.1f | prep %.1f | schur %.1f +bar %.1f | pcg %.1f | "
-                        "back1 %.1f | back2 %.1f | gram %.1f | tr %.1f | trial %.1f +bar %.1f\n", o[kSmallOutHead + 56], o[kSmallOutHead + 57],
-                o[kSmallOutHead + 58], o[kSmallOutHead + 59], o[kSmallOutHead + 60], o[kSmallOutHead + 61], o[kSmallOutHead + 62], o[kSmallOutHead + 63],
-                o[kSmallOutHead + 64], o[kSmallOutHead + 65], o[kSmallOutHead + 66], o[kSmallOutHead + 67], o[kSmallOutHead + 68], o[kSmallOutHead + 69]);
-    }
-    if (o[15] != 1.0) {
-        // a grid barrier ran into its spin limit: the participating workgroups were not all resident (another kernel --
-        // another process on this GPU -- held CUs of the XCD).  Every workgroup has left; the caller runs the
-        // multi-launch loop instead, and after two such launches the handle stops trying.
-        ++h->small_fail;
-        return kSmallRetry;
-    }
-    const int status = (int)o[0];
-    if (status == -2) return fail(h, -2, "Residuals are not finite in the initial point.");
-    memcpy(x_inout, h->h_x, sizeof(double) * n);
-    const double t_end = now_s();
-    const double m_total = 2.0 * (double)h->N_total;
-    const int n_hist = (int)o[11];
-    h->pcg_hist.assign((size_t)std::min(n_hist, kSmallHist / 2), 0);
-    for (size_t k = 0; k < h->pcg_hist.size(); ++k) h->pcg_hist[k] = (int)o[kSmallOutHead + k];
-    h->hist_C = C; h->hist_P = P; h->hist_N = N;
-    out->cost0 = o[5]; out->rmse0 = std::sqrt(2.0 * o[5] / m_total);
-    out->cost = o[6]; out->rmse = std::sqrt(2.0 * o[6] / m_total);
-    out->optimality = o[7];
-    out->nfev = (int64_t)o[1]; out->njev = (int64_t)o[2]; out->iterations = (int64_t)o[3]; out->pcg_iterations = (int64_t)o[4];
-    out->status = status;
-    out->seconds_total = t_end - t_begin;
-    out->seconds_device = t_end - t_dev0;
-    out->last_step_norm = o[8];
-    out->last_reg = o[9];
-    out->reserved = (int32_t)o[12];
-    h->solved = true;
-    return 0;
-}
-
 int sfmba_solve(sfmba_handle* h, double* x_inout, const sfmba_options* opt_in, sfmba_result* out) {
     return sfmba_solve_from(h, x_inout, x_inout, opt_in, out);
 }
@@ -2394,13 +2261,6 @@ static int solve_impl(sfmba_handle* h, const double* x_start, double* x_inout, c
     h->skip = nullptr; h->post = Mailbox{};
     h->pending_scale_sums = false;
     h->p2p.first_in_solve = true;
-    // small problems (the size the reference itself produces): the whole loop below as ONE launch.  The multi-launch loop
-    // stays for per-iteration output (verbose = 2), K1 timing events and the PCG trace.
-    if (h->small && h->small_fail < 2 && !multi_rank(h) && opt.verbose < 2 && !opt.profile && h->dbg.trace_pcg == 0) {
-        const int rc = solve_small(h, x_start, x_inout, opt, out);
-        if (rc != kSmallRetry) return rc;
-        memset(out, 0, sizeof *out);
-    }
     if (h->dbg.p2p_delay_ms > 0) std::this_thread::sleep_for(std::chrono::milliseconds(h->dbg.p2p_delay_ms));
     const double t_begin = now_s();
     const int64_t C = h->C, P = h->P, n = h->n;

@@ -20,7 +20,7 @@ SYMBOLS = (
     "sfmba_normal_blocks", "sfmba_schur_matvec", "sfmba_comm_get_unique_id", "sfmba_comm_init",
     "sfmba_comm_destroy", "sfmba_set_precision", "sfmba_p2p_export", "sfmba_p2p_attach", "sfmba_p2p_detach",
     "sfmba_p2p_calls", "sfmba_tr2d_solve", "sfmba_debug_option", "sfmba_set_print", "sfmba_get_counters", "sfmba_problem_reuse", "sfmba_dense_schur",
-    "sfmba_get_pcg_history",
+    "sfmba_get_pcg_history", "sfmba_set_fixed_cameras",
 )
 
 
@@ -99,6 +99,8 @@ def load():
     lib.sfmba_get_pcg_history.restype = C.c_int32
     lib.sfmba_set_print.argtypes = [P, PRINT_FN, P]
     lib.sfmba_set_print.restype = C.c_int
+    lib.sfmba_set_fixed_cameras.argtypes = [P, P, C.c_int64]
+    lib.sfmba_set_fixed_cameras.restype = C.c_int
     lib.sfmba_p2p_calls.argtypes = [P]
     lib.sfmba_p2p_calls.restype = C.c_int64
     for name in ("sfmba_set_stream", "sfmba_set_problem", "sfmba_set_problem_i64", "sfmba_set_exchange", "sfmba_residuals",

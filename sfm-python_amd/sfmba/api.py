@@ -92,6 +92,7 @@ def _lazy_lil_class():
                 self.dtype = np.dtype(int)
                 self.maxprint = 50
                 self._sfmba_builder = builder
+                self._sfmba_fixed = ()
 
             def __getattr__(self, name):                  # only reached for attributes that do not exist yet
                 if name in ("rows", "data") and "_sfmba_builder" in self.__dict__:
@@ -127,13 +128,64 @@ def create_sparsity_matrix(n_cameras, n_points, n_obs, camera_indices, point3d_i
 
     if not lazy:
         return build()
-    return _lazy_lil_class()((n_obs * 2, n_cameras * 6 + n_points * 3), build)
+    out = _lazy_lil_class()((n_obs * 2, n_cameras * 6 + n_points * 3), build)
+    out._sfmba_fixed = tuple(sorted(set(int(c) for c in fixed if 0 <= int(c) < n_cameras)))
+    return out
+
+
+def fixed_cameras_of(jac_sparsity, n_cameras, n_points, camera_indices):
+    """The cameras a ``jac_sparsity`` pattern holds still: ``create_sparsity_matrix(..., fixed_camera_indices)``
+    leaves their six columns empty (bundle_adjustment.py:13-14), scipy's sparse finite differences then never fill
+    them, and the parameters stay where they are.  A pattern built by this module knows its list; any other sparse
+    matrix / array is read row by row: rows 2i, 2i+1 must hold the 3 point columns plus either the 6 camera columns
+    (free) or nothing (held still), the same for every observation of a camera -- anything else is not the
+    bundle-adjustment pattern this back end implements and raises ``ValueError`` instead of being ignored."""
+    known = getattr(jac_sparsity, "__dict__", {}).get("_sfmba_fixed")
+    if known is not None:
+        return tuple(known)
+    from scipy.sparse import issparse, csr_matrix
+    ci = np.asarray(camera_indices, dtype=np.int64)
+    n_obs = len(ci)
+    bad = ValueError("`jac_sparsity` is not the bundle-adjustment pattern of create_sparsity_matrix (3 point columns "
+                     "per row, plus the 6 camera columns unless the camera is held still)")
+    if issparse(jac_sparsity) and jac_sparsity.format == "lil":
+        rows = jac_sparsity.rows
+        lens = np.fromiter(map(len, rows), dtype=np.int64, count=2 * n_obs)
+        first = None
+        if lens.sum() == 18 * n_obs and lens.min(initial=9) == 9:
+            return ()
+        first = np.fromiter((r[0] if r else -1 for r in rows), dtype=np.int64, count=2 * n_obs)
+    else:
+        S = jac_sparsity.tocsr() if issparse(jac_sparsity) else csr_matrix(np.atleast_2d(np.asarray(jac_sparsity)))
+        if S.nnz and not np.all(S.data):                      # explicit zeros are not part of the structure for scipy
+            S = S.copy()
+            S.eliminate_zeros()
+        S.sort_indices()
+        lens = np.diff(S.indptr).astype(np.int64)
+        if S.nnz == 18 * n_obs and lens.min(initial=9) == 9:
+            return ()
+        first = np.full(2 * n_obs, -1, dtype=np.int64)
+        nz = lens > 0
+        first[nz] = S.indices[S.indptr[:-1][nz]]
+    lens = lens.reshape(n_obs, 2)
+    first = first.reshape(n_obs, 2)
+    if np.any(lens[:, 0] != lens[:, 1]) or np.any((lens[:, 0] != 3) & (lens[:, 0] != 9)):
+        raise bad
+    held = lens[:, 0] == 3
+    if np.any(first[held] < 6 * n_cameras) or np.any(first[~held] != 6 * ci[~held][:, None]):
+        raise bad
+    fixed = np.zeros(n_cameras, dtype=bool)
+    fixed[ci[held]] = True
+    if np.any(fixed[ci[~held]]):
+        raise ValueError("`jac_sparsity` holds a camera still in some of its observations and not in others")
+    return tuple(int(c) for c in np.flatnonzero(fixed))
 
 
 def compute_residuals(x, n_cameras, n_points, camera_indices, point_indices, points_2d, K, device=0):
     """(2N,) interleaved residuals pi(K R(w)(X - T)) - uv, evaluated by the HIP kernel."""
     be = get_backend(device)
     be.set_precision(64)
+    be.set_fixed_cameras(())
     be.set_problem(n_cameras, n_points, camera_indices, point_indices, points_2d, K)
     return be.residuals(x)
 
@@ -162,7 +214,9 @@ def least_squares(fun, x0, jac="2-point", bounds=(-np.inf, np.inf), method="trf"
     Jacobian.  With ``check_fun=True`` (default) a foreign ``fun`` is evaluated once on the first few
     observations and compared with the model this back end implements; a mismatch raises ``ValueError``
     instead of silently optimising a different function.
-    ``jac_sparsity`` is accepted and shape-checked; ``jac``, ``diff_step``, ``tr_solver``,
+    ``jac_sparsity`` is shape-checked and read for cameras it holds still (empty camera columns, the
+    ``fixed_camera_indices`` of ``create_sparsity_matrix``): their parameters do not move, as with scipy; a pattern
+    that is not the bundle-adjustment block pattern raises ``ValueError``.  ``jac``, ``diff_step``, ``tr_solver``,
     ``tr_options`` are accepted and ignored (the Jacobian is analytic, the trust-region step comes
     from the Schur-complement PCG).  Unsupported: bounds, robust losses, methods other than 'trf',
     x_scale other than 'jac'.  ``return_jac=True`` fills ``result.jac`` with the analytic Jacobian at
@@ -200,8 +254,10 @@ def least_squares(fun, x0, jac="2-point", bounds=(-np.inf, np.inf), method="trf"
     if check_fun and fun is not compute_residuals:
         _check_fun(fun, x0, int(n_cameras), int(n_points), camera_indices, point_indices, points_2d, K)
 
+    fixed = () if jac_sparsity is None else fixed_cameras_of(jac_sparsity, int(n_cameras), int(n_points), camera_indices)
     be = backend if backend is not None else get_backend(device)
     be.set_precision(storage_bits)
+    be.set_fixed_cameras(fixed)
     be.set_problem(n_cameras, n_points, camera_indices, point_indices, points_2d, K)
     opt = be.default_options()
     opt.ftol = 0.0 if ftol is None else float(ftol)
@@ -216,7 +272,7 @@ def least_squares(fun, x0, jac="2-point", bounds=(-np.inf, np.inf), method="trf"
     x, res, _, _ = be.solve(x0, opt, want_fun=False, want_grad=False)
     out = _make_result(x, res, be, verbose)
     if return_jac:
-        out.jac = _jacobian_csr(be, x, int(n_cameras), int(n_points), camera_indices, point_indices)
+        out.jac = _jacobian_csr(be, x, int(n_cameras), int(n_points), camera_indices, point_indices, fixed)
     return out
 
 
@@ -247,10 +303,12 @@ def _check_fun(fun, x0, n_cameras, n_points, camera_indices, point_indices, poin
                          "check_fun=False to skip this check")
 
 
-def _jacobian_csr(be, x, n_cameras, n_points, camera_indices, point_indices):
+def _jacobian_csr(be, x, n_cameras, n_points, camera_indices, point_indices, fixed=()):
     from scipy.sparse import csr_matrix
     _, Jc, Jp = be.residual_jacobian(x)
     ci = np.asarray(camera_indices, dtype=np.int64)
+    if len(fixed):                                   # columns of cameras held still are zero, as in scipy's result.jac
+        Jc[np.isin(ci, np.asarray(fixed, dtype=np.int64))] = 0.0
     pi = np.asarray(point_indices, dtype=np.int64)
     n_obs = len(ci)
     cols = np.concatenate([ci[:, None] * 6 + np.arange(6)[None, :],

@@ -97,6 +97,16 @@ class Backend:
         self._flush_pending()
         self._check(self._lib.sfmba_set_precision(self._h, int(storage_bits)))
 
+    def set_fixed_cameras(self, camera_indices=()):
+        """Cameras whose six parameters stay as they are (``create_sparsity_matrix(..., fixed_camera_indices)``).
+        Applies from the next set_problem until replaced."""
+        idx = np.ascontiguousarray(sorted(set(int(c) for c in camera_indices)), dtype=np.int64)
+        if tuple(idx) == getattr(self, "_fixed", ()):
+            return
+        self._flush_pending()
+        self._check(self._lib.sfmba_set_fixed_cameras(self._h, _capi.ptr(idx) if len(idx) else None, len(idx)))
+        self._fixed = tuple(int(c) for c in idx)
+
     def debug_option(self, name: str, value: int):
         """Test / diagnostic hook (include/sfmba.h: sfmba_debug_option)."""
         self._check(self._lib.sfmba_debug_option(self._h, name.encode(), int(value)))
@@ -205,9 +215,10 @@ class Backend:
 
     def pcg_history(self):
         """PCG iterations of every outer iteration of the last solve on this handle."""
-        buf = (C.c_int32 * 4096)()
-        n = int(self._lib.sfmba_get_pcg_history(self._h, buf, 4096))
-        return [int(buf[k]) for k in range(min(n, 4096))]
+        n = int(self._lib.sfmba_get_pcg_history(self._h, None, 0))        # (returns the count, writes min(count, cap))
+        buf = (C.c_int32 * max(n, 1))()
+        n = min(n, int(self._lib.sfmba_get_pcg_history(self._h, buf, n)))
+        return [int(buf[k]) for k in range(n)]
 
     def p2p_calls(self) -> int:
         return int(self._lib.sfmba_p2p_calls(self._h))

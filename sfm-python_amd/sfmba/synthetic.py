@@ -177,6 +177,52 @@ def make_ring_problem(n_cameras: int, n_points: int, n_obs: int, seed: int = 0, 
     return BAProblem(n_cameras, n_points, cam_idx, pt_idx, uv, K, x0, x_true)
 
 
+def make_plane_crossing_problem(seed: int = 0, quanta: int = 1, n_cameras: int = 5, n_points: int = 60, n_obs: int = 360,
+                                x0_noise: float = 0.05) -> BAProblem:
+    """A problem whose FIRST trial step puts a point exactly on a camera's principal plane (p_z = 0), so that the
+    reference's unguarded division (``bundle_adjustment.py:30``) yields a non-finite residual and the solver has to take
+    scipy's branch for it (``trf.py:504-506``: radius <- 1/4 |step|, retry).
+
+    Crossing the plane is not enough -- floating point would step over it -- so the scene is built to LAND on it, in a
+    way that does not depend on the last bits of the step: every z coordinate is shifted by 2^44, where doubles are
+    spaced 2^-8 (3.9 mm) apart, so z moves in whole quanta.  Camera 0 (to be held still through ``jac_sparsity`` /
+    ``fixed_camera_indices``, rotation vector exactly 0, so p_z = Z - T_z exactly) stands 8 units in front of the others,
+    and point 0 sits ``quanta`` x 3.9 mm in front of it, seen by it and by three more cameras from 8 units away.  From the
+    far start the first step moves that point back by about its depth, which rounds onto the plane.  Returns the problem
+    with ``x0`` (camera 0 at its true pose); hold camera 0 fixed when solving."""
+    rng = np.random.default_rng(seed)
+    K = K_SCEAUX.copy()
+    q = 2.0 ** -8
+    z0 = 2.0 ** 44
+    C, P, N = n_cameras, n_points, n_obs
+    cam_w = rng.normal(0.0, 0.1, (C, 3))
+    cam_T = rng.normal(0.0, 0.5, (C, 3))
+    cam_w[0] = 0.0
+    cam_T[0] = (0.0, 0.0, 8.0)
+    pts = rng.normal(0.0, 1.0, (P, 3)) + np.array([0.0, 0.0, 10.0])
+    pts[:, 2] = np.maximum(pts[:, 2], 8.6)                     # everything else well in front of camera 0
+    pts[0] = (1e-3 * rng.normal(), 1e-3 * rng.normal(), 8.0 + quanta * q)
+    pt_idx = np.concatenate([np.arange(P), rng.integers(0, P, N - P)])
+    cam_idx = rng.integers(0, C, N)
+    sel = pt_idx == 0
+    cam_idx[sel] = np.where(cam_idx[sel] == 0, 3, cam_idx[sel])
+    pt_idx = np.concatenate([pt_idx, np.zeros(3, dtype=np.int64)])
+    cam_idx = np.concatenate([cam_idx, np.array([0, 1, 2])])
+    order = np.argsort(pt_idx, kind="stable")
+    pt_idx, cam_idx = pt_idx[order].astype(np.int64), cam_idx[order].astype(np.int64)
+    cam_T[:, 2] += z0
+    pts[:, 2] += z0
+    R = _rodrigues_batch(cam_w)
+    qq = np.einsum("nij,nj->ni", R[cam_idx], pts[pt_idx] - cam_T[cam_idx])
+    p = qq @ K.T
+    uv = np.trunc(p[:, :2] / p[:, 2:3] + rng.normal(0.0, 0.5, (len(pt_idx), 2))).astype(np.int64)
+    x_true = np.concatenate([np.hstack([cam_w, cam_T]).ravel(), pts.ravel()])
+    x0 = x_true + rng.normal(0.0, x0_noise, x_true.shape)
+    x0[:6] = x_true[:6]
+    x0[6 * C:6 * C + 3] = x_true[6 * C:6 * C + 3] + np.array([1e-3 * rng.normal(), 1e-3 * rng.normal(), 0.0])
+    return BAProblem(C, P, cam_idx, pt_idx, uv, K, x0, x_true)
+
+
 def growing_reconstruction(pb: BAProblem, order=None, first: int = 2):
     """The sequence of bundle-adjustment inputs an incremental reconstruction of ``pb`` produces when BA runs
     after every newly registered camera, the way ``SFM.construct`` grows its graph

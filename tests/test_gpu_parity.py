@@ -221,7 +221,7 @@ def dbg():
             touched.append((b, name))
     yield set_
     defaults = dict(pcg_fused=-1, tab_lds=-1, vec_lds=-1, cam_chunk=0, pcg_guess_bias=0, sweep_rc=-1, dense=-1, precond=-1, pcg_local=-1,
-                    pcg_split=-1, rhsrec=-1, cost_rider=-1, xcd_chunks=-1, small=-1, small_agent=0)
+                    pcg_split=-1, rhsrec=-1, cost_rider=-1, xcd_chunks=-1)
     for b, name in touched:
         b.debug_option(name, defaults[name])
 
@@ -275,6 +275,12 @@ def test_results_are_bitwise_reproducible(be):
 
 # ---- A5-A9: the solver -------------------------------------------------------------------------------
 
+def _fun_bound(case, dense):
+    """Twice the largest residual difference the ORACLE shows against the same scipy result (tools/gen_golden.py --params)."""
+    rows = json.load(open(os.path.join(GOLDEN, "param_bounds.json")))["rows"]
+    return 2.0 * next(r["fun_max"] for r in rows if r["case"] == case and r["settings"] == ("dense" if dense else "implicit"))
+
+
 def _oracle_kwargs(dense):
     """The reduced camera system is solved by PCG to 1e-2 with the Schur-diagonal block preconditioner: with the
     implicit product (two launches per iteration), or, when 6 C <= 128 (`dense`), with S formed and the iterations
@@ -296,7 +302,8 @@ def _ran_dense(be, calls):
 def test_solve_matches_scipy_on_tiny_problems(orc, dbg):
     """Stated tolerance (BASELINE.json north_star): final reprojection RMSE within 1e-6 px of the scipy
     reference on identical inputs.  scipy stops in a slow tail (optimality ~1e-1), so our cost may only
-    be lower; the residual vectors agree to 5e-2 px."""
+    be lower; the residual vectors agree to twice what the oracle measured against the same scipy run (2e-3 ... 9e-3 px;
+    parameters: tests/test_gpu_params.py)."""
     import sfmba
     g = np.load(os.path.join(GOLDEN, "lsq_tiny_cases.npz"))
     for k, dense in [(k, d) for k in range(int(g["n_cases"])) for d in (True, False)]:
@@ -314,7 +321,7 @@ def test_solve_matches_scipy_on_tiny_problems(orc, dbg):
         assert abs(my_rmse - rmse) < 1e-6
         assert abs(res.rmse - my_rmse) < 1e-12
         assert res.cost <= cost * (1 + 1e-9)
-        assert np.abs(res.fun - g[pre + "fun"]).max() < 5e-2
+        assert np.abs(res.fun - g[pre + "fun"]).max() <= _fun_bound(f"tiny{k}_{C}_{P}_{N}", dense)
         # and against the oracle's restatement of the same algorithm
         o = orc.trf_schur(pb.x0, *pb.args, ftol=1e-10, **_oracle_kwargs(dense))
         assert abs(res.cost - o.cost) <= 1e-8 * o.cost
@@ -373,60 +380,6 @@ def test_rejected_steps_and_nfev_limit_follow_the_oracle(orc, dbg, dense):
         assert np.abs(res.x - o.x).max() <= (1e-4 if dense else 1e-6) * np.abs(o.x).max()
         r = orc.compute_residuals(res.x, *pb.args)
         assert np.abs(r - res.fun).max() < 1e-8            # result.fun belongs to result.x
-
-
-def test_one_launch_solver_follows_the_launch_loop_and_the_oracle(orc):
-    """csrc/small_solve.hpp: the whole trust-region loop of a small problem as ONE resident kernel on the workgroups of
-    one XCD (opt-in: debug option small = 1; DESIGN.md section 6 has the measurements).  Same algorithm as the
-    multi-launch loop with S in LDS, other summation orders: status, nfev, njev and the PCG iterations of every outer
-    iteration must be equal, cost within 1e-9 of the loop's and 1e-8 of the oracle's -- on a SceauxCastle-scale problem
-    (pair lists in two passes, 20 workgroups), on far starts with rejected steps, at every max_nfev, with a camera and
-    points nobody observes, and with agent-scope barriers forced (the fallback when the workgroups do not share an XCD)."""
-    import sfmba
-    small, loop = sfmba.Backend(0), sfmba.Backend(0)
-    try:
-        small.debug_option("small", 1)
-        loop.debug_option("small", 0)
-
-        def both(pb, **kw):
-            out = []
-            for be in (small, loop):
-                n0 = be.counters()[0]
-                res = sfmba.least_squares(sfmba.compute_residuals, pb.x0, x_scale="jac", ftol=1e-10, method="trf", args=pb.args,
-                                          backend=be, **kw)
-                out.append((res, be.pcg_history(), be.counters()[0] - n0))
-            (a, ha, la), (b, hb, lb) = out
-            assert la < lb and la <= 6              # one kernel (+ the structure kernels of set_problem) against dozens
-            assert (a.status, a.nfev, a.njev) == (b.status, b.nfev, b.njev) and ha == hb
-            assert abs(a.cost - b.cost) <= 1e-9 * b.cost
-            assert abs(a.optimality - np.abs(a.grad).max()) <= 1e-12 * max(1.0, a.optimality)
-            r = orc.compute_residuals(a.x, *pb.args)
-            assert np.abs(r - a.fun).max() < 1e-8            # result.fun belongs to result.x
-            return a, b
-
-        pb = sfmba.make_problem(11, 3000, 10000, seed=5, x0_noise=0.03)
-        a, b = both(pb)
-        o = orc.trf_schur(pb.x0, *pb.args, ftol=1e-10, **_oracle_kwargs(True))
-        assert (a.status, a.nfev, a.njev) == (o.status, o.nfev, o.njev) and abs(a.cost - o.cost) <= 1e-8 * o.cost
-        assert np.abs(a.x - b.x).max() <= 1e-6 * np.abs(b.x).max()
-        saw_rejection = False
-        for seed in (1, 2, 5):
-            pb = sfmba.make_problem(6, 80, 500, seed=seed, x0_noise=0.2)
-            a, b = both(pb)
-            o = orc.trf_schur(pb.x0, *pb.args, ftol=1e-10, **_oracle_kwargs(True))
-            assert (a.status, a.nfev, a.njev) == (o.status, o.nfev, o.njev) and abs(a.cost - o.cost) <= 1e-8 * o.cost
-            saw_rejection |= a.nfev > a.njev
-        assert saw_rejection
-        for max_nfev in range(2, 9):
-            a, b = both(pb, max_nfev=max_nfev)
-            assert a.status == 0 and a.nfev == max_nfev
-        pb = sfmba.drop_observations(sfmba.make_problem(7, 300, 1500, seed=3), cameras=(2,), points=(5, 17, 299))
-        both(pb)
-        small.debug_option("small_agent", 1)
-        both(sfmba.make_problem(5, 900, 3000, seed=3, x0_noise=0.03))
-    finally:
-        small.close()
-        loop.close()
 
 
 def test_speculative_pcg_miss_changes_nothing(dbg):
@@ -561,7 +514,7 @@ def test_ring_scene_large_rotations(orc, dbg, dense):
     assert res.success and abs(res.rmse - rmse) < 1e-6 and res.cost <= cost * (1 + 1e-9)
     assert (res.status, res.nfev, res.njev) == (o.status, o.nfev, o.njev)
     assert abs(res.cost - o.cost) <= 1e-9 * o.cost
-    assert np.abs(res.fun - g["ring_fun"]).max() < 5e-2
+    assert np.abs(res.fun - g["ring_fun"]).max() <= _fun_bound("ring_12_150_900", dense)
 
 
 def test_error_behaviour(be):

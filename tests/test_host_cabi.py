@@ -328,3 +328,38 @@ def test_lazy_result_behaves_like_scipys_without_a_gpu():
     o = api._make_result(x, Res(), be, verbose=0)
     with pytest.raises(AttributeError):
         o.no_such_field
+
+
+def test_held_cameras_are_read_from_the_sparsity_pattern():
+    """api.fixed_cameras_of: the pattern of create_sparsity_matrix(..., fixed_camera_indices) (bundle_adjustment.py:13-14)
+    says which cameras scipy would never move; this module's lazy pattern knows, any other matrix is read row by row,
+    and a pattern that is not the bundle-adjustment block pattern raises instead of being ignored."""
+    import sfmba
+    from sfmba.api import fixed_cameras_of
+    from sfmba.synthetic import make_problem
+    g = np.load(os.path.join(GOLDEN, "sparsity_cases.npz"))
+    C, P, N = (int(v) for v in g["dims"])
+    ci, pi = g["ci"], g["pi"]
+    import scipy.sparse as sp
+    for tag in ("free", "fixed"):
+        fixed = tuple(int(c) for c in g[tag + "_fixed"])
+        ref = sp.csr_matrix((g[tag + "_data"], g[tag + "_indices"], g[tag + "_indptr"]), shape=tuple(g[tag + "_shape"]))   # the reference's own
+        lazy = sfmba.create_sparsity_matrix(C, P, N, ci, pi, fixed_camera_indices=fixed)
+        assert fixed_cameras_of(lazy, C, P, ci) == fixed and "_sfmba_builder" in lazy.__dict__        # without building it
+        for S in (ref, ref.tolil(), ref.tocsc(), ref.toarray(), sfmba.create_sparsity_matrix(C, P, N, ci, pi, fixed, lazy=False)):
+            assert fixed_cameras_of(S, C, P, ci) == fixed
+    ref = sp.csr_matrix((g["fixed_data"], g["fixed_indices"], g["fixed_indptr"]), shape=tuple(g["fixed_shape"])).tolil()
+    k = int(np.flatnonzero(ci == 1)[0])                           # camera 1 is free: drop its columns in ONE observation
+    ref[2 * k, 6:12] = 0
+    ref[2 * k + 1, 6:12] = 0
+    with pytest.raises(ValueError, match="some of its observations"):
+        fixed_cameras_of(ref.tocsr(), C, P, ci)
+    bad = sp.csr_matrix((g["free_data"], g["free_indices"], g["free_indptr"]), shape=tuple(g["free_shape"])).tolil()
+    bad[0, int(6 * ci[0])] = 0
+    for S in (bad, bad.tocsr()):
+        with pytest.raises(ValueError, match="not the bundle-adjustment pattern"):
+            fixed_cameras_of(S, C, P, ci)
+    explicit = sp.csr_matrix((g["free_data"], g["free_indices"], g["free_indptr"]), shape=tuple(g["free_shape"])).astype(float)
+    explicit.data[:] = 1.0
+    explicit[0, 6 * C + 3 * P - 1] = 0.0                           # an explicit zero is no structure for scipy either
+    assert fixed_cameras_of(explicit, C, P, ci) == ()
