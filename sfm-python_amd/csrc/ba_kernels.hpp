@@ -1139,6 +1139,61 @@ __device__ __forceinline__ void point_prep_one(const double* __restrict__ V, con
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// MIXED-PRECISION Schur product (BASELINE config 5: "mixed-precision PCG with fp64 accumulation"; sfmba_set_precision).
+// The product S u inside the PCG only has to be good to the forcing term (1e-2 ... 0.1), so its OPERANDS are kept in
+// fp32 and everything computed from them -- blocks, dot products, every sum -- in fp64:
+//   rt32   [C][12] float   R | T - o           per parameter vector (k_prep)
+//   rec32  [P][8]  float   X - o | z0 z1 z2 . .   one 32-byte record per point: coordinates per parameter vector
+//                          (k_prep), z by pass A of every product -- what pass B gathers per observation (one sector
+//                          instead of a 48-byte record that straddles two)
+//   table  [C][20] float   R | T - o | a' | u_T . .   pass A's camera rows, 80 bytes instead of 144: in LDS (<= 1100
+//                          cameras: half the staging traffic and half the LDS reads per observation) or in global
+//                          memory behind five LDS-DMA pieces per row instead of nine
+// o = an origin near the points (mean of a sample of x0's points, fixed for the solve): coordinates are rounded RELATIVE
+// to it, so a scene far from the coordinate origin keeps its fp32 digits for X - T.  Both passes see the same rounded
+// R, T, X, a', u_T, hence blocks of ONE Jacobian; what is not symmetric to the last bit is the rounding of z and a'
+// themselves (fp32-class, 1e-7 relative).  Gradient, cost, normal blocks, preconditioner, right-hand side, the PCG's
+// vectors and scalars and the back-substitution stay fp64 as before.
+// ---------------------------------------------------------------------------------------------
+constexpr int kRt32 = 12, kRec32 = 8, kRc32Row = 20;
+constexpr int kRow32Pieces = kRc32Row / 4;                     // 16-byte pieces per row
+constexpr size_t kRow32SlabFloats = 64 * (size_t)kRc32Row;     // per wave
+struct Origin { double x, y, z; };
+struct MixedPrep {                     // rt32 == null: not the mixed mode
+    const double* __restrict__ camtab;
+    float* __restrict__ rt32;
+    float* __restrict__ rec32;
+    double* __restrict__ rtd;          // [C][12]: the values of rt32 as doubles (pass B reads its camera's row with scalar
+    Origin o;                          // loads: a conversion there would move twelve doubles from SGPRs to VGPRs)
+};
+__device__ __forceinline__ void mixed_prep_camera(const MixedPrep& mx, int C, int c) {
+    const double* __restrict__ rt = mx.camtab + cam_rt_offset(C) + (size_t)kCamRT * c;
+    float4* __restrict__ out = reinterpret_cast<float4*>(mx.rt32 + (size_t)kRt32 * c);
+    out[0] = make_float4((float)rt[0], (float)rt[1], (float)rt[2], (float)rt[3]);
+    out[1] = make_float4((float)rt[4], (float)rt[5], (float)rt[6], (float)rt[7]);
+    out[2] = make_float4((float)rt[8], (float)(rt[9] - mx.o.x), (float)(rt[10] - mx.o.y), (float)(rt[11] - mx.o.z));
+    double* __restrict__ d = mx.rtd + (size_t)kRt32 * c;
+    const float4 a = out[0], b = out[1], e = out[2];
+    d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+    d[8] = e.x; d[9] = e.y; d[10] = e.z; d[11] = e.w;
+}
+__device__ __forceinline__ void mixed_prep_point(const MixedPrep& mx, const double* __restrict__ pts, int p) {
+    float4* __restrict__ out = reinterpret_cast<float4*>(mx.rec32 + (size_t)kRec32 * p);
+    out[0] = make_float4((float)(pts[3 * (size_t)p] - mx.o.x), (float)(pts[3 * (size_t)p + 1] - mx.o.y),
+                         (float)(pts[3 * (size_t)p + 2] - mx.o.z), 0.f);
+}
+// the fp32 operands of the parameter vector (pts, camtab), outside a solve (test and timing entries)
+__global__ void k_mixed_prep(MixedPrep mx, const double* __restrict__ pts, int C, int P, int bc) {
+    if ((int)blockIdx.x < bc) {
+        const int c = blockIdx.x * blockDim.x + threadIdx.x;
+        if (c < C) mixed_prep_camera(mx, C, c);
+        return;
+    }
+    const int p = (blockIdx.x - bc) * blockDim.x + threadIdx.x;
+    if (p < P) mixed_prep_point(mx, pts, p);
+}
+
 // Per point: Vinv = (V + reg diag(si_p^2))^-1 and e_p = Vinv g_p.
 __global__ void k_point_prep(const double* __restrict__ V, const double* __restrict__ gp,
                              const double* __restrict__ sip, const double* __restrict__ dp_extra,
@@ -1265,7 +1320,7 @@ __global__ __launch_bounds__(64) void k_prep(double* __restrict__ sc, double Del
                                              double* __restrict__ Minv,
                                              double* __restrict__ Vinv, double* __restrict__ e,
                                              const double* __restrict__ jd_part, int jd_n, double eta_min, double eta_max,
-                                             const double* __restrict__ pts, double* __restrict__ rhsrec) {
+                                             const double* __restrict__ pts, double* __restrict__ rhsrec, MixedPrep mx) {
     // G11 = |J D^2 g|^2: either already in slot 1 (k_finish, then all-reduced over ranks) or summed here from
     // k_jdot's per-workgroup partials -- every workgroup (one wave) repeats the same 256-term sum in
     // k_finish's order, which is cheaper than a launch in between
@@ -1293,6 +1348,7 @@ __global__ __launch_bounds__(64) void k_prep(double* __restrict__ sc, double Del
     if ((int)blockIdx.x < bc) {
         const int c = blockIdx.x * blockDim.x + threadIdx.x;
         if (c >= C) return;
+        if (mx.rt32 != nullptr) mixed_prep_camera(mx, C, c);
         if (Minv != nullptr) { cam_prep_one(Ugc, si, nullptr, C, c, reg, Dc, Minv); return; }
 #pragma unroll                                        // Schur-diagonal preconditioner: only Dc here, Minv by k_cam_prep_schur
         for (int a = 0; a < 6; ++a) Dc[(size_t)a * C + c] = reg * si[6 * (size_t)c + a] * si[6 * (size_t)c + a];
@@ -1300,6 +1356,7 @@ __global__ __launch_bounds__(64) void k_prep(double* __restrict__ sc, double Del
     }
     const int p = (blockIdx.x - bc) * blockDim.x + threadIdx.x;
     if (p >= P) return;
+    if (mx.rt32 != nullptr) mixed_prep_point(mx, pts, p);
     point_prep_one(V, gp, si + 6 * (size_t)C, nullptr, p, reg, Vinv, e, pts, rhsrec);
 }
 
@@ -1687,6 +1744,46 @@ __global__ __launch_bounds__(256) void k_rc_table(const double* __restrict__ cam
     row[15] = u[3]; row[16] = u[4]; row[17] = u[5];
 }
 
+// the same table with fp32 operands (mixed-precision product): [C][20] float = R | T - o (from rt32) | a' | u_T . .
+__global__ __launch_bounds__(256) void k_rc_table32(const double* __restrict__ camtab, const float* __restrict__ rt32,
+                                                    const double* __restrict__ u_planes, const PcgCtrl* __restrict__ ctrl2,
+                                                    int L, int C, float* __restrict__ rctab32) {
+    if (ctrl2 != nullptr) {
+        const PcgCtrl* __restrict__ ctrl = ctrl2 + (L & 1);
+        if (ctrl->done != 0) return;                          // grid-uniform
+        u_planes += (size_t)((ctrl->iters & 1) * kPcgVecs + kPcgU) * 6 * C;
+    }
+    const int cam = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cam >= C) return;
+    const float4* __restrict__ src = reinterpret_cast<const float4*>(rt32 + (size_t)kRt32 * cam);
+    float4* __restrict__ row = reinterpret_cast<float4*>(rctab32 + (size_t)kRc32Row * cam);
+    row[0] = src[0]; row[1] = src[1]; row[2] = src[2];
+    const double* __restrict__ wbc = camtab + cam_wbc_offset(C);
+    double u[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) u[k] = u_planes[(size_t)k * C + cam];
+    const double wx = wbc[cam], wy = wbc[(size_t)C + cam], wz = wbc[2 * (size_t)C + cam];
+    const double b = wbc[3 * (size_t)C + cam], cc = wbc[4 * (size_t)C + cam];
+    const double c0 = wy * u[2] - wz * u[1], c1 = wz * u[0] - wx * u[2], c2 = wx * u[1] - wy * u[0];   // w x u_w
+    const double d0 = wy * c2 - wz * c1, d1 = wz * c0 - wx * c2, d2 = wx * c1 - wy * c0;               // w x (w x u_w)
+    row[3] = make_float4((float)(u[0] - b * c0 + cc * d0), (float)(u[1] - b * c1 + cc * d1), (float)(u[2] - b * c2 + cc * d2),
+                         (float)u[3]);
+    row[4] = make_float4((float)u[4], (float)u[5], 0.f, 0.f);
+}
+// five LDS-DMA pieces per 80-byte row (rows_request with the fp32 table)
+__device__ __forceinline__ void rows_request32(const float* __restrict__ table, int cam, int lane, float* slab) {
+#pragma unroll
+    for (int k = 0; k < kRow32Pieces; ++k) {
+        int q = k * 64 + lane;
+        asm volatile("" : "+v"(q));              // recomputed per request: hoisted out of the walk, the piece addresses spill
+        const int row = q / kRow32Pieces, piece = q - kRow32Pieces * row;
+        const int cr = __shfl(cam, row);
+        __builtin_amdgcn_global_load_lds(table + (size_t)cr * kRc32Row + 4 * piece,
+                                         (__attribute__((address_space(3))) void*)(slab + 4 * 64 * k), 16, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // GTAB (more cameras than the LDS holds): the table [C][18] was written to global memory by k_rc_table and its rows are
 // gathered from L2 by nine 16-byte loads per observation; `vin` is not used.
 template <bool FUSED, bool GTAB = false>
@@ -1879,6 +1976,188 @@ __global__ __launch_bounds__(kSweepThreads) void k_point_sweep_rc(
     }
 }
 
+// Pass A with fp32 OPERANDS and fp64 arithmetic (see MixedPrep): the structure of k_point_sweep_rc with 80-byte camera
+// rows R | T - o | a' | u_T (five 16-byte pieces instead of nine, in LDS or behind the LDS-DMA slab), the point read
+// from its 32-byte fp32 record, z written there as three floats.
+template <bool FUSED, bool GTAB = false, bool Z64 = false>
+__global__ __launch_bounds__(kSweepThreads) void k_point_sweep_rc32(
+    StepTable st, const int* __restrict__ cam_idx, const int* __restrict__ pt_idx,
+    const double* __restrict__ camtab, const float* __restrict__ rt32, KMat K, const double* __restrict__ vin,
+    const double* __restrict__ Vinv, float* __restrict__ rec32, const double* __restrict__ acc, int C,
+    const PcgCtrl* __restrict__ ctrl2, int L, PcgFused pf, const float* __restrict__ rctab32, double* __restrict__ zout64) {
+    // Z64: pass B keeps its fp64 records, z goes there (zout64: [P][kRec]) unrounded
+    static_assert(!(FUSED && GTAB), "the fused PCG update needs the table in LDS");
+    static_assert(kVinvInRec < 0, "the mixed-precision product reads the inverse point blocks from their own array");
+    extern __shared__ __align__(16) double smem_d[];
+    float* const smem = reinterpret_cast<float*>(smem_d);
+    const int n6 = 6 * C;
+    const int wg = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    int s = 0, s_end = 0;
+    if (wg < st.n_waves) { const int2 w = st.wsteps[wg]; s = w.x; s_end = w.x + w.y; }
+    int2 cur = make_int2(0, 0), nxt = make_int2(0, 0), nn = make_int2(0, 0);
+    if (s < s_end) cur = st.steps[s];
+    if (s + 1 < s_end) nxt = st.steps[s + 1];
+    if (s + 2 < s_end) nn = st.steps[s + 2];
+    const double* __restrict__ wbc = camtab + cam_wbc_offset(C);                  // w, b, c plane-major [5][C]
+    auto put_au = [&](int cam, const double* u) {          // a' and u_T of camera `cam` from its u (6), rounded to fp32
+        const double wx = wbc[cam], wy = wbc[(size_t)C + cam], wz = wbc[2 * (size_t)C + cam];
+        const double b = wbc[3 * (size_t)C + cam], cc = wbc[4 * (size_t)C + cam];
+        const double c0 = wy * u[2] - wz * u[1], c1 = wz * u[0] - wx * u[2], c2 = wx * u[1] - wy * u[0];   // w x u_w
+        const double d0 = wy * c2 - wz * c1, d1 = wz * c0 - wx * c2, d2 = wx * c1 - wy * c0;               // w x (w x u_w)
+        float4* __restrict__ row = reinterpret_cast<float4*>(smem + (size_t)kRc32Row * cam);
+        row[3] = make_float4((float)(u[0] - b * c0 + cc * d0), (float)(u[1] - b * c1 + cc * d1),
+                             (float)(u[2] - b * c2 + cc * d2), (float)u[3]);
+        row[4] = make_float4((float)u[4], (float)u[5], 0.f, 0.f);
+    };
+    if (FUSED) {
+        double uu[6];
+        if (!pcg_fused_update(pf, acc, C, L, uu)) return;
+        if ((int)threadIdx.x < C) put_au(threadIdx.x, uu);
+    } else {
+        if (ctrl2 != nullptr) {                               // two-kernel PCG: vin = base of the vector sets
+            const PcgCtrl* __restrict__ ctrl = ctrl2 + (L & 1);
+            if (ctrl->done != 0) return;                      // grid-uniform
+            vin += (size_t)((ctrl->iters & 1) * kPcgVecs + kPcgU) * n6;
+        }
+        if (!GTAB) {
+            for (int cam = threadIdx.x; cam < C; cam += blockDim.x) {     // vin: plane-major [6][C]
+                double u[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) u[k] = vin[(size_t)k * C + cam];
+                put_au(cam, u);
+            }
+        }
+    }
+    // (the indices of the first two steps are requested here, behind the PCG prologue -- held across it they spill --
+    // and in front of the staging loop, which hides their latency)
+    int c = 0, p = 0, cn = 0, pn = 0;
+    if (cur.y <= 64 && lane < cur.y) { c = cam_idx[cur.x + lane]; p = pt_idx[cur.x + lane]; }
+    if (nxt.y <= 64 && lane < nxt.y) { cn = cam_idx[nxt.x + lane]; pn = pt_idx[nxt.x + lane]; }
+    if (!GTAB) {
+        for (int e = threadIdx.x; e < C * (kRt32 / 4); e += blockDim.x) {      // R | T - o: 3 x 16 bytes per camera, coalesced
+            const int cam = e / (kRt32 / 4), k = e - cam * (kRt32 / 4);
+            reinterpret_cast<float4*>(smem + (size_t)kRc32Row * cam)[k] = reinterpret_cast<const float4*>(rt32)[e];
+        }
+        __syncthreads();
+    }
+    const float* __restrict__ table = GTAB ? rctab32 : smem;
+    float* const slab = smem + (size_t)(threadIdx.x >> 6) * kRow32SlabFloats;
+
+    // y contribution of one observation from its camera row (five 16-byte pieces) and its point X - o
+    auto contrib = [&](const float4* __restrict__ row, float X, float Y, float Z, double* y) {
+        const float4 f0 = row[0], f1 = row[1], f2 = row[2], f3 = row[3], f4 = row[4];
+        const double R0 = f0.x, R1 = f0.y, R2 = f0.z, R3 = f0.w, R4 = f1.x, R5 = f1.y, R6 = f1.z, R7 = f1.w, R8 = f2.x;
+        const double vx = (double)X - (double)f2.y, vy = (double)Y - (double)f2.z, vz = (double)Z - (double)f2.w;
+        const double qx = R0 * vx + R1 * vy + R2 * vz;
+        const double qy = R3 * vx + R4 * vy + R5 * vz;
+        const double qz = R6 * vx + R7 * vy + R8 * vz;
+        const double px = K.k[0] * qx + K.k[1] * qy + K.k[2] * qz;
+        const double py = K.k[3] * qx + K.k[4] * qy + K.k[5] * qz;
+        const double pz = K.k[6] * qx + K.k[7] * qy + K.k[8] * qz;
+        const double iz = 1.0 / pz;
+        const double ax = f3.x, ay = f3.y, az = f3.z;             // g = v x a' + u_T
+        const double g0 = vy * az - vz * ay + (double)f3.w, g1 = vz * ax - vx * az + (double)f4.x,
+                     g2 = vx * ay - vy * ax + (double)f4.y;
+        y[0] = 0.0; y[1] = 0.0; y[2] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const double pk = (k == 0 ? px : py) * iz;
+            const double b0 = (K.k[3 * k + 0] - pk * K.k[6]) * iz;
+            const double b1 = (K.k[3 * k + 1] - pk * K.k[7]) * iz;
+            const double b2 = (K.k[3 * k + 2] - pk * K.k[8]) * iz;
+            const double j0 = b0 * R0 + b1 * R3 + b2 * R6;            // row k of A R
+            const double j1 = b0 * R1 + b1 * R4 + b2 * R7;
+            const double j2 = b0 * R2 + b1 * R5 + b2 * R8;
+            const double tk = -(j0 * g0 + j1 * g1 + j2 * g2);        // (Jc u)_k
+            y[0] += j0 * tk; y[1] += j1 * tk; y[2] += j2 * tk;
+        }
+    };
+    auto row_of = [&](int cc) { return reinterpret_cast<const float4*>(table + (size_t)kRc32Row * cc); };
+    auto store_z = [&](int pp, const double* vv, const double* y) {
+        if (Z64) {
+            double* __restrict__ zd = zout64 + (size_t)kRec * pp;
+            zd[3] = vv[0] * y[0] + vv[1] * y[1] + vv[2] * y[2];
+            zd[4] = vv[1] * y[0] + vv[3] * y[1] + vv[4] * y[2];
+            zd[5] = vv[2] * y[0] + vv[4] * y[1] + vv[5] * y[2];
+        } else {
+            float* __restrict__ zp = rec32 + (size_t)kRec32 * pp;
+            zp[3] = (float)(vv[0] * y[0] + vv[1] * y[1] + vv[2] * y[2]);
+            *reinterpret_cast<float2*>(zp + 4) = make_float2((float)(vv[1] * y[0] + vv[3] * y[1] + vv[4] * y[2]),
+                                                             (float)(vv[2] * y[0] + vv[4] * y[1] + vv[5] * y[2]));
+        }
+    };
+    auto load_point = [&](bool on, int pp, float* X, double* vi) {
+        if (on) {
+            const float4 xr = *reinterpret_cast<const float4*>(rec32 + (size_t)kRec32 * pp);
+            X[0] = xr.x; X[1] = xr.y; X[2] = xr.z;
+            if (!GTAB) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) vi[k] = Vinv[kVinvRow * (size_t)pp + k];
+            }
+        }
+    };
+    float X[3] = {0.f, 0.f, 0.f};
+    double vi[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    load_point(cur.y <= 64 && lane < cur.y, p, X, vi);
+    bool requested = false;                       // (wave-uniform) the slab holds / will hold the rows of step `cur`
+    while (s < s_end) {
+        double y[3] = {0.0, 0.0, 0.0};
+        if (GTAB && cur.y <= 64) {
+            if (!requested) rows_request32(rctab32, c, lane, slab);
+            rows_wait();
+            if (lane < cur.y) contrib(reinterpret_cast<const float4*>(slab + (size_t)lane * kRc32Row), X[0], X[1], X[2], y);
+            rows_read_done();
+            requested = s + 1 < s_end && nxt.y <= 64;
+            if (requested) rows_request32(rctab32, cn, lane, slab);
+        } else {
+            requested = false;
+        }
+        int2 n3 = make_int2(0, 0);
+        if (s + 3 < s_end) n3 = st.steps[s + 3];
+        n3.x = __builtin_amdgcn_readfirstlane(n3.x);
+        n3.y = __builtin_amdgcn_readfirstlane(n3.y);
+        int c2 = 0, p2 = 0;
+        if (nn.y <= 64 && lane < nn.y) { c2 = cam_idx[nn.x + lane]; p2 = pt_idx[nn.x + lane]; }
+        float Xn[3] = {0.f, 0.f, 0.f};
+        double vin_[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        load_point(nxt.y <= 64 && lane < nxt.y, pn, Xn, vin_);
+        if (GTAB && cur.y <= 64 && lane < cur.y) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) vi[k] = Vinv[kVinvRow * (size_t)p + k];
+        }
+        if (cur.y > 64) {                          // one point with more than 64 observations
+            const int run_end = cur.x + cur.y;
+            const int pp = pt_idx[cur.x];
+            const float4 xr = *reinterpret_cast<const float4*>(rec32 + (size_t)kRec32 * pp);
+            const float Xl = xr.x, Yl = xr.y, Zl = xr.z;
+            for (int j = cur.x + lane; j < run_end; j += 64) {
+                double w[3];
+                contrib(row_of(cam_idx[j]), Xl, Yl, Zl, w);
+                y[0] += w[0]; y[1] += w[1]; y[2] += w[2];
+            }
+            y[0] = wave_sum(y[0]); y[1] = wave_sum(y[1]); y[2] = wave_sum(y[2]);
+            if (lane == 0) store_z(pp, Vinv + kVinvRow * (size_t)pp, y);
+        } else {
+            const bool act = lane < cur.y;
+            if (!GTAB && act) contrib(row_of(c), X[0], X[1], X[2], y);
+            const int key = act ? p : -1 - lane;
+            seg_reduce_serial<3>(y, key, lane);
+            const int prev = lane_below(key, lane);
+            if (act && (lane == 0 || prev != key)) store_z(p, vi, y);
+        }
+        cur = nxt; nxt = nn; nn = n3;
+        c = cn; p = pn; cn = c2; pn = p2;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) X[k] = Xn[k];
+        if (!GTAB) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) vi[k] = vin_[k];
+        }
+        ++s;
+    }
+}
+
 // The local form of the PCG update as a kernel of its own (more cameras than the fused launch takes: one thread per
 // camera of a 1024-thread workgroup).  Pass B's workgroup of every camera has done that camera's bookkeeping and left
 // four partial dot products (PcgLocal); this kernel sums them -- every workgroup all of them, in the same order -- and
@@ -1972,12 +2251,17 @@ struct PcgLocal {
     double* __restrict__ part;           // null: not the local form
 };
 
-template <int MODE, bool ROUND>
+// MIXED (MODE 0, exact-block form): the operands of the mixed-precision product -- R, T - o, a', u_T rounded to fp32
+// exactly as pass A's table holds them, the point and z from its 32-byte fp32 record (`rec` then points at rec32).
+struct MixedB { const double* __restrict__ rtd; };      // [C][12] = R | T - o, fp32 values held as doubles
+template <int MODE, bool ROUND, bool MIXED = false>
 __global__ __launch_bounds__(kCamThreads) void k_cam_schur(CamMajor cm, const double* __restrict__ camtab,
                                                            const double* __restrict__ rec, KMat K,
                                                            const double* __restrict__ vin, int C,
                                                            double* __restrict__ acc, double* __restrict__ partial,
-                                                           const PcgCtrl* __restrict__ ctrl_done, int set, PcgLocal pl) {
+                                                           const PcgCtrl* __restrict__ ctrl_done, int set, PcgLocal pl,
+                                                           MixedB mxb) {
+    static_assert(!MIXED || (MODE == 0 && !ROUND), "mixed operands: the product, exact-block form");
     __shared__ double red[kCamWaves][6];
     if (ctrl_done != nullptr) {
         if (ctrl_done->done != 0) return;                       // grid-uniform
@@ -2006,6 +2290,13 @@ __global__ __launch_bounds__(kCamThreads) void k_cam_schur(CamMajor cm, const do
         const double d0 = wy * c2 - wz * c1, d1 = wz * c0 - wx * c2, d2 = wx * c1 - wy * c0;
         ap[0] = vc[0] - t[15] * c0 + t[16] * d0; ap[1] = vc[1] - t[15] * c1 + t[16] * d1; ap[2] = vc[2] - t[15] * c2 + t[16] * d2;
     }
+    double vT[3] = {vc[3], vc[4], vc[5]};                  // the translation part of the camera vector as the sweep uses it
+    if (MIXED) {
+#pragma unroll
+        for (int k = 0; k < kRt32; ++k) t[k] = mxb.rtd[(size_t)ch.x * kRt32 + k];      // wave-uniform: scalar loads
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { ap[k] = (double)(float)ap[k]; vT[k] = (double)(float)vT[k]; }
+    }
     double a[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     for (int k0 = ch.y + (int)threadIdx.x; k0 < ch.z; k0 += kCamThreads * kCamUnroll) {      // see k_cam_blocks
         int p[kCamUnroll];
@@ -2016,11 +2307,19 @@ __global__ __launch_bounds__(kCamThreads) void k_cam_schur(CamMajor cm, const do
             p[u] = k < ch.z ? cm.pt[k] : -1;
         }
 #pragma unroll
-        for (int u = 0; u < kCamUnroll; ++u) {            // the point's record: X Y | Z z0 | z1 z2, three 16-byte loads
-            const double2* __restrict__ rp = reinterpret_cast<const double2*>(rec + (size_t)kRec * (p[u] < 0 ? 0 : p[u]));
-            const double2 r0 = rp[0], r1 = rp[1], r2 = rp[2];
-            X[u][0] = r0.x; X[u][1] = r0.y; X[u][2] = r1.x;
-            z[u][0] = r1.y; z[u][1] = r2.x; z[u][2] = r2.y;
+        for (int u = 0; u < kCamUnroll; ++u) {
+            if (MIXED) {                                  // the point's fp32 record: X Y Z z0 | z1 z2, one 32-byte sector
+                const float* __restrict__ rp = reinterpret_cast<const float*>(rec) + (size_t)kRec32 * (p[u] < 0 ? 0 : p[u]);
+                const float4 r0 = *reinterpret_cast<const float4*>(rp);
+                const float2 r1 = *reinterpret_cast<const float2*>(rp + 4);
+                X[u][0] = r0.x; X[u][1] = r0.y; X[u][2] = r0.z;
+                z[u][0] = r0.w; z[u][1] = r1.x; z[u][2] = r1.y;
+            } else {                                      // the point's record: X Y | Z z0 | z1 z2, three 16-byte loads
+                const double2* __restrict__ rp = reinterpret_cast<const double2*>(rec + (size_t)kRec * (p[u] < 0 ? 0 : p[u]));
+                const double2 r0 = rp[0], r1 = rp[1], r2 = rp[2];
+                X[u][0] = r0.x; X[u][1] = r0.y; X[u][2] = r1.x;
+                z[u][0] = r1.y; z[u][1] = r2.x; z[u][2] = r2.y;
+            }
         }
 #pragma unroll
         for (int u = 0; u < kCamUnroll; ++u) {
@@ -2053,9 +2352,9 @@ __global__ __launch_bounds__(kCamThreads) void k_cam_schur(CamMajor cm, const do
                 const double iz = 1.0 / pz;
                 double h0 = z[u][0], h1 = z[u][1], h2 = z[u][2];
                 if (MODE == 0) {
-                    h0 += vy * ap[2] - vz * ap[1] + vc[3];
-                    h1 += vz * ap[0] - vx * ap[2] + vc[4];
-                    h2 += vx * ap[1] - vy * ap[0] + vc[5];
+                    h0 += vy * ap[2] - vz * ap[1] + vT[0];
+                    h1 += vz * ap[0] - vx * ap[2] + vT[1];
+                    h2 += vx * ap[1] - vy * ap[0] + vT[2];
                 }
                 double s0 = 0.0, s1 = 0.0, s2 = 0.0;             // q = sum_k u_k j_k
 #pragma unroll
@@ -2147,6 +2446,131 @@ __global__ __launch_bounds__(kCamThreads) void k_cam_schur(CamMajor cm, const do
             if (k < 4) pl.part[(size_t)k * C + ch.x] = k == 0 ? d0 : (k == 1 ? d1 : (k == 2 ? d2 : d3));
         }
     }
+}
+
+// Pass B over the XCD-aware chunk table (many points: every camera's list cut at the eight point-range boundaries), ONE
+// WAVE PER CHUNK.  A chunk there is short (a camera's ~2000 observations / 8 = 250): as a 256-thread workgroup it used
+// one of its four unroll slots, and paid two barriers and an LDS round trip for the six sums of 250 terms.  Here the
+// four waves of a workgroup take four chunks of the SAME point range (cameras 4 g .. 4 g + 3, range k: workgroup 8 g + k,
+// which runs on XCD k), each wave walks its chunk with four gathers per lane in flight and reduces with DPP / readlane
+// alone; no LDS, no barrier.  Row q = (8 g + k) 4 + j of `partial` holds the sums of camera 4 g + j over range k;
+// k_cam_combine_w adds a camera's eight rows in range order.
+constexpr int kWaveChunkCams = 4, kWaveChunkRanges = 8;
+template <bool MIXED>
+__global__ __launch_bounds__(kCamThreads) void k_cam_schur_w(CamMajor cm, const double* __restrict__ camtab,
+                                                             const double* __restrict__ rec, KMat K,
+                                                             const double* __restrict__ vin, int C,
+                                                             double* __restrict__ partial,
+                                                             const PcgCtrl* __restrict__ ctrl_done, int set, MixedB mxb) {
+    if (ctrl_done != nullptr) {
+        if (ctrl_done->done != 0) return;                       // grid-uniform
+        vin += (size_t)((set < 0 ? (ctrl_done->iters & 1) : set) * kPcgVecs + kPcgU) * 6 * C;
+    }
+    const int lane = threadIdx.x & 63;
+    const int q = __builtin_amdgcn_readfirstlane((int)blockIdx.x * kWaveChunkCams + ((int)threadIdx.x >> 6));   // wave-uniform
+    const int4 ch = cm.chunks[q];
+    if (ch.x < 0) return;                                       // padding behind the last camera
+    double t[kCamTab];
+#pragma unroll
+    for (int k = 0; k < kCamTab; ++k) t[k] = camtab[(size_t)ch.x * kCamRow + k];      // wave-uniform: scalar loads
+    double vc[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) vc[k] = vin[(size_t)k * C + ch.x];
+    double ap[3];
+    {
+        const double wx = t[12], wy = t[13], wz = t[14];
+        const double c0 = wy * vc[2] - wz * vc[1], c1 = wz * vc[0] - wx * vc[2], c2 = wx * vc[1] - wy * vc[0];
+        const double d0 = wy * c2 - wz * c1, d1 = wz * c0 - wx * c2, d2 = wx * c1 - wy * c0;
+        ap[0] = vc[0] - t[15] * c0 + t[16] * d0; ap[1] = vc[1] - t[15] * c1 + t[16] * d1; ap[2] = vc[2] - t[15] * c2 + t[16] * d2;
+    }
+    double vT[3] = {vc[3], vc[4], vc[5]};
+    if (MIXED) {
+#pragma unroll
+        for (int k = 0; k < kRt32; ++k) t[k] = mxb.rtd[(size_t)ch.x * kRt32 + k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { ap[k] = (double)(float)ap[k]; vT[k] = (double)(float)vT[k]; }
+    }
+    double a[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int k0 = ch.y + lane; k0 < ch.z; k0 += 64 * kCamUnroll) {
+        int p[kCamUnroll];
+        double X[kCamUnroll][3], z[kCamUnroll][3];
+#pragma unroll
+        for (int u = 0; u < kCamUnroll; ++u) {
+            const int k = k0 + u * 64;
+            p[u] = k < ch.z ? cm.pt[k] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < kCamUnroll; ++u) {
+            if (MIXED) {
+                const float* __restrict__ rp = reinterpret_cast<const float*>(rec) + (size_t)kRec32 * (p[u] < 0 ? 0 : p[u]);
+                const float4 r0 = *reinterpret_cast<const float4*>(rp);
+                const float2 r1 = *reinterpret_cast<const float2*>(rp + 4);
+                X[u][0] = r0.x; X[u][1] = r0.y; X[u][2] = r0.z;
+                z[u][0] = r0.w; z[u][1] = r1.x; z[u][2] = r1.y;
+            } else {
+                const double2* __restrict__ rp = reinterpret_cast<const double2*>(rec + (size_t)kRec * (p[u] < 0 ? 0 : p[u]));
+                const double2 r0 = rp[0], r1 = rp[1], r2 = rp[2];
+                X[u][0] = r0.x; X[u][1] = r0.y; X[u][2] = r1.x;
+                z[u][0] = r1.y; z[u][1] = r2.x; z[u][2] = r2.y;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kCamUnroll; ++u) {
+            if (p[u] < 0) continue;
+            const double vx = X[u][0] - t[9], vy = X[u][1] - t[10], vz = X[u][2] - t[11];
+            const double qx = t[0] * vx + t[1] * vy + t[2] * vz;
+            const double qy = t[3] * vx + t[4] * vy + t[5] * vz;
+            const double qz = t[6] * vx + t[7] * vy + t[8] * vz;
+            const double px = K.k[0] * qx + K.k[1] * qy + K.k[2] * qz;
+            const double py = K.k[3] * qx + K.k[4] * qy + K.k[5] * qz;
+            const double pz = K.k[6] * qx + K.k[7] * qy + K.k[8] * qz;
+            const double iz = 1.0 / pz;
+            const double h0 = z[u][0] + vy * ap[2] - vz * ap[1] + vT[0];
+            const double h1 = z[u][1] + vz * ap[0] - vx * ap[2] + vT[1];
+            const double h2 = z[u][2] + vx * ap[1] - vy * ap[0] + vT[2];
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0;             // q = sum_k u_k j_k
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const double pk = (k == 0 ? px : py) * iz;
+                const double b0 = (K.k[3 * k + 0] - pk * K.k[6]) * iz;
+                const double b1 = (K.k[3 * k + 1] - pk * K.k[7]) * iz;
+                const double b2 = (K.k[3 * k + 2] - pk * K.k[8]) * iz;
+                const double j0 = b0 * t[0] + b1 * t[3] + b2 * t[6];
+                const double j1 = b0 * t[1] + b1 * t[4] + b2 * t[7];
+                const double j2 = b0 * t[2] + b1 * t[5] + b2 * t[8];
+                const double uk = -(j0 * h0 + j1 * h1 + j2 * h2);
+                s0 += uk * j0; s1 += uk * j1; s2 += uk * j2;
+            }
+            a[0] += s1 * vz - s2 * vy; a[1] += s2 * vx - s0 * vz; a[2] += s0 * vy - s1 * vx;       // q x v
+            a[3] += s0; a[4] += s1; a[5] += s2;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) a[k] = wave_sum(a[k]);        // on every lane
+    if (lane < 6) {
+        const double wx = t[12], wy = t[13], wz = t[14];
+        const double m0 = a[0], m1 = a[1], m2 = a[2];
+        const double c0 = m1 * wz - m2 * wy, c1 = m2 * wx - m0 * wz, c2 = m0 * wy - m1 * wx;          // M x w
+        const double d0 = c1 * wz - c2 * wy, d1 = c2 * wx - c0 * wz, d2 = c0 * wy - c1 * wx;          // (M x w) x w
+        const double r0 = -(m0 - t[15] * c0 + t[16] * d0), r1 = -(m1 - t[15] * c1 + t[16] * d1),
+                     r2 = -(m2 - t[15] * c2 + t[16] * d2);
+        const double out = lane == 0 ? r0 : (lane == 1 ? r1 : (lane == 2 ? r2 : (lane == 3 ? -a[3] : (lane == 4 ? -a[4] : -a[5]))));
+        partial[(size_t)q * 6 + lane] = out;
+    }
+}
+// acc[k][c] = sum over the eight ranges of camera c's rows of k_cam_schur_w, in range order
+__global__ __launch_bounds__(256) void k_cam_combine_w(const double* __restrict__ partial, int C, double* __restrict__ acc,
+                                                       const int* __restrict__ done) {
+    if (done != nullptr && *done != 0) return;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= C * 6) return;
+    const int c = e / 6, col = e - c * 6;
+    const int g = c / kWaveChunkCams, j = c - g * kWaveChunkCams;
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < kWaveChunkRanges; ++k)
+        s += partial[(size_t)((g * kWaveChunkRanges + k) * kWaveChunkCams + j) * 6 + col];
+    acc[(size_t)col * C + c] = s;
 }
 
 // Reduced right-hand side WITH the diagonal blocks of W Vinv W^T (Schur-diagonal preconditioner): one camera-major

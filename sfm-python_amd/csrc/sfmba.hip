@@ -229,6 +229,11 @@ struct sfmba_handle {
     bool sweep_rc = false;                   // pass A recomputes the blocks from an LDS table (k_point_sweep_rc)
     bool sweep_rc_g = false;                 // ... from a table in global memory (more cameras than the LDS holds)
     DevBuf rctab;                            // [C][18], k_rc_table
+    // mixed-precision Schur product (ba_kernels.hpp: MixedPrep): fp32 operands, fp64 arithmetic
+    bool mixed = false;                      // pass A
+    bool mixed_b = false;                    // ... and pass B (fp32 point records)
+    DevBuf rt32, rec32, rctab32, rtd;        // [C][12], [P][8], [C][20] floats; [C][12] doubles
+    Origin origin{0.0, 0.0, 0.0};            // coordinates are rounded relative to it (set with every uploaded x)
     bool dense = false;                      // reduced camera matrix formed and factorised (6 C <= kDenseMaxN) instead of PCG
     DevView cov_ptr, cov_pt, blk_ab;         // dense path: per block pair (a <= b) the points both cameras see
     DevBuf Sblk;
@@ -245,6 +250,8 @@ struct sfmba_handle {
         int xcd_chunks = -1;                 // 1 / 0: camera lists cut at the eight point-range boundaries (one chunk per XCD) whatever the size
         int rhsrec = -1;                     // 1 / 0: the rhs + preconditioner pass gathers its own 128-byte records whatever the size
         int cost_rider = -1;                 // 0: the trial cost is summed and posted by a k_finish launch of its own
+        int pcg_mixed_b = -1;                // 0: pass B keeps fp64 point records although pass A runs on fp32 operands
+        int pcg_mixed = -1;                  // 1 / 0: fp32 operands in the implicit Schur product whatever the storage mode
         int pcg_split = -1;                  // 1: the local form with its tail in a kernel of its own (k_pcg_tail) on a
                                              // single rank too; 0: sharded / multi-chunk solves keep the round-2 forms
                                              // (whole update in every workgroup of pass A, or k_pcg_update)
@@ -489,6 +496,19 @@ int set_lds(sfmba_handle* h, Kern k, size_t bytes) {
 // records -- written by k_prep / k_point_prep for h->rec before every consumer of the iteration
 double* vinv_ptr(const sfmba_handle* h) { return kVinvInRec < 0 ? h->Vinv.as<double>() : h->rec + kVinvInRec; }
 
+MixedPrep mixed_prep(const sfmba_handle* h, const double* tab) {
+    if (!h->mixed) return MixedPrep{nullptr, nullptr, nullptr, nullptr, Origin{0.0, 0.0, 0.0}};
+    return MixedPrep{tab, h->rt32.as<float>(), h->rec32.as<float>(), h->rtd.as<double>(), h->origin};
+}
+// fp32 operands of (x, tab) outside a solve (inside, k_prep writes them)
+int launch_mixed_prep(sfmba_handle* h, const double* x, const double* tab) {
+    if (!h->mixed) return 0;
+    const int bc = (int)((h->C + 255) / 256), bp = (int)((h->P + 255) / 256);
+    hipLaunchKernelGGL(k_mixed_prep, dim3(bc + bp), dim3(256), 0, h->stream, mixed_prep(h, tab), x + 6 * h->C, (int)h->C, (int)h->P, bc);
+    LAUNCHED(h);
+    return 0;
+}
+
 ObsArrays obs_arrays(const sfmba_handle* h) {
     return ObsArrays{h->cam_idx.as<int>(), h->pt_idx.as<int>(), h->pt_ptr.as<int>(),
                      h->J.as<double>(), h->ld, h->f32 ? 1 : 0};
@@ -710,6 +730,31 @@ int launch_normal_blocks(sfmba_handle* h, const double* x, const double* tab, co
 // plane-major when it is staged in LDS, camera-major otherwise; ctrl2 = nullptr.
 int launch_point_sweep(sfmba_handle* h, const double* vin, const PcgCtrl* ctrl2, int L) {
     const int grid = (h->n_ranges + kWavesPerSweepBlock - 1) / kWavesPerSweepBlock;
+    if (h->mixed && h->sweep_rc) {        // fp32 operands, table in LDS
+        const size_t lds = sizeof(float) * kRc32Row * (size_t)h->C;
+        auto kern = h->mixed_b ? k_point_sweep_rc32<false, false, false> : k_point_sweep_rc32<false, false, true>;
+        CHK(set_lds(h, kern, lds));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), lds, h->stream, step_table(h), (const int*)h->cam_idx.as<int>(),
+                           (const int*)h->pt_idx.as<int>(), (const double*)h->tab, (const float*)h->rt32.as<float>(), h->K, vin,
+                           (const double*)vinv_ptr(h), h->rec32.as<float>(), (const double*)h->acc(), (int)h->C, ctrl2, L,
+                           PcgFused{}, (const float*)nullptr, h->rec);
+        LAUNCHED(h);
+        return 0;
+    }
+    if (h->mixed && h->sweep_rc_g) {      // fp32 operands, table in global memory
+        hipLaunchKernelGGL(k_rc_table32, dim3((unsigned)((h->C + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->tab,
+                           (const float*)h->rt32.as<float>(), vin, ctrl2, L, (int)h->C, h->rctab32.as<float>());
+        LAUNCHED(h);
+        const size_t slabs = sizeof(float) * kRow32SlabFloats * kWavesPerSweepBlock;
+        auto kern_g = h->mixed_b ? k_point_sweep_rc32<false, true, false> : k_point_sweep_rc32<false, true, true>;
+        CHK(set_lds(h, kern_g, slabs));
+        hipLaunchKernelGGL(kern_g, dim3(grid), dim3(kSweepThreads), slabs, h->stream, step_table(h),
+                           (const int*)h->cam_idx.as<int>(), (const int*)h->pt_idx.as<int>(), (const double*)h->tab,
+                           (const float*)h->rt32.as<float>(), h->K, vin, (const double*)vinv_ptr(h), h->rec32.as<float>(),
+                           (const double*)h->acc(), (int)h->C, ctrl2, L, PcgFused{}, (const float*)h->rctab32.as<float>(), h->rec);
+        LAUNCHED(h);
+        return 0;
+    }
     if (h->sweep_rc) {                    // recomputing form: vin plane-major (or the base of the vector sets)
         const size_t lds = sizeof(double) * kRcRow * (size_t)h->C;
         auto kern = k_point_sweep_rc<false>;
@@ -756,6 +801,18 @@ int launch_pcg_fused(sfmba_handle* h, int L) {
     PcgFused pf{h->Dc.as<double>(), h->Minv.as<double>(), h->Ugc(), h->vecs.as<double>(), h->ctrl.as<PcgCtrl>(),
                 h->pcg_tol, h->pcg_cap, (const double*)(h->scal() + kEtaSlot),
                 h->pcg_local ? h->pcg_part.as<double>() : (double*)nullptr};
+    if (h->mixed && h->sweep_rc) {
+        const size_t lds32 = sizeof(float) * kRc32Row * (size_t)h->C;
+        auto kern32 = h->mixed_b ? k_point_sweep_rc32<true, false, false> : k_point_sweep_rc32<true, false, true>;
+        CHK(set_lds(h, kern32, lds32));
+        hipLaunchKernelGGL(kern32, dim3(grid), dim3(kSweepThreads), lds32, h->stream, step_table(h),
+                           (const int*)h->cam_idx.as<int>(), (const int*)h->pt_idx.as<int>(), (const double*)h->tab,
+                           (const float*)h->rt32.as<float>(), h->K, (const double*)h->vecs.as<double>(),
+                           (const double*)vinv_ptr(h), h->rec32.as<float>(), (const double*)h->acc(), (int)h->C,
+                           (const PcgCtrl*)h->ctrl.as<PcgCtrl>(), L, pf, (const float*)nullptr, h->rec);
+        LAUNCHED(h);
+        return 0;
+    }
     if (h->sweep_rc) {
         const size_t lds_rc = sizeof(double) * kRcRow * (size_t)h->C;
         auto kern_rc = k_point_sweep_rc<true>;
@@ -788,14 +845,36 @@ int launch_cam_schur(sfmba_handle* h, const double* vin, const PcgCtrl* ctrl_don
     const bool tb = MODE == 0 && h->xcd_b;
     const CamMajor cm = tb ? CamMajor{h->cam_chunks_b.as<int4>(), h->cm_pt.as<int>(), h->cm_uv.as<double>()} : cam_major(h);
     const int grid = tb ? h->n_chunks_b : h->n_chunks;
+    const MixedB mxb{h->rtd.as<double>()};
+    if (tb) {                                       // one wave per chunk of the XCD-aware table
+        const bool round = h->f32 && !h->sweep_rc && !h->sweep_rc_g;
+        if (round) return fail(h, -1, "XCD-aware chunks need the recomputing form of pass A");
+        const int wgrid = h->n_chunks_b / kWaveChunkCams;
+        if (h->mixed_b)
+            hipLaunchKernelGGL((k_cam_schur_w<true>), dim3(wgrid), dim3(kCamThreads), 0, h->stream, cm, (const double*)h->tab,
+                               reinterpret_cast<const double*>(h->rec32.as<float>()), h->K, vin, (int)h->C,
+                               h->cam_partial.as<double>(), ctrl_done, set, mxb);
+        else
+            hipLaunchKernelGGL((k_cam_schur_w<false>), dim3(wgrid), dim3(kCamThreads), 0, h->stream, cm, (const double*)h->tab,
+                               (const double*)h->rec, h->K, vin, (int)h->C, h->cam_partial.as<double>(), ctrl_done, set, mxb);
+        LAUNCHED(h);
+        hipLaunchKernelGGL(k_cam_combine_w, dim3((unsigned)((6 * h->C + 255) / 256)), dim3(256), 0, h->stream,
+                           (const double*)h->cam_partial.as<double>(), (int)h->C, h->acc(), ctrl_done ? &ctrl_done->done : (const int*)nullptr);
+        LAUNCHED(h);
+        return 0;
+    }
     if (h->f32 && !h->sweep_rc && !h->sweep_rc_g)   // pass A applies the stored fp32 blocks: pass B rounds its own the same way
         hipLaunchKernelGGL((k_cam_schur<MODE, true>), dim3(grid), dim3(kCamThreads), 0, h->stream, cm,
                            (const double*)h->tab, (const double*)h->rec, h->K, vin, (int)h->C, h->acc(),
-                           h->cam_partial.as<double>(), ctrl_done, set, pl);
+                           h->cam_partial.as<double>(), ctrl_done, set, pl, mxb);
+    else if (MODE == 0 && h->mixed_b)               // fp32 operands: the same rounded R, T - o, X - o, a', u_T as pass A
+        hipLaunchKernelGGL((k_cam_schur<0, false, true>), dim3(grid), dim3(kCamThreads), 0, h->stream, cm,
+                           (const double*)h->tab, reinterpret_cast<const double*>(h->rec32.as<float>()), h->K, vin, (int)h->C,
+                           h->acc(), h->cam_partial.as<double>(), ctrl_done, set, pl, mxb);
     else
         hipLaunchKernelGGL((k_cam_schur<MODE, false>), dim3(grid), dim3(kCamThreads), 0, h->stream, cm,
                            (const double*)h->tab, (const double*)h->rec, h->K, vin, (int)h->C, h->acc(),
-                           h->cam_partial.as<double>(), ctrl_done, set, pl);
+                           h->cam_partial.as<double>(), ctrl_done, set, pl, mxb);
     LAUNCHED(h);
     return launch_cam_combine(h, 6, h->acc(), 1, (int)h->C, nullptr, ctrl_done ? &ctrl_done->done : nullptr, tb);
 }
@@ -1031,6 +1110,15 @@ void staging_copy(sfmba_handle* h, void* dst, const void* src, size_t bytes) {
 
 int upload_x(sfmba_handle* h, const double* x_host) {
     CHK(ensure_h_x(h));
+    if (h->mixed) {                    // origin of the fp32 operands: mean of (a sample of) this vector's points
+        const double* pts = x_host + 6 * h->C;
+        const int64_t stride = std::max<int64_t>(1, h->P / 1024);
+        double sx = 0.0, sy = 0.0, sz = 0.0;
+        int64_t cnt = 0;
+        for (int64_t q = 0; q < h->P; q += stride, ++cnt) { sx += pts[3 * q]; sy += pts[3 * q + 1]; sz += pts[3 * q + 2]; }
+        h->origin = Origin{sx / (double)cnt, sy / (double)cnt, sz / (double)cnt};
+        if (!std::isfinite(h->origin.x + h->origin.y + h->origin.z)) h->origin = Origin{0.0, 0.0, 0.0};
+    }
     HIPCHK(h, hipStreamSynchronize(h->stream));      // the staging buffer may still be in flight
     const double t0 = now_s();
     hipError_t err = hipSuccess;
@@ -1311,6 +1399,8 @@ int sfmba_debug_option(sfmba_handle* h, const char* name, int64_t value) {
     else if (n == "precond") h->dbg.precond = v;
     else if (n == "pcg_local") h->dbg.pcg_local = v;
     else if (n == "pcg_split") h->dbg.pcg_split = v;
+    else if (n == "pcg_mixed") h->dbg.pcg_mixed = v;
+    else if (n == "pcg_mixed_b") h->dbg.pcg_mixed_b = v;
     else if (n == "cost_rider") h->dbg.cost_rider = v;
     else if (n == "rhsrec") h->dbg.rhsrec = v;
     else if (n == "xcd_chunks") h->dbg.xcd_chunks = v;
@@ -1813,10 +1903,13 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
         chunk_ptr_b.clear();
         h->xcd_b = h->dbg.xcd_chunks == 1 || (h->dbg.xcd_chunks != 0 && P >= 250000);
         if (h->xcd_b) {
-            constexpr int kX = 8;
-            chunk_ptr_b.resize((size_t)C + 1);
+            // row (8 g + k) 4 + j = camera 4 g + j, range k: the four waves of workgroup 8 g + k (XCD k) take the pieces of
+            // four cameras over the same point range (k_cam_schur_w); cameras behind the last one are padding (camera -1)
+            constexpr int kX = kWaveChunkRanges, kG = kWaveChunkCams;
+            static_assert(kX == 8, "one range per XCD");
+            const int64_t groups = (C + kG - 1) / kG;
+            chunks_b.assign((size_t)(groups * kX * kG), make_int4(-1, 0, 0, kX));
             for (int64_t c = 0; c < C; ++c) {
-                chunk_ptr_b[c] = (int)chunks_b.size();
                 const int b = cam_ptr[c], e = cam_ptr[c + 1];
                 int prev = b;
                 for (int k = 0; k < kX; ++k) {
@@ -1827,11 +1920,10 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
                         while (lo < hi) { const int mid = (lo + hi) >> 1; if (pi[perm[mid]] < p_hi) lo = mid + 1; else hi = mid; }
                         bound = lo;
                     }
-                    chunks_b.push_back(make_int4((int)c, prev, bound, kX));
+                    chunks_b[(size_t)(((c / kG) * kX + k) * kG + c % kG)] = make_int4((int)c, prev, bound, kX);
                     prev = bound;
                 }
             }
-            chunk_ptr_b[C] = (int)chunks_b.size();
         }
         h->n_chunks_b = (int)chunks_b.size();
     }
@@ -1885,6 +1977,9 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     h->sweep_rc_g = !h->sweep_rc && h->dbg.sweep_rc != 0;      // too many cameras for the LDS: the table lives in L2
     h->pcg_fused = (h->lds_vec || h->sweep_rc) && C <= kSweepThreads;
     if (h->dbg.pcg_fused == 0) h->pcg_fused = false;
+    // fp32 operands in the implicit Schur product: with fp32 storage (BASELINE config 5 names it), or on request
+    h->mixed = (h->sweep_rc || h->sweep_rc_g) && (h->dbg.pcg_mixed == 1 || (h->dbg.pcg_mixed != 0 && f32));
+    h->mixed_b = h->mixed && h->dbg.pcg_mixed_b != 0;
 
     // ---- device arrays: grow-only; the index / pixel arrays keep their re-used prefix when they grow -------------
     const size_t esz = f32 ? sizeof(float) : sizeof(double);     // element size of the per-observation streams
@@ -1951,6 +2046,12 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     HIPCHK(h, h->vtmp.ensure(sizeof(double) * 6 * C));
     HIPCHK(h, h->vcm.ensure(sizeof(double) * 6 * C));
     if (h->sweep_rc_g) HIPCHK(h, h->rctab.ensure(sizeof(double) * kRcRow * (size_t)C));
+    if (h->mixed) {
+        HIPCHK(h, h->rt32.ensure(sizeof(float) * kRt32 * (size_t)C));
+        HIPCHK(h, h->rtd.ensure(sizeof(double) * kRt32 * (size_t)C));
+        HIPCHK(h, h->rec32.ensure(sizeof(float) * kRec32 * (size_t)P));
+        if (h->sweep_rc_g) HIPCHK(h, h->rctab32.ensure(sizeof(float) * kRc32Row * (size_t)C));
+    }
     // k_update_scale: cameras one element per thread, points kScalePts points per thread (all loads of a thread in flight
     // together); at most 1024 partial rows, summed by k_jdot's rider workgroup
     h->scale_pts = P >= 65536 ? 2 : 1;
@@ -2094,6 +2195,7 @@ int sfmba_schur_matvec(sfmba_handle* h, const double* x, const double* dc, const
                        h->gp.as<double>(), (const double*)nullptr, h->e.as<double>(), (int)h->P, 0.0,
                        vinv_ptr(h), (double*)nullptr, (const double*)nullptr, (double*)nullptr);
     LAUNCHED(h);
+    CHK(launch_mixed_prep(h, h->x, h->tab));
     CHK(schur_product_standalone(h, h->vtmp.as<double>()));
     CHK(exchange(h, h->acc(), 6 * C, 0));
     std::vector<double> a(6 * C);
@@ -2177,6 +2279,7 @@ int sfmba_time_kernel(sfmba_handle* h, const double* x, int32_t which, int32_t r
                            1e-6, vinv_ptr(h), h->rec + 3, (const double*)(h->x + 6 * h->C),
                            h->use_rhsrec ? h->rhsrec.as<double>() : (double*)nullptr);
         LAUNCHED(h);
+        CHK(launch_mixed_prep(h, h->x, h->tab));
         // v = the camera slice of the gradient, as plane-major planes (and camera-major when v is not staged in LDS)
         hipLaunchKernelGGL(k_transpose, dim3((unsigned)((6 * h->C + 255) / 256)), dim3(256), 0, h->stream,
                            (const double*)h->g.as<double>(), (int)h->C, 6, h->vtmp.as<double>(), (const PcgCtrl*)nullptr, 0);
@@ -2395,7 +2498,8 @@ static int solve_impl(sfmba_handle* h, const double* x_start, double* x_inout, c
                                vinv_ptr(h), h->rec + 3,
                                one_rank ? (const double*)h->partB() : (const double*)nullptr, np, opt.pcg_tol,
                                std::max(opt.pcg_tol, opt.pcg_tol_max), (const double*)(h->x + 6 * C),
-                               (h->use_rhsrec && !(h->dense && one_rank)) ? h->rhsrec.as<double>() : (double*)nullptr);   // (read by k_cam_rhs_diag only)
+                               (h->use_rhsrec && !(h->dense && one_rank)) ? h->rhsrec.as<double>() : (double*)nullptr,   // (read by k_cam_rhs_diag only)
+                               (h->dense && one_rank) ? MixedPrep{nullptr, nullptr, nullptr, nullptr, Origin{0.0, 0.0, 0.0}} : mixed_prep(h, h->tab));
             LAUNCHED(h);
         }
         const bool dense = h->dense && one_rank;               // (sharded: the block pairs would need their own all-reduce)

@@ -3,8 +3,11 @@ the per-observation streams with fp64 arithmetic and accumulation (the per-GPU s
 observations; the camera-side sizes, which decide operand placement, are the same).
 
 At this camera count the camera table of K1 no longer fits the LDS (its rows are fetched from L2), pass A of the Schur
-product recomputes its blocks from a table R | T | a' | u_T that k_rc_table writes to global memory (so the product is
-exact fp64 in BOTH storage modes: no stored fp32 block is ever applied), and the PCG update is a kernel of its own.
+product recomputes its blocks from a table R | T | a' | u_T that k_rc_table writes to global memory, and the PCG update is
+a kernel of its own.  In fp32-storage mode the product inside the PCG is the MIXED-PRECISION one configs[4] names: fp32
+operands (camera rows, point records), fp64 arithmetic and accumulation -- within 1e-7 of the exact product (bound in the
+test: 1e-6), PCG iterations count for count those of the recorded fp64 oracle run; with fp64 storage, or behind debug
+option pcg_mixed = 0, the product is exact fp64 (no stored fp32 block is ever applied).
 Checked: kernel parity against the oracle on a 200k-observation slice of the same problem, size-independent properties
 at full size, the full solves against the recorded oracle run (tests/golden/oracle_cfg5.json), and that the solve is
 reproducible: same input, same iteration counts, same bits.
@@ -76,10 +79,23 @@ def test_cfg5_slice_parity_vs_oracle(cfg5):
             z = np.einsum("pij,pj->pi", np.linalg.inv(Vd), yy)
             ref = np.einsum("cij,cj->ci", nb.U, vc) + dc * vc
             np.add.at(ref, args[2], -np.einsum("nij,nj->ni", nb.W, z[args[3]]))
-            assert _rel(y, ref.ravel()) < 1e-9
             w = rng.normal(size=6 * C)
             yw = be.schur_matvec(x, dc, dp, w)
-            assert abs(v @ yw - w @ y) <= 1e-10 * abs(v @ yw)
+            if bits == 64:
+                assert _rel(y, ref.ravel()) < 1e-9
+                assert abs(v @ yw - w @ y) <= 1e-10 * abs(v @ yw)
+            else:
+                # fp32 operands (R, T - o, X - o, a', u_T, z), fp64 arithmetic: measured 1e-7 of the exact product and
+                # symmetric to 1e-7 (both passes see the same rounded operands; z and a' are rounded themselves)
+                assert 1e-12 < _rel(y, ref.ravel()) < 1e-6
+                assert abs(v @ yw - w @ y) <= 1e-6 * abs(v @ yw)
+                # ... and the exact fp64 product stays available in this storage mode
+                be.debug_option("pcg_mixed", 0)
+                be.set_problem(*args)
+                y = be.schur_matvec(x, dc, dp, v)
+                yw = be.schur_matvec(x, dc, dp, w)
+                assert _rel(y, ref.ravel()) < 1e-9
+                assert abs(v @ yw - w @ y) <= 1e-10 * abs(v @ yw)
         finally:
             be.close()
     # the debug form sweep_rc = 0 in fp32-storage mode really applies rounded blocks (pass A the stored ones, pass B its
@@ -130,8 +146,8 @@ def test_cfg5_full_size_fp32_storage(cfg5):
         v, w = rng.normal(size=6 * C), rng.normal(size=6 * C)
         Sv, Sw = be.schur_matvec(pb.x0, dc, dp, v), be.schur_matvec(pb.x0, dc, dp, w)
         Svw = be.schur_matvec(pb.x0, dc, dp, 2.0 * v - 3.0 * w)
-        assert _rel(Svw, 2.0 * Sv - 3.0 * Sw) < 1e-10
-        assert abs(v @ Sw - w @ Sv) <= 1e-10 * abs(v @ Sw) and v @ Sv > 0
+        assert _rel(Svw, 2.0 * Sv - 3.0 * Sw) < 1e-6                  # (fp32 operands: a', u_T, z are rounded per product)
+        assert abs(v @ Sw - w @ Sv) <= 1e-6 * abs(v @ Sw) and v @ Sv > 0
         # (4) full solves with the reference's tolerance: converge to the noise floor of the generator, and
         #     back-to-back solves from the same x0 are THE SAME solve -- iteration counts equal, every bit of x
         #     equal (no atomics anywhere; the gradient does not carry fp32 noise, so ftol = 1e-10 terminates the

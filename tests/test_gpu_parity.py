@@ -221,7 +221,7 @@ def dbg():
             touched.append((b, name))
     yield set_
     defaults = dict(pcg_fused=-1, tab_lds=-1, vec_lds=-1, cam_chunk=0, pcg_guess_bias=0, sweep_rc=-1, dense=-1, precond=-1, pcg_local=-1,
-                    pcg_split=-1, rhsrec=-1, cost_rider=-1, xcd_chunks=-1)
+                    pcg_split=-1, rhsrec=-1, cost_rider=-1, xcd_chunks=-1, pcg_mixed=-1, pcg_mixed_b=-1)
     for b, name in touched:
         b.debug_option(name, defaults[name])
 
@@ -253,6 +253,52 @@ def test_operand_placements_and_camera_chunking(be, orc, dbg):
         assert _rel(y, ref[0]) < 1e-11
         assert (res.status, res.nfev) == (ref[1].status, ref[1].nfev)
         assert abs(res.cost - ref[1].cost) <= 1e-10 * ref[1].cost
+
+
+def test_mixed_precision_schur_product(be, orc, dbg):
+    """BASELINE configs[4]: "mixed-precision PCG with fp64 accumulation".  Debug option pcg_mixed = 1 (the default with
+    fp32 storage) runs the implicit Schur product of the PCG on fp32 OPERANDS -- camera rows R | T - o | a' | u_T, point
+    records X - o | z -- with every arithmetic operation and sum in fp64; gradient, blocks, right-hand side, preconditioner
+    and the PCG's own vectors stay fp64.  Checked on the LDS-table form (<= 1100 cameras, fused and two-kernel PCG), on
+    the table-in-global-memory form (LDS-DMA row slabs), with pass B on fp32 records and on its fp64 ones, with the
+    XCD-aware chunk table (one wave per chunk, camera count not a multiple of four, cameras with empty ranges), and on a
+    scene far from the coordinate origin (coordinates are rounded relative to an origin near the points):
+    product within 1e-6 of the oracle's (measured 1e-7), symmetric to 1e-6; whole solves take the iterations of the
+    exact product -- status, nfev, njev, PCG iterations per outer iteration -- and end at the same cost."""
+    import sfmba
+    tls = sfmba.get_backend(0)
+    dbg((be, tls), "dense", 0)
+    for C, P, N, shift in ((37, 400, 5000, 0.0), (300, 4000, 30000, 0.0), (1300, 4000, 40000, 0.0), (37, 400, 5000, 4.0e6)):
+        pb = sfmba.make_problem(C, P, N, seed=3)
+        if shift:                                                # the same scene 4000 km from the origin
+            x0 = pb.x0.copy()
+            x0[:6 * C].reshape(C, 6)[:, 3:] += shift
+            x0[6 * C:] += shift
+            pb = sfmba.BAProblem(C, P, pb.camera_indices, pb.point_indices, pb.points_2d, pb.K, x0, pb.x_true)
+        dbg((be, tls), "pcg_mixed", 0)
+        nb = _blocks_case(be, orc, pb)
+        y_ref = _matvec_case(be, orc, pb, nb)
+        exact = sfmba.least_squares(sfmba.compute_residuals, pb.x0, x_scale="jac", ftol=1e-10, method="trf", args=pb.args)
+        hist = tls.pcg_history()
+        for mixed_b, xcd, fused in ((-1, -1, -1), (0, -1, -1), (-1, 1, -1), (0, 1, -1), (-1, -1, 0)):
+            for name, v in (("pcg_mixed", 1), ("pcg_mixed_b", mixed_b), ("xcd_chunks", xcd), ("pcg_fused", fused)):
+                dbg((be, tls), name, v)
+            be.set_problem(*pb.args)
+            dc = 1e-3 * np.einsum("cii->ci", nb.U).ravel() + 1e-6
+            dp = 1e-3 * np.einsum("pii->pi", nb.V).ravel() + 1e-6
+            v = np.random.default_rng(0).normal(size=6 * C)          # (the vector of _matvec_case)
+            w = np.random.default_rng(5).normal(size=6 * C)
+            Sv, Sw = be.schur_matvec(pb.x0, dc, dp, v), be.schur_matvec(pb.x0, dc, dp, w)
+            tag = (C, shift, mixed_b, xcd, fused)
+            assert 1e-13 < _rel(Sv, y_ref) < 1e-6, tag
+            assert abs(w @ Sv - v @ Sw) <= 1e-6 * abs(w @ Sv), tag
+            res = sfmba.least_squares(sfmba.compute_residuals, pb.x0, x_scale="jac", ftol=1e-10, method="trf", args=pb.args)
+            assert (res.status, res.nfev, res.njev) == (exact.status, exact.nfev, exact.njev), tag
+            assert tls.pcg_history() == hist, tag
+            assert abs(res.cost - exact.cost) <= 1e-9 * exact.cost, tag
+            assert np.abs(res.x - exact.x).max() <= 1e-6 * np.abs(exact.x).max(), tag
+        for name in ("pcg_mixed", "pcg_mixed_b", "xcd_chunks", "pcg_fused"):
+            dbg((be, tls), name, -1)
 
 
 def test_results_are_bitwise_reproducible(be):
