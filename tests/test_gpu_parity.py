@@ -295,7 +295,9 @@ def test_mixed_precision_schur_product(be, orc, dbg):
             res = sfmba.least_squares(sfmba.compute_residuals, pb.x0, x_scale="jac", ftol=1e-10, method="trf", args=pb.args)
             assert (res.status, res.nfev, res.njev) == (exact.status, exact.nfev, exact.njev), tag
             assert tls.pcg_history() == hist, tag
-            assert abs(res.cost - exact.cost) <= 1e-9 * exact.cost, tag
+            # (the shifted scene stops on xtol after its first steps -- |x| is huge -- i.e. NOT at a minimum, where the
+            # 1e-7 perturbation of the PCG iterates shows in the ninth digit of the cost; converged runs agree to 1e-12)
+            assert abs(res.cost - exact.cost) <= (1e-8 if shift else 1e-9) * exact.cost, tag
             assert np.abs(res.x - exact.x).max() <= 1e-6 * np.abs(exact.x).max(), tag
         for name in ("pcg_mixed", "pcg_mixed_b", "xcd_chunks", "pcg_fused"):
             dbg((be, tls), name, -1)
