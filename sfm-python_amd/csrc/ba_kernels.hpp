@@ -795,6 +795,63 @@ __device__ __forceinline__ double cam_block_total(double (&a)[NV], double (*red)
     return s;
 }
 
+// Sharded solves, the all-reduce of a per-camera sum INSIDE the kernel that produces it (world > 1): the workgroup of
+// camera c holds the camera's local sums -- pass B's six, the 27 of K3 or of the right-hand-side pass -- the moment its own
+// reduction ends, so its first lanes exchange them themselves -- each stores its value into
+// slot [parity][rank][k][c] of every PEER's staging buffer (remote stores over xGMI), polls the slots of the peers in
+// its own buffer until they are no longer EMPTY, adds in RANK ORDER (bitwise the same total on all ranks), marks the
+// slots EMPTY again and carries on with the camera's PCG bookkeeping as on a single rank.  No launch of its own
+// (k_p2p_pcg: 8-10 us per PCG iteration, a third of a sharded iteration at 125k observations per rank), no grid-wide
+// arrival, and NO FENCE: a value is its own flag (EMPTY is a NaN payload no computation produces), so nothing has to
+// be ordered against anything -- a first version with a flag per camera behind a system-scope release / acquire pair
+// in every one of the 1000-5000 workgroups ran 1.4x (cfg4 / 8) to 2.8x (cfg5 / 8) SLOWER than the separate launch:
+// every such fence writes back / invalidates the L2 under the other workgroups' gathers.
+// Pass B alternates two slot sets (parity = iters & 1): a rank reaches iteration i + 2 only after every peer has posted
+// i + 1, i.e. has consumed (and emptied) i; between two solves lie grid-wide collectives (cost, scalars).  K3 and the
+// right-hand-side pass have one slot set each: two launches of either are always separated by such a collective.  Launches behind convergence return
+// before they exchange, on every rank alike.  Deadlock-free although lanes wait: a workgroup posts BEFORE it waits and
+// the hardware dispatches workgroups in index order, so the lowest-indexed waiting camera of any rank always finds its
+// peers' posts on the way.  The wait gives up after `timeout` ticks and raises *error, so the grid always drains.
+constexpr unsigned long long kCamSlotEmpty = 0xFFF8A5A5FFF8A5A5ull;      // (both halves equal: set by a 32-bit fill)
+struct CamExchange {
+    double* data[16];                    // camera-slot region of every rank's staging buffer (own included):
+                                         // [2][W][6][C] pass B | [W][27][C] K3 | [W][27][C] right-hand side
+    int rank, world;                     // world <= 1: no exchange
+    int C;
+    unsigned* error;                     // local: set to 1 on timeout
+    long long timeout;                   // ticks of the 100 MHz wall clock
+};
+
+// lane k (< nv) of a camera's workgroup: `out` = its local sum -> the sum over the ranks, in rank order.  base = first
+// double of the slot set inside the region; slot (q, k, c) at base + (q nv + k) C + c.
+__device__ __forceinline__ double cam_exchange_value(const CamExchange& cx, size_t base, int nv, int k, int C, int c, double out) {
+    if (*cx.error != 0u) return out;                         // an earlier exchange of this solve gave up: do not wait again
+    const size_t mine = base + ((size_t)cx.rank * nv + k) * C + c;
+    for (int q = 0; q < cx.world; ++q)
+        if (q != cx.rank) __hip_atomic_store(cx.data[q] + mine, out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    double sum = 0.0;
+    const long long t0 = wall_clock64();
+    for (int q = 0; q < cx.world; ++q) {                     // rank order: bitwise the same sum on every rank
+        double v = out;
+        if (q != cx.rank) {
+            unsigned long long* slot = reinterpret_cast<unsigned long long*>(cx.data[cx.rank] + base + ((size_t)q * nv + k) * C + c);
+            unsigned long long bits;
+            while ((bits = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) == kCamSlotEmpty) {
+                if (wall_clock64() - t0 > cx.timeout) { atomicExch(cx.error, 1u); break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            __hip_atomic_store(slot, kCamSlotEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);     // consumed
+            v = __longlong_as_double((long long)bits);
+        }
+        sum = q == 0 ? v : sum + v;
+    }
+    return sum;
+}
+__host__ __device__ constexpr size_t cam_slots_pcg(int world, int C, int par) { return (size_t)par * world * 6 * C; }
+__host__ __device__ constexpr size_t cam_slots_k3(int world, int C) { return (size_t)2 * world * 6 * C; }
+__host__ __device__ constexpr size_t cam_slots_rhs(int world, int C) { return cam_slots_k3(world, C) + (size_t)world * 27 * C; }
+__host__ __device__ constexpr size_t cam_slots_total(int world, int C) { return cam_slots_rhs(world, C) + (size_t)world * 27 * C; }
+
 // K3: U_c = sum Jc^T Jc (21, packed upper triangle), g_c = sum Jc^T r (6) of one camera chunk.
 // A camera with a single chunk stores straight into Ugc[c][27]; otherwise the chunk's 27 sums go to
 // partial[chunk][27] and k_cam_combine adds them.
@@ -804,7 +861,7 @@ __global__ __launch_bounds__(kCamThreads) void k_cam_blocks(CamMajor cm, const d
                                                             double* __restrict__ Ugc, double* __restrict__ partial,
                                                             const double* __restrict__ skip, int n_chunks,
                                                             const int* __restrict__ pt_idx, int N, PointBlocksOut pb,
-                                                            Piggyback fin, Mailbox mb) {
+                                                            Piggyback fin, Mailbox mb, CamExchange cx) {
     __shared__ double red[kCamWaves][27];
     // One more rider (fin.part != null: the FIRST workgroup of the grid): the sum of the cost partials the residual
     // launch in front of this one left, and the hand-off post behind it -- k_finish's work without its launch; the host
@@ -862,8 +919,9 @@ __global__ __launch_bounds__(kCamThreads) void k_cam_blocks(CamMajor cm, const d
             for (int i = 0; i < 6; ++i) a[21 + i] += jc[i] * rx + jc[6 + i] * ry;
         }
     }
-    const double s = cam_block_total<27>(a, red);
+    double s = cam_block_total<27>(a, red);
     if (threadIdx.x < 27) {
+        if (cx.world > 1) s = cam_exchange_value(cx, cam_slots_k3(cx.world, cx.C), 27, threadIdx.x, cx.C, ch.x, s);
         if (ch.w == 1) Ugc[(size_t)ch.x * 27 + threadIdx.x] = s;
         else partial[(size_t)bid * 27 + threadIdx.x] = s;
     }
@@ -2251,6 +2309,7 @@ struct PcgLocal {
     double* __restrict__ part;           // null: not the local form
 };
 
+
 // MIXED (MODE 0, exact-block form): the operands of the mixed-precision product -- R, T - o, a', u_T rounded to fp32
 // exactly as pass A's table holds them, the point and z from its 32-byte fp32 record (`rec` then points at rec32).
 struct MixedB { const double* __restrict__ rtd; };      // [C][12] = R | T - o, fp32 values held as doubles
@@ -2260,7 +2319,7 @@ __global__ __launch_bounds__(kCamThreads) void k_cam_schur(CamMajor cm, const do
                                                            const double* __restrict__ vin, int C,
                                                            double* __restrict__ acc, double* __restrict__ partial,
                                                            const PcgCtrl* __restrict__ ctrl_done, int set, PcgLocal pl,
-                                                           MixedB mxb) {
+                                                           MixedB mxb, CamExchange cx) {
     static_assert(!MIXED || (MODE == 0 && !ROUND), "mixed operands: the product, exact-block form");
     __shared__ double red[kCamWaves][6];
     if (ctrl_done != nullptr) {
@@ -2410,6 +2469,8 @@ __global__ __launch_bounds__(kCamThreads) void k_cam_schur(CamMajor cm, const do
             out = -tot[threadIdx.x];
         }
     }
+    if (MODE == 0 && cx.world > 1 && threadIdx.x < 6)        // (every camera is a single chunk in this form)
+        out = cam_exchange_value(cx, cam_slots_pcg(cx.world, C, l_it & 1), 6, threadIdx.x, C, ch.x, out);
     if (threadIdx.x < 6) {
         if (ch.w == 1) acc[(size_t)threadIdx.x * C + ch.x] = out;
         else partial[(size_t)blockIdx.x * 6 + threadIdx.x] = out;
@@ -2596,7 +2657,7 @@ __global__ __launch_bounds__(kRhsThreads) void k_cam_rhs_diag(CamMajor cm, const
                                                               const double* __restrict__ rec,
                                                               const double* __restrict__ Vinv, KMat K, int C,
                                                               double* __restrict__ out, double* __restrict__ partial,
-                                                              RhsPrecond mp, const double* __restrict__ rhsrec) {
+                                                              RhsPrecond mp, const double* __restrict__ rhsrec, CamExchange cx) {
     __shared__ double red[kRhsThreads / 64][27];
     const int4 ch = cm.chunks[blockIdx.x];
     double t[kCamTab];
@@ -2667,8 +2728,9 @@ __global__ __launch_bounds__(kRhsThreads) void k_cam_rhs_diag(CamMajor cm, const
                 for (int j = i; j < 6; ++j) a[n++] += jc[i] * m0[j] + jc[6 + i] * m1[j];
         }
     }
-    const double s = cam_block_total<27, kRhsThreads / 64>(a, red);
+    double s = cam_block_total<27, kRhsThreads / 64>(a, red);
     if (threadIdx.x < 27) {
+        if (cx.world > 1) s = cam_exchange_value(cx, cam_slots_rhs(cx.world, C), 27, threadIdx.x, C, ch.x, s);
         if (ch.w == 1) out[(size_t)threadIdx.x * C + ch.x] = s;
         else partial[(size_t)blockIdx.x * 27 + threadIdx.x] = s;
     }

@@ -250,6 +250,7 @@ struct sfmba_handle {
         int xcd_chunks = -1;                 // 1 / 0: camera lists cut at the eight point-range boundaries (one chunk per XCD) whatever the size
         int rhsrec = -1;                     // 1 / 0: the rhs + preconditioner pass gathers its own 128-byte records whatever the size
         int cost_rider = -1;                 // 0: the trial cost is summed and posted by a k_finish launch of its own
+        int pcg_inline = -1;                 // 0: sharded solves keep the collective of the product as a launch of its own
         int pcg_mixed_b = -1;                // 0: pass B keeps fp64 point records although pass A runs on fp32 operands
         int pcg_mixed = -1;                  // 1 / 0: fp32 operands in the implicit Schur product whatever the storage mode
         int pcg_split = -1;                  // 1: the local form with its tail in a kernel of its own (k_pcg_tail) on a
@@ -304,6 +305,7 @@ struct sfmba_handle {
         void* opened[kP2pMaxRanks] = {};     // peers' buffers as mapped here (null for own)
         double* data[kP2pMaxRanks] = {};
         unsigned long long* flags[kP2pMaxRanks] = {};
+        double* camdata[kP2pMaxRanks] = {};  // [2][W][6 C]: the product's per-camera exchange inside pass B (CamExchange)
         unsigned* words = nullptr;           // [0] ticket, [1] error, [2..3] uint64 count of performed collectives
         int64_t calls = 0;
         bool first_in_solve = true;          // the next collective is the rendezvous of a solve (long timeout)
@@ -341,6 +343,8 @@ struct sfmba_handle {
     bool pcg_fused = false;               // PCG update fused into the launch of pass A (v in LDS, C <= 1024)
     bool pcg_local = false;               // ... with the per-camera bookkeeping in pass B (one rank, single-chunk cameras)
     bool pcg_local2 = false;              // the same bookkeeping with the light update as a kernel of its own (> 1024 cameras)
+    bool pcg_inline = false;              // sharded, direct link, single-chunk cameras: the product's all-reduce runs inside
+                                          // pass B, camera by camera (CamExchange), and the iteration is the local form
     bool pcg_split = false;               // local form whose per-camera tail runs behind the reduction (k_p2p_pcg / k_pcg_tail)
                                           // instead of inside pass B: sharded solves, cameras of several chunks
     DevBuf pcg_part;                      // [4][C] partial dot products of the local form
@@ -436,6 +440,21 @@ void p2p_fill_args(sfmba_handle* h, P2pArgs& a) {
     a.timeout = p.first_in_solve ? 6000000000ll : 300000000ll;
     if (h->dbg.p2p_timeout_ms > 0) a.timeout = 100000ll * h->dbg.p2p_timeout_ms;       // test hook
     p.first_in_solve = false;
+}
+
+// sharded over the direct link, every camera a single chunk: per-camera sums are all-reduced by the workgroup that
+// forms them (CamExchange) instead of by a collective launch behind the kernel
+bool cam_inline(const sfmba_handle* h) { return h->p2p.ready && !h->cam_multi && h->dbg.pcg_inline != 0; }
+
+CamExchange cam_exchange(sfmba_handle* h) {
+    CamExchange cx{};
+    auto& p = h->p2p;
+    for (int q = 0; q < p.world; ++q) cx.data[q] = p.camdata[q];
+    cx.rank = p.rank; cx.world = p.world; cx.C = (int)h->C; cx.error = p.words + 1;
+    cx.timeout = p.first_in_solve ? 6000000000ll : 300000000ll;            // (as p2p_fill_args)
+    if (h->dbg.p2p_timeout_ms > 0) cx.timeout = 100000ll * h->dbg.p2p_timeout_ms;
+    p.first_in_solve = false;
+    return cx;
 }
 
 int p2p_allreduce(sfmba_handle* h, double* ptr, int64_t count, int op, const int* cancel,
@@ -707,6 +726,8 @@ int launch_normal_blocks_v(sfmba_handle* h, const double* x, const double* tab, 
     (void)x;
     const int tiles = (int)((h->N + 63) / 64);
     const int riders = (tiles + kCamThreads - 1) / kCamThreads;
+    CamExchange cx{};
+    if (cam_inline(h)) { cx = cam_exchange(h); ++h->p2p.calls; ++h->n_collectives; }
     Piggyback fin{};
     if (cost_parts > 0) {
         fin = Piggyback{h->part.as<double>(), h->scal(), FinishJob{}, 1, 1, 0};
@@ -715,9 +736,11 @@ int launch_normal_blocks_v(sfmba_handle* h, const double* x, const double* tab, 
     }
     hipLaunchKernelGGL((k_cam_blocks<F32>), dim3(h->n_chunks + riders + (cost_parts > 0 ? 1 : 0)), dim3(kCamThreads), 0, h->stream,
                        cam_major(h), tab, rec, h->K, h->Ugc(), h->cam_partial.as<double>(), h->skip, (int)h->n_chunks,
-                       (const int*)h->pt_idx.as<int>(), (int)h->N, point_blocks_out(h), fin, mb);
+                       (const int*)h->pt_idx.as<int>(), (int)h->N, point_blocks_out(h), fin, mb, cx);
     LAUNCHED(h);
-    return launch_cam_combine(h, 27, h->Ugc(), 27, 1, h->skip, nullptr);
+    CHK(launch_cam_combine(h, 27, h->Ugc(), 27, 1, h->skip, nullptr));
+    if (cx.world > 1 || cam_inline(h)) return 0;               // [U | g_c] was summed over the ranks camera by camera
+    return exchange(h, h->Ugc(), 27 * h->C, 0);
 }
 int launch_normal_blocks(sfmba_handle* h, const double* x, const double* tab, const double* rec, int cost_parts = 0,
                          const Mailbox& mb = Mailbox{}) {
@@ -838,9 +861,12 @@ int launch_pcg_fused(sfmba_handle* h, int L) {
 // Pass B (camera-major): MODE 0  acc = sum Jc^T (Jc v - Jp z) with z from pass A; MODE 1  acc = -sum Jc^T Jp e.
 // ctrl_done / set: see k_cam_schur.
 template <int MODE>
-int launch_cam_schur(sfmba_handle* h, const double* vin, const PcgCtrl* ctrl_done, int set, bool local = false) {
+int launch_cam_schur(sfmba_handle* h, const double* vin, const PcgCtrl* ctrl_done, int set, bool local = false,
+                     bool inline_exchange = false) {
     const PcgLocal pl{h->Dc.as<double>(), h->Minv.as<double>(), h->vecs.as<double>(),
                       local ? h->pcg_part.as<double>() : (double*)nullptr};
+    CamExchange cx{};
+    if (MODE == 0 && inline_exchange) { cx = cam_exchange(h); ++h->p2p.calls; ++h->n_collectives; }
     // MODE 0 with the XCD-aware table: chunk 8 c + k runs on XCD k and gathers records of point range k only
     const bool tb = MODE == 0 && h->xcd_b;
     const CamMajor cm = tb ? CamMajor{h->cam_chunks_b.as<int4>(), h->cm_pt.as<int>(), h->cm_uv.as<double>()} : cam_major(h);
@@ -866,15 +892,15 @@ int launch_cam_schur(sfmba_handle* h, const double* vin, const PcgCtrl* ctrl_don
     if (h->f32 && !h->sweep_rc && !h->sweep_rc_g)   // pass A applies the stored fp32 blocks: pass B rounds its own the same way
         hipLaunchKernelGGL((k_cam_schur<MODE, true>), dim3(grid), dim3(kCamThreads), 0, h->stream, cm,
                            (const double*)h->tab, (const double*)h->rec, h->K, vin, (int)h->C, h->acc(),
-                           h->cam_partial.as<double>(), ctrl_done, set, pl, mxb);
+                           h->cam_partial.as<double>(), ctrl_done, set, pl, mxb, cx);
     else if (MODE == 0 && h->mixed_b)               // fp32 operands: the same rounded R, T - o, X - o, a', u_T as pass A
         hipLaunchKernelGGL((k_cam_schur<0, false, true>), dim3(grid), dim3(kCamThreads), 0, h->stream, cm,
                            (const double*)h->tab, reinterpret_cast<const double*>(h->rec32.as<float>()), h->K, vin, (int)h->C,
-                           h->acc(), h->cam_partial.as<double>(), ctrl_done, set, pl, mxb);
+                           h->acc(), h->cam_partial.as<double>(), ctrl_done, set, pl, mxb, cx);
     else
         hipLaunchKernelGGL((k_cam_schur<MODE, false>), dim3(grid), dim3(kCamThreads), 0, h->stream, cm,
                            (const double*)h->tab, (const double*)h->rec, h->K, vin, (int)h->C, h->acc(),
-                           h->cam_partial.as<double>(), ctrl_done, set, pl, mxb);
+                           h->cam_partial.as<double>(), ctrl_done, set, pl, mxb, cx);
     LAUNCHED(h);
     return launch_cam_combine(h, 6, h->acc(), 1, (int)h->C, nullptr, ctrl_done ? &ctrl_done->done : nullptr, tb);
 }
@@ -896,17 +922,20 @@ int launch_rhs_and_preconditioner(sfmba_handle* h) {
         CHK(launch_cam_schur<1>(h, nullptr, nullptr, 0));
         return exchange(h, h->acc(), 6 * C, 0);
     }
-    // one rank and single-chunk cameras: every workgroup inverts its own preconditioner block (RhsPrecond)
-    const bool own_inverse = !multi_rank(h) && !h->cam_multi;
+    // single-chunk cameras on one rank, or sharded with the sums exchanged camera by camera inside the pass
+    // (CamExchange): every workgroup holds its camera's complete sums and inverts its own preconditioner block (RhsPrecond)
+    CamExchange cx{};
+    if (cam_inline(h)) { cx = cam_exchange(h); ++h->p2p.calls; ++h->n_collectives; }
+    const bool own_inverse = !h->cam_multi && (!multi_rank(h) || cam_inline(h));
     const RhsPrecond mp = own_inverse ? RhsPrecond{h->Ugc(), h->Dc.as<double>(), h->Minv.as<double>()} : RhsPrecond{nullptr, nullptr, nullptr};
     if (h->f32 && !h->sweep_rc && !h->sweep_rc_g)
         hipLaunchKernelGGL((k_cam_rhs_diag<true>), dim3(h->n_chunks), dim3(kRhsThreads), 0, h->stream, cam_major(h),
                            (const double*)h->tab, (const double*)h->rec, (const double*)vinv_ptr(h), h->K, (int)C,
-                           h->acc(), h->cam_partial.as<double>(), mp, h->use_rhsrec ? (const double*)h->rhsrec.as<double>() : (const double*)nullptr);
+                           h->acc(), h->cam_partial.as<double>(), mp, h->use_rhsrec ? (const double*)h->rhsrec.as<double>() : (const double*)nullptr, cx);
     else
         hipLaunchKernelGGL((k_cam_rhs_diag<false>), dim3(h->n_chunks), dim3(kRhsThreads), 0, h->stream, cam_major(h),
                            (const double*)h->tab, (const double*)h->rec, (const double*)vinv_ptr(h), h->K, (int)C,
-                           h->acc(), h->cam_partial.as<double>(), mp, h->use_rhsrec ? (const double*)h->rhsrec.as<double>() : (const double*)nullptr);
+                           h->acc(), h->cam_partial.as<double>(), mp, h->use_rhsrec ? (const double*)h->rhsrec.as<double>() : (const double*)nullptr, cx);
     LAUNCHED(h);
     if (own_inverse) return 0;
     CHK(launch_cam_combine(h, 27, h->acc(), 1, (int)C, nullptr, nullptr));
@@ -1167,9 +1196,14 @@ int pcg_max_iters(const sfmba_handle* h, const sfmba_options& opt) {
 // x = 0, r = rhs, u = Minv r (acc holds the reduced right-hand side term of pass B, MODE 1)
 int pcg_start(sfmba_handle* h, const sfmba_options& opt) {
     h->pcg_L = 0;
-    h->pcg_split = pcg_split_mode(h);
-    h->pcg_local = h->pcg_fused && h->dbg.pcg_local != 0 && ((!multi_rank(h) && !h->cam_multi && !h->xcd_b) || h->pcg_split);
-    h->pcg_local2 = !h->pcg_fused && h->sweep_rc_g && h->dbg.pcg_local != 0 && ((!multi_rank(h) && !h->cam_multi && !h->xcd_b) || h->pcg_split);
+    // sharded over the direct link with single-chunk cameras: the local form itself, the all-reduce of the product inside
+    // pass B (CamExchange); else the local form with its tail behind the reduction (pcg_split), else the general forms
+    h->pcg_inline = h->p2p.ready && !h->cam_multi && !h->xcd_b && h->dbg.pcg_inline != 0 && h->dbg.pcg_local != 0 &&
+                    h->dbg.precond != 0 && h->dbg.pcg_split != 1 && (h->pcg_fused || h->sweep_rc_g);
+    h->pcg_split = !h->pcg_inline && pcg_split_mode(h);
+    const bool own_cameras = (!multi_rank(h) && !h->cam_multi && !h->xcd_b) || h->pcg_split || h->pcg_inline;
+    h->pcg_local = h->pcg_fused && h->dbg.pcg_local != 0 && own_cameras;
+    h->pcg_local2 = !h->pcg_fused && h->sweep_rc_g && h->dbg.pcg_local != 0 && own_cameras;
     if (h->pcg_fused) {                   // launch 0 of the fused form initialises the solve itself
         h->pcg_tol = opt.pcg_tol;
         h->pcg_cap = pcg_max_iters(h, opt);
@@ -1221,15 +1255,15 @@ int pcg_enqueue(sfmba_handle* h, int count) {
             // a launch that found the solve finished (or finished it) produced no z: its control block (written
             // to slot (L+1)&1) says so, and pass B and the collective behind it are void as well
             const PcgCtrl* cd = ctrl2 + ((L + 1) & 1);
-            CHK(launch_cam_schur<0>(h, h->vecs.as<double>(), cd, L & 1, h->pcg_local && !h->pcg_split));
+            CHK(launch_cam_schur<0>(h, h->vecs.as<double>(), cd, L & 1, h->pcg_local && !h->pcg_split, h->pcg_inline));
             if (h->pcg_split) CHK(launch_reduce_and_tail(h, cd, L & 1));
-            else CHK(exchange(h, h->acc(), 6 * h->C, 0, &cd->done));
+            else if (!h->pcg_inline) CHK(exchange(h, h->acc(), 6 * h->C, 0, &cd->done));
             h->pcg_L = L + 1;
             continue;
         }
         const PcgCtrl* cd = ctrl2 + (L & 1);                     // current until k_pcg_update writes the other one
         CHK(launch_point_sweep(h, h->vecs.as<double>(), ctrl2, L));
-        CHK(launch_cam_schur<0>(h, h->vecs.as<double>(), cd, -1, h->pcg_local2 && !h->pcg_split));
+        CHK(launch_cam_schur<0>(h, h->vecs.as<double>(), cd, -1, h->pcg_local2 && !h->pcg_split, h->pcg_inline));
         if (h->pcg_local2 && h->pcg_split) CHK(launch_reduce_and_tail(h, cd, -1));
         if (h->pcg_local2) {                                    // pass B / the tail did the bookkeeping: the light update
             hipLaunchKernelGGL(k_pcg_update_local, dim3((unsigned)((h->C + 1023) / 1024)), dim3(1024), 0, h->stream,
@@ -1400,6 +1434,7 @@ int sfmba_debug_option(sfmba_handle* h, const char* name, int64_t value) {
     else if (n == "pcg_local") h->dbg.pcg_local = v;
     else if (n == "pcg_split") h->dbg.pcg_split = v;
     else if (n == "pcg_mixed") h->dbg.pcg_mixed = v;
+    else if (n == "pcg_inline") h->dbg.pcg_inline = v;
     else if (n == "pcg_mixed_b") h->dbg.pcg_mixed_b = v;
     else if (n == "cost_rider") h->dbg.cost_rider = v;
     else if (n == "rhsrec") h->dbg.rhsrec = v;
@@ -1504,7 +1539,7 @@ void p2p_close_peers(sfmba_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (int q = 0; q < kP2pMaxRanks; ++q) {
         if (p.opened[q]) (void)hipIpcCloseMemHandle(p.opened[q]);
-        p.opened[q] = nullptr; p.data[q] = nullptr; p.flags[q] = nullptr;
+        p.opened[q] = nullptr; p.data[q] = nullptr; p.flags[q] = nullptr; p.camdata[q] = nullptr;
     }
     p.ready = false;
 }
@@ -1525,7 +1560,8 @@ int sfmba_p2p_export(sfmba_handle* h, int32_t world, void* handle64_out) {
     auto& p = h->p2p;
     p.world = world;
     p.stride = (27 * h->C + 15) / 16 * 16;                // the largest vector exchanged: [U | g_c]
-    const size_t bytes = kP2pFlagBytes + sizeof(double) * 2 * (size_t)world * (size_t)p.stride;
+    const size_t bytes = kP2pFlagBytes + sizeof(double) * 2 * (size_t)world * (size_t)p.stride +
+                         sizeof(double) * cam_slots_total(world, (int)h->C);          // + the per-camera slots (CamExchange)
     // uncached device memory: remote stores land in HBM and local loads do not see stale cache lines
     if (hipExtMallocWithFlags(&p.own, bytes, hipDeviceMallocUncached) != hipSuccess) {
         p.own = nullptr; (void)hipGetLastError();
@@ -1533,6 +1569,10 @@ int sfmba_p2p_export(sfmba_handle* h, int32_t world, void* handle64_out) {
     }
     HIPCHK(h, hipMalloc((void**)&p.words, 4 * sizeof(unsigned)));
     HIPCHK(h, hipMemset(p.own, 0, bytes));
+    {   // the per-camera slots start EMPTY (CamExchange)
+        const size_t cam_off = kP2pFlagBytes + sizeof(double) * 2 * (size_t)world * (size_t)p.stride;
+        HIPCHK(h, hipMemsetD32((hipDeviceptr_t)(static_cast<char*>(p.own) + cam_off), (int)0xFFF8A5A5u, (bytes - cam_off) / 4));
+    }
     HIPCHK(h, hipMemset(p.words, 0, 4 * sizeof(unsigned)));
     HIPCHK(h, hipDeviceSynchronize());
     hipIpcMemHandle_t mh;
@@ -1564,6 +1604,7 @@ int sfmba_p2p_attach(sfmba_handle* h, const void* handles, int32_t rank, int32_t
         }
         p.flags[q] = static_cast<unsigned long long*>(base);
         p.data[q] = reinterpret_cast<double*>(static_cast<char*>(base) + kP2pFlagBytes);
+        p.camdata[q] = p.data[q] + 2 * (size_t)world * (size_t)p.stride;
     }
     // Self-test: 24 rounds over the three message sizes the solver uses (a few scalars, 6 C, 27 C), each a
     // chain of one to three back-to-back collectives on the same vector (parity and sequence protocol without
@@ -2161,7 +2202,6 @@ int sfmba_normal_blocks(sfmba_handle* h, const double* x, double* U, double* V, 
     int np = 0;
     CHK((launch_resjac<true, true>(h, h->x, h->tab, &np)));
     CHK(launch_normal_blocks(h, h->x, h->tab, h->rec));
-    CHK(exchange(h, h->Ugc(), 27 * h->C, 0));
     std::vector<double> ugc(27 * h->C);
     HIPCHK(h, hipMemcpyAsync(ugc.data(), h->Ugc(), sizeof(double) * 27 * h->C, hipMemcpyDeviceToHost, h->stream));
     if (V) HIPCHK(h, hipMemcpyAsync(V, h->V.p, sizeof(double) * 6 * h->P, hipMemcpyDeviceToHost, h->stream));
@@ -2183,7 +2223,6 @@ int sfmba_schur_matvec(sfmba_handle* h, const double* x, const double* dc, const
     int np = 0;
     CHK((launch_resjac<true, true>(h, h->x, h->tab, &np)));
     CHK(launch_normal_blocks(h, h->x, h->tab, h->rec));
-    CHK(exchange(h, h->Ugc(), 27 * h->C, 0));
     // stage dp in e (as explicit diagonal), v in pk -- camera vectors are plane-major on the device
     const int64_t C = h->C;
     std::vector<double> vp(6 * C);
@@ -2219,7 +2258,6 @@ int sfmba_dense_schur(sfmba_handle* h, const double* x, const double* dc, const 
     int np = 0;
     CHK((launch_resjac<true, true>(h, h->x, h->tab, &np)));
     CHK(launch_normal_blocks(h, h->x, h->tab, h->rec));
-    CHK(exchange(h, h->Ugc(), 27 * C, 0));
     std::vector<double> ugc(27 * C), planes(6 * C), accp(6 * C);
     HIPCHK(h, hipMemcpyAsync(ugc.data(), h->Ugc(), sizeof(double) * 27 * C, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -2308,7 +2346,7 @@ int sfmba_time_kernel(sfmba_handle* h, const double* x, int32_t which, int32_t r
                 hipLaunchKernelGGL((k_cam_rhs_diag<false>), dim3(h->n_chunks), dim3(kRhsThreads), 0, h->stream, cam_major(h),
                                    (const double*)h->tab, (const double*)h->rec, (const double*)vinv_ptr(h), h->K, (int)h->C,
                                    h->acc(), h->cam_partial.as<double>(), RhsPrecond{nullptr, nullptr, nullptr},
-                                   h->use_rhsrec ? (const double*)h->rhsrec.as<double>() : (const double*)nullptr);
+                                   h->use_rhsrec ? (const double*)h->rhsrec.as<double>() : (const double*)nullptr, CamExchange{});
                 LAUNCHED(h);
                 break;
             case 10:   // streaming-store ceiling: fill the Jacobian planes, 16 B per lane, one stream
@@ -2416,7 +2454,6 @@ static int solve_impl(sfmba_handle* h, const double* x_start, double* x_inout, c
     };
     auto linearise = [&](int first) -> int {      // normal blocks, scale, gradient, q0..q4 at h->x
         CHK(launch_normal_blocks(h, h->x, h->tab, h->rec));
-        CHK(exchange(h, h->Ugc(), 27 * C, 0));
         CHK(launch_update_scale(h, first));
         CHK(exchange_linearise(h));
         return 0;
@@ -2461,7 +2498,6 @@ static int solve_impl(sfmba_handle* h, const double* x_start, double* x_inout, c
         if (!nb_valid) {                                        // a rejected trial overwrote the blocks and no
             CHK(eval_jac(h->x, h->tab, true));         // step was accepted afterwards
             CHK(launch_normal_blocks(h, h->x, h->tab, h->rec));                       // (nfev limit)
-            CHK(exchange(h, h->Ugc(), 27 * C, 0));
             nb_valid = true;
         }
         // ---- enqueue the whole linear phase ---------------------------------------------------
@@ -2599,7 +2635,6 @@ static int solve_impl(sfmba_handle* h, const double* x_start, double* x_inout, c
             if (trial_post_pending) CHK(launch_normal_blocks(h, h->x_new, h->tab_new, h->rec_new, np_cost, trial_post));
             else CHK(launch_normal_blocks(h, h->x_new, h->tab_new, h->rec_new));
             trial_post_pending = false;
-            CHK(exchange(h, h->Ugc(), 27 * C, 0));
             nb_valid = false;
             CHK(wait_mailbox(h, h->mbox_seq));
             memcpy(h->h_scal, h->mbox, sizeof(double) * kScalSlots);

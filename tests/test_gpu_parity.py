@@ -966,7 +966,10 @@ def _late_rank_worker(rank, world, port, q):
             torch.cuda.synchronize()
         calls_after = ex.n_calls
         q.put(dict(rank=rank, err=err, seconds=dt, cost_ok=float(res_ok.cost), cost_again=float(res_again.cost),
-                   same=bool(np.array_equal(x_ok[:180], x_again[:180])), callback_calls=calls_after))
+                   # (over the direct link the product is reduced camera by camera inside pass B and the PCG bookkeeping
+                   # sums its dot products in that kernel's order; behind the callback it runs in k_pcg_tail: same
+                   # arithmetic, other summation order -- equal to rounding, not to the bit)
+                   same=bool(np.abs(x_ok[:180] - x_again[:180]).max() <= 1e-9 * np.abs(x_ok[:180]).max()), callback_calls=calls_after))
         td.barrier()
         be.close()
     finally:
