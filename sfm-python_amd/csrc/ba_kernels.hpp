@@ -957,6 +957,95 @@ __global__ void k_build_cam_major(const int* __restrict__ perm, const int* __res
     else reinterpret_cast<double2*>(cm_uv)[k] = reinterpret_cast<const double2*>(uv)[i];
 }
 
+// The camera-major order built ON THE DEVICE (the reference hands a new problem to every call, sfm.py:59-71, and the
+// host's counting sort + the upload of its permutation were 0.4-0.5 ms of a 3.6 ms call at a million observations): a
+// stable counting sort of the point-major positions by camera in three launches.  The observations are cut into
+// kSortSlices contiguous slices, one WAVE each:
+//   k_cam_hist     per-slice histogram over the cameras (LDS counters)          -> hist[slice][C]
+//   k_cam_offsets  one thread per camera: first destination of every slice's observations of that camera
+//                  = cam_ptr[c] + sum of the earlier slices' counts (in place)
+//   k_cam_scatter  every wave walks its slice in order, 64 observations at a time; a lane's destination = the running
+//                  offset of its camera (LDS) + the number of LOWER lanes with the same camera, found without a sort:
+//                  one ballot per key bit gives every lane the mask of its equals (ceil(log2 C) ballots per batch)
+// Same order as the host's stable sort, entry for entry (a test compares the tables), so every per-camera sum keeps
+// its summation order.  Cameras held still (`fixed`, may be null) contribute no entries.
+constexpr int kSortSlices = 512;
+__global__ __launch_bounds__(64) void k_cam_hist(const int* __restrict__ cam_idx, const unsigned char* __restrict__ fixed,
+                                                 int N, int C, int per, int* __restrict__ hist) {
+    extern __shared__ int cnt[];
+    for (int c = threadIdx.x; c < C; c += 64) cnt[c] = 0;
+    __syncthreads();
+    const int b0 = blockIdx.x * per, b1 = min(N, b0 + per);
+    for (int k = b0 + (int)threadIdx.x; k < b1; k += 64) {
+        const int c = cam_idx[k];
+        if (fixed == nullptr || fixed[c] == 0) atomicAdd(&cnt[c], 1);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 64) hist[(size_t)blockIdx.x * C + c] = cnt[c];
+}
+__global__ __launch_bounds__(256) void k_cam_offsets(int* __restrict__ hist, const int* __restrict__ cam_ptr, int B, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    int run = cam_ptr[c];
+#pragma unroll 8
+    for (int b = 0; b < B; ++b) {
+        const int n = hist[(size_t)b * C + c];
+        hist[(size_t)b * C + c] = run;
+        run += n;
+    }
+}
+__global__ __launch_bounds__(64) void k_cam_scatter(const int* __restrict__ cam_idx, const unsigned char* __restrict__ fixed,
+                                                    const int* __restrict__ pt_idx, const double* __restrict__ uv, int f32,
+                                                    int N, int C, int per, int key_bits, const int* __restrict__ off,
+                                                    int* __restrict__ cm_pt, double* __restrict__ cm_uv) {
+    extern __shared__ int cur[];
+    for (int c = threadIdx.x; c < C; c += 64) cur[c] = off[(size_t)blockIdx.x * C + c];
+    __syncthreads();
+    const int lane = threadIdx.x;
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    const int b0 = blockIdx.x * per, b1 = min(N, b0 + per);
+    for (int k0 = b0; k0 < b1; k0 += 64) {
+        const int k = k0 + lane;
+        int c = -1;
+        if (k < b1) { c = cam_idx[k]; if (fixed != nullptr && fixed[c] != 0) c = -1; }
+        const bool act = c >= 0;
+        unsigned long long eq = __ballot(act);                 // lanes with the same camera as this one
+        for (int bit = 0; bit < key_bits; ++bit) {
+            const unsigned long long m = __ballot(act && ((c >> bit) & 1));
+            eq &= ((c >> bit) & 1) ? m : ~m;
+        }
+        if (act) {
+            const int dst = cur[c] + __popcll(eq & lt);
+            cm_pt[dst] = pt_idx[k];
+            if (f32) reinterpret_cast<float2*>(cm_uv)[dst] = reinterpret_cast<const float2*>(uv)[k];
+            else reinterpret_cast<double2*>(cm_uv)[dst] = reinterpret_cast<const double2*>(uv)[k];
+            if ((eq >> lane) == 1ull) cur[c] += __popcll(eq);   // the highest lane of the group advances the offset
+        }
+        __syncthreads();                                       // (one wave: orders the LDS update before the next batch)
+    }
+}
+// The XCD-aware chunk table of pass B (k_cam_schur_w) from the camera-major point indices: row (8 g + k) 4 + j = the
+// piece of camera 4 g + j inside point range k (its list is ascending in the point index: two binary searches).
+__global__ __launch_bounds__(256) void k_xcd_chunks(const int* __restrict__ cam_ptr, const int* __restrict__ cm_pt, int C, int P,
+                                                    int4* __restrict__ chunks) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int groups = (C + 3) / 4;
+    if (e >= groups * 32) return;
+    const int j = e & 3, k = (e >> 2) & 7, g = e >> 5;
+    const int c = 4 * g + j;
+    if (c >= C) { chunks[e] = make_int4(-1, 0, 0, 8); return; }
+    const int b = cam_ptr[c], en = cam_ptr[c + 1];
+    auto bound = [&](int kk) {                                  // first entry of the list whose point lies in range >= kk
+        if (kk <= 0) return b;
+        if (kk >= 8) return en;
+        const int p_hi = (int)(((long long)P * kk) / 8);
+        int lo = b, hi = en;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (cm_pt[mid] < p_hi) lo = mid + 1; else hi = mid; }
+        return lo;
+    };
+    chunks[e] = make_int4(c, bound(k), bound(k + 1), 8);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Point-major sweep skeleton.  Each WAVE owns an observation range cut at point boundaries
 // (host-built) and walks it in precomputed steps: steps[s] = (first observation, count); count <= 64 is a

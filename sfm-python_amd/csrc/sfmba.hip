@@ -250,6 +250,7 @@ struct sfmba_handle {
         int xcd_chunks = -1;                 // 1 / 0: camera lists cut at the eight point-range boundaries (one chunk per XCD) whatever the size
         int rhsrec = -1;                     // 1 / 0: the rhs + preconditioner pass gathers its own 128-byte records whatever the size
         int cost_rider = -1;                 // 0: the trial cost is summed and posted by a k_finish launch of its own
+        int cm_device = -1;                  // 0: the camera-major order is sorted on the host and its permutation uploaded
         int pcg_inline = -1;                 // 0: sharded solves keep the collective of the product as a launch of its own
         int pcg_mixed_b = -1;                // 0: pass B keeps fp64 point records although pass A runs on fp32 operands
         int pcg_mixed = -1;                  // 1 / 0: fp32 operands in the implicit Schur product whatever the storage mode
@@ -269,6 +270,8 @@ struct sfmba_handle {
     int n_steps = 0;
     // camera-major order of the same observations (structure only): per-camera sums without atomics
     DevBuf cm_perm, cm_pt, cm_uv, cam_partial;
+    DevBuf sort_hist, fixed_dev;             // device-side camera-major sort: [kSortSlices][C] counts -> offsets; held cameras
+    DevView cam_ptr_dev;                     // [C + 1]
     DevView cam_chunks, cam_chunk_ptr;
     int n_chunks = 0;
     // a second chunk table for pass B of the Schur product alone (many points): every camera's list cut at the eight
@@ -1435,6 +1438,7 @@ int sfmba_debug_option(sfmba_handle* h, const char* name, int64_t value) {
     else if (n == "pcg_split") h->dbg.pcg_split = v;
     else if (n == "pcg_mixed") h->dbg.pcg_mixed = v;
     else if (n == "pcg_inline") h->dbg.pcg_inline = v;
+    else if (n == "cm_device") h->dbg.cm_device = v;
     else if (n == "pcg_mixed_b") h->dbg.pcg_mixed_b = v;
     else if (n == "cost_rider") h->dbg.cost_rider = v;
     else if (n == "rhsrec") h->dbg.rhsrec = v;
@@ -1823,19 +1827,23 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     }
     // ---- pass 2 (parallel): run offsets of the points, camera-major permutation ---------------------------------
     // ptr[p] = first position whose point index is >= p (pi is non-decreasing): every run start k writes the
-    // entries (pi[k-1], pi[k]], so the parts touch disjoint pieces of ptr
+    // entries (pi[k-1], pi[k]], so the parts touch disjoint pieces of ptr.
+    // The camera-major order itself is sorted on the DEVICE (k_cam_hist / k_cam_offsets / k_cam_scatter: the same stable
+    // order) unless the camera counters do not fit the LDS; the host then only needs the run offsets.
+    const bool cm_device = h->dbg.cm_device != 0 && sizeof(int) * (size_t)C <= kLdsDynMax;
     h->pool.run(parts, [&](int t) {
         const int64_t b = std::min<int64_t>(N, t * per), e = std::min<int64_t>(N, (t + 1) * per);
         int* off = hist.data() + (size_t)t * (size_t)C;
         for (int64_t k = b; k < e; ++k) {
             const int lo = k == 0 ? -1 : pi[k - 1];
             for (int q = lo + 1; q <= pi[k]; ++q) ptr[q] = (int)k;
-            if (!fixed[(size_t)ci[k]]) perm[off[ci[k]]++] = (int)k;
+            if (!cm_device && !fixed[(size_t)ci[k]]) perm[off[ci[k]]++] = (int)k;
         }
     });
     for (int64_t q = (int64_t)pi[N - 1] + 1; q <= P; ++q) ptr[q] = (int)N;
     ts1 = now_s();
-    for (size_t k = (size_t)cam_ptr[C]; k < ldz; ++k) perm[k] = 0;      // (shorter than N when cameras are held still)
+    if (!cm_device)
+        for (size_t k = (size_t)cam_ptr[C]; k < ldz; ++k) perm[k] = 0;  // (shorter than N when cameras are held still)
 
     for (int k = 0; k < 9; ++k) h->K.k[k] = K[k];
     h->f32 = f32;
@@ -1950,7 +1958,7 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
             static_assert(kX == 8, "one range per XCD");
             const int64_t groups = (C + kG - 1) / kG;
             chunks_b.assign((size_t)(groups * kX * kG), make_int4(-1, 0, 0, kX));
-            for (int64_t c = 0; c < C; ++c) {
+            for (int64_t c = 0; c < C && !cm_device; ++c) {            // (device-side sort: k_xcd_chunks fills the table)
                 const int b = cam_ptr[c], e = cam_ptr[c + 1];
                 int prev = b;
                 for (int k = 0; k < kX; ++k) {
@@ -2034,7 +2042,8 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     HIPCHK(h, h->pt_ptr.ensure_keep(sizeof(int) * ((size_t)P + 1), sizeof(int) * (size_t)p_keep));
     // the structure tables: one device buffer, one pinned staging buffer, one copy
     struct Piece { const void* src; size_t bytes; DevView* view; size_t off; };
-    Piece pieces[10] = {
+    Piece pieces[11] = {
+        {cam_ptr.data(), sizeof(int) * cam_ptr.size(), &h->cam_ptr_dev, 0},
         {ranges.data(), sizeof(int2) * ranges.size(), &h->ranges, 0}, {wsteps.data(), sizeof(int2) * wsteps.size(), &h->wsteps, 0},
         {steps.data(), sizeof(int2) * steps.size(), &h->steps, 0}, {chunks.data(), sizeof(int4) * chunks.size(), &h->cam_chunks, 0},
         {chunk_ptr.data(), sizeof(int) * chunk_ptr.size(), &h->cam_chunk_ptr, 0},
@@ -2137,11 +2146,44 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
         hipLaunchKernelGGL(k_zero_many, dim3((unsigned)grid_1d(most, 256 * 4, 2048), 7), dim3(256), 0, h->stream, z);
         LAUNCHED(h);
     }
-    HIPCHK(h, hipMemcpyAsync(h->cm_perm.p, perm, sizeof(int) * ldz, hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_build_cam_major, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, h->stream, h->cm_perm.as<int>(),
-                       h->pt_idx.as<int>(), h->uv.as<double>(), f32 ? 1 : 0, (int)N, h->cm_pt.as<int>(),
-                       h->cm_uv.as<double>());
-    LAUNCHED(h);
+    if (cm_device) {
+        const int B = (int)std::min<int64_t>(kSortSlices, (N + 63) / 64);
+        const int per_slice = (int)(((N + B - 1) / B + 63) / 64 * 64);
+        int key_bits = 0;
+        while (((int64_t)1 << key_bits) < C) ++key_bits;
+        HIPCHK(h, h->sort_hist.ensure(sizeof(int) * (size_t)B * (size_t)C));
+        const unsigned char* fixed_dev = nullptr;
+        if (h->n_fixed > 0) {
+            HIPCHK(h, h->fixed_dev.ensure((size_t)C));
+            HIPCHK(h, hipMemcpyAsync(h->fixed_dev.p, fixed.data(), (size_t)C, hipMemcpyHostToDevice, h->stream));
+            fixed_dev = h->fixed_dev.as<unsigned char>();
+        }
+        const size_t lds = sizeof(int) * (size_t)C;
+        CHK(set_lds(h, k_cam_hist, lds));
+        CHK(set_lds(h, k_cam_scatter, lds));
+        hipLaunchKernelGGL(k_cam_hist, dim3(B), dim3(64), lds, h->stream, (const int*)h->cam_idx.as<int>(), fixed_dev, (int)N, (int)C,
+                           per_slice, h->sort_hist.as<int>());
+        LAUNCHED(h);
+        hipLaunchKernelGGL(k_cam_offsets, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, h->stream, h->sort_hist.as<int>(),
+                           (const int*)h->cam_ptr_dev.as<int>(), B, (int)C);
+        LAUNCHED(h);
+        hipLaunchKernelGGL(k_cam_scatter, dim3(B), dim3(64), lds, h->stream, (const int*)h->cam_idx.as<int>(), fixed_dev,
+                           (const int*)h->pt_idx.as<int>(), (const double*)h->uv.as<double>(), f32 ? 1 : 0, (int)N, (int)C, per_slice,
+                           key_bits, (const int*)h->sort_hist.as<int>(), h->cm_pt.as<int>(), h->cm_uv.as<double>());
+        LAUNCHED(h);
+        if (h->xcd_b) {
+            hipLaunchKernelGGL(k_xcd_chunks, dim3((unsigned)((h->n_chunks_b + 255) / 256)), dim3(256), 0, h->stream,
+                               (const int*)h->cam_ptr_dev.as<int>(), (const int*)h->cm_pt.as<int>(), (int)C, (int)P,
+                               h->cam_chunks_b.as<int4>());
+            LAUNCHED(h);
+        }
+    } else {
+        HIPCHK(h, hipMemcpyAsync(h->cm_perm.p, perm, sizeof(int) * ldz, hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_build_cam_major, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, h->stream, h->cm_perm.as<int>(),
+                           h->pt_idx.as<int>(), h->uv.as<double>(), f32 ? 1 : 0, (int)N, h->cm_pt.as<int>(),
+                           h->cm_uv.as<double>());
+        LAUNCHED(h);
+    }
     tp3 = now_s();
     HIPCHK(h, hipStreamSynchronize(h->stream));     // the host tables are rebuilt by the next call
     if (timing)

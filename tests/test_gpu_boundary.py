@@ -392,3 +392,41 @@ def test_in_out_and_separate_array_forms_of_the_solve_agree():
         assert be._lib.sfmba_solve_from(be._h, _capi.ptr(x0), None, C.byref(opt), C.byref(null)) == -1      # x_out is NULL
     finally:
         be.close()
+
+
+def test_camera_major_order_sorted_on_the_device_equals_the_hosts():
+    """set_problem builds the camera-major order with a stable counting sort ON THE DEVICE (k_cam_hist / k_cam_offsets /
+    k_cam_scatter; the reference hands a new problem to every call, sfm.py:59-71) instead of sorting on the host and
+    uploading the permutation (debug option cm_device = 0).  Same order entry for entry, so every per-camera sum keeps
+    its summation order: normal blocks, the Schur product and whole solves are equal to the BIT -- with duplicated
+    (camera, point) pairs, cameras nobody observes, cameras held still, fp32 storage, the XCD-aware chunk table of
+    pass B (built by k_xcd_chunks from the device-side order) and more observations than one slice batch."""
+    import sfmba
+    cases = [(sfmba.make_problem(7, 60, 400, seed=3), (), 64, -1), (sfmba.make_problem(300, 4000, 30000, seed=3), (), 64, -1),
+             (sfmba.drop_observations(sfmba.make_problem(40, 400, 5000, seed=3), cameras=(5, 39)), (0, 17), 64, 1),
+             (sfmba.make_problem(1300, 4000, 70000, seed=21), (), 32, 1), (sfmba.make_problem(3, 8, 20, seed=0), (1,), 64, -1)]
+    for pb, fixed, bits, xcd in cases:
+        outs = []
+        for dev in (0, 1):
+            be = sfmba.Backend(0)
+            try:
+                be.debug_option("cm_device", dev)
+                be.debug_option("xcd_chunks", xcd)
+                be.debug_option("dense", 0)
+                be.set_precision(bits)
+                be.set_fixed_cameras(fixed)
+                be.set_problem(*pb.args)
+                U, V, gc, gp = be.normal_blocks(pb.x0)
+                C, P = pb.n_cameras, pb.n_points
+                rng = np.random.default_rng(2)
+                y = be.schur_matvec(pb.x0, np.full(6 * C, 10.0), np.full(3 * P, 10.0), rng.normal(size=6 * C))
+                opt = be.default_options()
+                opt.ftol = 1e-10
+                x, res, fun, grad = be.solve(pb.x0, opt)
+                outs.append((U, gc, y, x, fun, grad, res.cost, res.nfev, res.pcg_iterations))
+            finally:
+                be.close()
+        a, b = outs
+        for u, v in zip(a[:6], b[:6]):
+            assert np.array_equal(u, v)
+        assert a[6:] == b[6:]
