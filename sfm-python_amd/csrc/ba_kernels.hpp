@@ -507,7 +507,9 @@ struct PointBlocksOut {
     double* __restrict__ edge;                   // [tiles][2][kEdgeRow]
 };
 
-template <bool LDS_TAB, bool JAC, bool STORE_R, bool F32, bool BLOCKS = false>
+// STORE_J = false (the J-free iteration, debug option jfree): the blocks are formed for the point sums only and not
+// written -- every consumer recomputes them (k_jdot / k_backsub<.., JFREE>).
+template <bool LDS_TAB, bool JAC, bool STORE_R, bool F32, bool BLOCKS = false, bool STORE_J = true>
 __global__ __launch_bounds__(kSweepThreads) void k_resjac(
     const double* __restrict__ camtab, const double* __restrict__ pts, const int* __restrict__ cam_idx,
     const int* __restrict__ pt_idx, const double* __restrict__ uv, double* __restrict__ r,
@@ -578,7 +580,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_resjac(
             if (STORE_R) {
                 if (F32) store_pair(r, 1, i, rx, ry); else st16(r + 2 * (size_t)i, rx, ry);
             }
-            if (JAC) {
+            if (JAC && STORE_J) {
                 // compact form: d r/d w (jc[0..2], jc[6..8]) and d r/d X (jp); d r/d T = -jp is not stored
                 if (F32) {
                     float4* __restrict__ Jf = reinterpret_cast<float4*>(J);
@@ -1173,11 +1175,39 @@ __global__ void k_finish(const double* __restrict__ part, FinishJob job, int nq,
 
 // t1_i = J (D^2 g) per observation and sum |t1|^2 (the quadratic of the 1-D Cauchy problem,
 // SCIPY trf.py:471-475 / common.py:251-299).  Camera slice of D^2 g staged in LDS.
-template <bool LDS_VEC>
+// The J-FREE iteration (debug option jfree, an A/B measurement: DESIGN.md): the consumers of the stored Jacobian, k_jdot
+// and k_backsub, recompute an observation's blocks from the camera table (staged in LDS, where the camera vector
+// otherwise sits; the vector is then read from L2) and its point, as K1 itself forms them -- same function, same bits in
+// fp64 storage -- and K1 no longer writes them (STORE_J = false): 96 of its 136 bytes per observation.
+struct Recompute {
+    const double* __restrict__ camtab;   // [C][kCamRow]
+    const double* __restrict__ pts;      // [P][3]
+    KMat K;
+};
+__device__ __forceinline__ void stage_cam_table(const double* __restrict__ camtab, int C, double* __restrict__ smem) {
+    const int n2 = (C * kCamRow) >> 1;
+    const double2* __restrict__ src = reinterpret_cast<const double2*>(camtab);
+    double2* __restrict__ dst = reinterpret_cast<double2*>(smem);
+    for (int k = threadIdx.x; k < n2; k += blockDim.x) dst[k] = src[k];
+    __syncthreads();
+}
+__device__ __forceinline__ void recompute_blocks(const Recompute& rc, const double* __restrict__ tab_lds, int c, int p,
+                                                 double* jc, double* jp) {
+    double tl[kCamRow];
+    const double2* __restrict__ trow = reinterpret_cast<const double2*>(tab_lds + (size_t)c * kCamRow);
+#pragma unroll
+    for (int k = 0; k < kCamRow / 2; ++k) { const double2 q = trow[k]; tl[2 * k] = q.x; tl[2 * k + 1] = q.y; }
+    const double* __restrict__ Xp = rc.pts + 3 * (size_t)p;
+    double rx, ry;
+    observe<true>(tl, Xp[0], Xp[1], Xp[2], 0.0, 0.0, rc.K, rx, ry, jc, jp);
+}
+
+template <bool LDS_VEC, bool JFREE = false>
 __global__ __launch_bounds__(kSweepThreads) void k_jdot(ObsArrays o, const double* __restrict__ sgc,
                                                         const double* __restrict__ sgp, int N, int C,
                                                         double* __restrict__ t1,
-                                                        double* __restrict__ part, Piggyback pb) {
+                                                        double* __restrict__ part, Piggyback pb, Recompute rc) {
+    static_assert(!(LDS_VEC && JFREE), "J-free: the LDS holds the camera table, the vector comes from L2");
     extern __shared__ __align__(16) double smem[];
     __shared__ double red[kWavesPerSweepBlock];
     const int nwork = pb.part != nullptr ? (int)gridDim.x - 1 : (int)gridDim.x;
@@ -1186,11 +1216,13 @@ __global__ __launch_bounds__(kSweepThreads) void k_jdot(ObsArrays o, const doubl
         for (int i = threadIdx.x; i < 6 * C; i += blockDim.x) smem[i] = sgc[i];
         __syncthreads();
     }
+    if (JFREE) stage_cam_table(rc.camtab, C, smem);
     const double* __restrict__ vc = LDS_VEC ? smem : sgc;
     double acc = 0.0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += nwork * blockDim.x) {
         double jc[12], jp[6];
-        load_blocks(o, i, jc, jp);
+        if (JFREE) recompute_blocks(rc, smem, o.cam_idx[i], o.pt_idx[i], jc, jp);
+        else load_blocks(o, i, jc, jp);
         const double2* a2 = reinterpret_cast<const double2*>(vc + 6 * o.cam_idx[i]);    // 16-byte aligned rows
         const double2 a01 = a2[0], a23 = a2[1], a45 = a2[2];
         const double a[6] = {a01.x, a01.y, a23.x, a23.y, a45.x, a45.y};
@@ -3320,13 +3352,14 @@ __global__ __launch_bounds__(1024) void k_pcg_update(const double* __restrict__ 
 // q5 = g.p, q6 = |p s|^2, q7 = (D^2 g).p, q8 = |p|^2 -- the point part where each dp is produced (run heads),
 // the camera part spread over the workgroups.  part[block] = (G12, G22, q5..q8 points, q5..q8 cameras), kBacksubCols wide.
 constexpr int kBacksubCols = 10;
-template <bool LDS_VEC>
+template <bool LDS_VEC, bool JFREE = false>
 __global__ __launch_bounds__(kSweepThreads) void k_backsub(
     const int2* __restrict__ ranges, int n_ranges, ObsArrays o, const double* __restrict__ dc_planes,
     double* __restrict__ dc, const double* __restrict__ Vinv, const double* __restrict__ gp,
     const double* __restrict__ t1, double* __restrict__ dp, double* __restrict__ part, int C,
     const PcgCtrl* __restrict__ ctrl2, int L, const double* __restrict__ gvec,
-    const double* __restrict__ si, const double* __restrict__ sg) {
+    const double* __restrict__ si, const double* __restrict__ sg, Recompute rc) {
+    static_assert(!(LDS_VEC && JFREE), "J-free: the LDS holds the camera table, the step vector comes from L2");
     extern __shared__ __align__(16) double smem[];
     __shared__ double red[kBacksubCols * kWavesPerSweepBlock];
     if (ctrl2 != nullptr)                      // dc_planes = base of the PCG vector sets: take x of the final set
@@ -3342,11 +3375,16 @@ __global__ __launch_bounds__(kSweepThreads) void k_backsub(
         }
         __syncthreads();
     }
+    if (JFREE) stage_cam_table(rc.camtab, C, smem);
     const double* __restrict__ vv = LDS_VEC ? smem : dc;
     const int wg = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     int pos = 0, end = 0;
     if (wg < n_ranges) { const int2 rg = ranges[wg]; pos = rg.x; end = rg.y; }
+    auto blocks_of = [&](int j, int pj, double* jc_, double* jp_) {       // the blocks of observation j (of point pj)
+        if (JFREE) recompute_blocks(rc, smem, o.cam_idx[j], pj, jc_, jp_);
+        else load_blocks(o, j, jc_, jp_);
+    };
     double g12 = 0.0, g22 = 0.0;
     double qs[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};       // q5..q8: [0..3] points, [4..7] cameras
     auto dots = [&](double* q, size_t e, double pe) {              // element e of the parameter vector, step pe
@@ -3403,7 +3441,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_backsub(
             const int pp = __shfl(p, 0);
             double y[3] = {0.0, 0.0, 0.0};
             for (int j = pos + lane; j < run_end; j += 64) {
-                load_blocks(o, j, jc, jp);
+                blocks_of(j, pp, jc, jp);
                 double t0, t1v;
                 jcv(jc, o.cam_idx[j], t0, t1v);
                 y[0] += jp[0] * t0 + jp[3] * t1v; y[1] += jp[1] * t0 + jp[4] * t1v;
@@ -3414,7 +3452,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_backsub(
             solve_point(pp, y, z0, z1, z2);              // every lane writes the same values
             if (lane == 0) point_dots(pp, si + 6 * (size_t)C + 3 * (size_t)pp, z0, z1, z2);
             for (int j = pos + lane; j < run_end; j += 64) {
-                load_blocks(o, j, jc, jp);
+                blocks_of(j, pp, jc, jp);
                 double t0, t1v;
                 jcv(jc, o.cam_idx[j], t0, t1v);
                 gram(j, jp, t0, t1v, z0, z1, z2);
@@ -3427,7 +3465,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_backsub(
         double y[3] = {0.0, 0.0, 0.0};
         double s3[3] = {1.0, 1.0, 1.0};        // scale entries of the lane's point, requested with the blocks so
         if (act) {                             // that the run head does not wait for them after the reduction
-            load_blocks(o, i, jc, jp);
+            blocks_of(i, p, jc, jp);
 #pragma unroll
             for (int k = 0; k < 3; ++k) s3[k] = si[6 * (size_t)C + 3 * (size_t)p + k];
             jcv(jc, o.cam_idx[i], t0, t1v);

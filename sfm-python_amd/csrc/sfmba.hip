@@ -230,6 +230,7 @@ struct sfmba_handle {
     bool sweep_rc_g = false;                 // ... from a table in global memory (more cameras than the LDS holds)
     DevBuf rctab;                            // [C][18], k_rc_table
     // mixed-precision Schur product (ba_kernels.hpp: MixedPrep): fp32 operands, fp64 arithmetic
+    bool jfree = false;                      // J-free iteration (debug option jfree; needs the camera table in LDS)
     bool mixed = false;                      // pass A
     bool mixed_b = false;                    // ... and pass B (fp32 point records)
     DevBuf rt32, rec32, rctab32, rtd;        // [C][12], [P][8], [C][20] floats; [C][12] doubles
@@ -250,6 +251,8 @@ struct sfmba_handle {
         int xcd_chunks = -1;                 // 1 / 0: camera lists cut at the eight point-range boundaries (one chunk per XCD) whatever the size
         int rhsrec = -1;                     // 1 / 0: the rhs + preconditioner pass gathers its own 128-byte records whatever the size
         int cost_rider = -1;                 // 0: the trial cost is summed and posted by a k_finish launch of its own
+        int jfree = -1;                      // 1: the J-free iteration (measurement): K1 does not write the Jacobian, k_jdot and
+                                             // k_backsub recompute its blocks from the LDS camera table
         int cm_device = -1;                  // 0: the camera-major order is sorted on the host and its permutation uploaded
         int pcg_inline = -1;                 // 0: sharded solves keep the collective of the product as a launch of its own
         int pcg_mixed_b = -1;                // 0: pass B keeps fp64 point records although pass A runs on fp32 operands
@@ -627,6 +630,9 @@ int launch_resjac_b(sfmba_handle* h, const double* x, const double* tab, int gri
     const double* pts = x + 6 * h->C;
     const PointBlocksOut pb = BLOCKS ? point_blocks_out(h) : PointBlocksOut{nullptr, nullptr, nullptr};
     auto kern = k_resjac<LDS, JAC, STORE_R, F32, BLOCKS>;
+    if constexpr (JAC && BLOCKS && LDS && STORE_R) {           // J-free iteration: the blocks feed the point sums only
+        if (h->jfree) kern = k_resjac<LDS, JAC, STORE_R, F32, BLOCKS, false>;
+    }
     CHK(set_lds(h, kern, lds));
     if (ev0) {
         hipExtLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), (uint32_t)lds, h->stream, ev0, ev1, 0u, tab, pts,
@@ -994,15 +1000,22 @@ int launch_jdot(sfmba_handle* h, int* nparts) {
     Piggyback pb{};
     if (h->pending_scale_sums) pb = slices_rider(h, 0, 4);
     const int launch_grid = grid + (pb.part != nullptr ? 1 : 0);
-    if (h->lds_vec) {
+    const Recompute rc{h->tab, h->x + 6 * h->C, h->K};
+    if (h->jfree) {
+        const size_t lds = sizeof(double) * kCamRow * (size_t)h->C;
+        auto kern = k_jdot<false, true>;
+        CHK(set_lds(h, kern, lds));
+        hipLaunchKernelGGL(kern, dim3(launch_grid), dim3(kSweepThreads), lds, h->stream, obs_arrays(h), sgc, sgp,
+                           (int)h->N, (int)h->C, h->t1.as<double>(), h->partB(), pb, rc);
+    } else if (h->lds_vec) {
         const size_t lds = sizeof(double) * 6 * h->C;
         auto kern = k_jdot<true>;
         CHK(set_lds(h, kern, lds));
         hipLaunchKernelGGL(kern, dim3(launch_grid), dim3(kSweepThreads), lds, h->stream, obs_arrays(h), sgc, sgp,
-                           (int)h->N, (int)h->C, h->t1.as<double>(), h->partB(), pb);
+                           (int)h->N, (int)h->C, h->t1.as<double>(), h->partB(), pb, rc);
     } else {
         hipLaunchKernelGGL(k_jdot<false>, dim3(launch_grid), dim3(kSweepThreads), 0, h->stream, obs_arrays(h),
-                           sgc, sgp, (int)h->N, (int)h->C, h->t1.as<double>(), h->partB(), pb);
+                           sgc, sgp, (int)h->N, (int)h->C, h->t1.as<double>(), h->partB(), pb, rc);
     }
     LAUNCHED(h);
     h->pending_scale_sums = false;
@@ -1015,22 +1028,34 @@ int launch_backsub(sfmba_handle* h, int* nparts) {
     double* dc = h->p.as<double>();
     double* dp = dc + 6 * h->C;
     const PcgCtrl* ctrl2 = h->ctrl.as<PcgCtrl>();
-    if (h->lds_vec) {
+    const Recompute rc{h->tab, h->x + 6 * h->C, h->K};
+    if (h->jfree) {
+        hipLaunchKernelGGL(k_transpose, dim3((6 * h->C + 255) / 256), dim3(256), 0, h->stream,
+                           (const double*)h->vecs.as<double>(), 6, (int)h->C, dc, ctrl2, h->pcg_L);
+        LAUNCHED(h);
+        const size_t lds = sizeof(double) * kCamRow * (size_t)h->C;
+        auto kern = k_backsub<false, true>;
+        CHK(set_lds(h, kern, lds));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), lds, h->stream, h->ranges.as<int2>(), h->n_ranges, obs_arrays(h),
+                           h->vecs.as<double>(), dc, vinv_ptr(h), h->gp.as<double>(), h->t1.as<double>(), dp, h->partB(),
+                           (int)h->C, (const PcgCtrl*)nullptr, 0, h->g.as<double>(), h->si.as<double>(), h->sg.as<double>(), rc);
+    } else if (h->lds_vec) {
         const size_t lds = sizeof(double) * 6 * h->C;
         auto kern = k_backsub<true>;
         CHK(set_lds(h, kern, lds));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), lds, h->stream, h->ranges.as<int2>(),
                            h->n_ranges, obs_arrays(h), h->vecs.as<double>(), dc, vinv_ptr(h),
                            h->gp.as<double>(), h->t1.as<double>(), dp, h->partB(), (int)h->C,
-                           ctrl2, h->pcg_L, h->g.as<double>(), h->si.as<double>(), h->sg.as<double>());
+                           ctrl2, h->pcg_L, h->g.as<double>(), h->si.as<double>(), h->sg.as<double>(), rc);
     } else {
         hipLaunchKernelGGL(k_transpose, dim3((6 * h->C + 255) / 256), dim3(256), 0, h->stream,
                            (const double*)h->vecs.as<double>(), 6, (int)h->C, dc, ctrl2, h->pcg_L);
+        LAUNCHED(h);
         hipLaunchKernelGGL(k_backsub<false>, dim3(grid), dim3(kSweepThreads), 0, h->stream,
                            h->ranges.as<int2>(), h->n_ranges, obs_arrays(h), h->vecs.as<double>(), dc,
                            vinv_ptr(h), h->gp.as<double>(), h->t1.as<double>(), dp,
                            h->partB(), (int)h->C, (const PcgCtrl*)nullptr, 0, h->g.as<double>(),
-                           h->si.as<double>(), h->sg.as<double>());
+                           h->si.as<double>(), h->sg.as<double>(), rc);
     }
     LAUNCHED(h);
     *nparts = grid;
@@ -1439,6 +1464,7 @@ int sfmba_debug_option(sfmba_handle* h, const char* name, int64_t value) {
     else if (n == "pcg_mixed") h->dbg.pcg_mixed = v;
     else if (n == "pcg_inline") h->dbg.pcg_inline = v;
     else if (n == "cm_device") h->dbg.cm_device = v;
+    else if (n == "jfree") h->dbg.jfree = v;
     else if (n == "pcg_mixed_b") h->dbg.pcg_mixed_b = v;
     else if (n == "cost_rider") h->dbg.cost_rider = v;
     else if (n == "rhsrec") h->dbg.rhsrec = v;
@@ -2029,6 +2055,7 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     // fp32 operands in the implicit Schur product: with fp32 storage (BASELINE config 5 names it), or on request
     h->mixed = (h->sweep_rc || h->sweep_rc_g) && (h->dbg.pcg_mixed == 1 || (h->dbg.pcg_mixed != 0 && f32));
     h->mixed_b = h->mixed && h->dbg.pcg_mixed_b != 0;
+    h->jfree = h->dbg.jfree == 1 && h->lds_tab;
 
     // ---- device arrays: grow-only; the index / pixel arrays keep their re-used prefix when they grow -------------
     const size_t esz = f32 ? sizeof(float) : sizeof(double);     // element size of the per-observation streams
@@ -2216,7 +2243,7 @@ int sfmba_residual_jacobian(sfmba_handle* h, const double* x, double* r_out, dou
     CHK(upload_x(h, x));
     CHK(launch_cam_table(h, h->x, h->tab, h->rec));
     int np = 0;
-    CHK((launch_resjac<true, true>(h, h->x, h->tab, &np, nullptr, nullptr, /*blocks=*/false)));
+    CHK((launch_resjac<true, true>(h, h->x, h->tab, &np, nullptr, nullptr, /*blocks=*/false)));   // (blocks = false: always stored)
     DevBuf jc_rm, jp_rm;
     HIPCHK(h, jc_rm.ensure(sizeof(double) * 12 * h->N));
     HIPCHK(h, jp_rm.ensure(sizeof(double) * 6 * h->N));

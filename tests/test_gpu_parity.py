@@ -221,7 +221,7 @@ def dbg():
             touched.append((b, name))
     yield set_
     defaults = dict(pcg_fused=-1, tab_lds=-1, vec_lds=-1, cam_chunk=0, pcg_guess_bias=0, sweep_rc=-1, dense=-1, precond=-1, pcg_local=-1,
-                    pcg_split=-1, rhsrec=-1, cost_rider=-1, xcd_chunks=-1, pcg_mixed=-1, pcg_mixed_b=-1)
+                    pcg_split=-1, rhsrec=-1, cost_rider=-1, xcd_chunks=-1, pcg_mixed=-1, pcg_mixed_b=-1, jfree=-1)
     for b, name in touched:
         b.debug_option(name, defaults[name])
 
@@ -301,6 +301,36 @@ def test_mixed_precision_schur_product(be, orc, dbg):
             assert np.abs(res.x - exact.x).max() <= 1e-6 * np.abs(exact.x).max(), tag
         for name in ("pcg_mixed", "pcg_mixed_b", "xcd_chunks", "pcg_fused"):
             dbg((be, tls), name, -1)
+
+
+def test_j_free_iteration_equals_the_stored_jacobian_iteration(dbg):
+    """Debug option jfree = 1 (a measurement mode): K1 forms the blocks for the point sums but does
+    not write them, and the two consumers of the stored Jacobian -- k_jdot (J D^2 g) and k_backsub (back-substitution,
+    J p, Gram sums) -- recompute every observation's blocks from the LDS camera table and its point, by the function K1
+    itself uses.  With fp64 storage that is the same arithmetic on the same inputs: the whole solve is equal to the BIT;
+    with fp32 storage the recomputed blocks are the exact ones instead of their fp32 roundings: same iterations, cost to
+    1e-9."""
+    import sfmba
+    tls = sfmba.get_backend(0)
+    dbg((tls,), "dense", 0)
+    for pb in (sfmba.make_problem(300, 4000, 30000, seed=3), sfmba.make_config("cfg2"),
+               sfmba.make_problem(6, 80, 500, seed=5, x0_noise=0.2), sfmba.make_problem(900, 3000, 40000, seed=8)):
+        for bits in (64, 32):
+            runs = []
+            for jf in (-1, 1):
+                dbg((tls,), "jfree", jf)
+                runs.append(sfmba.least_squares(sfmba.compute_residuals, pb.x0, x_scale="jac", ftol=1e-10, method="trf",
+                                                args=pb.args, storage_bits=bits))
+                runs[-1].fun                                   # (download before the next solve reuses the buffers)
+            a, b = runs
+            assert (a.status, a.nfev, a.njev, a.pcg_iterations) == (b.status, b.nfev, b.njev, b.pcg_iterations)
+            if bits == 64:
+                assert a.cost == b.cost and np.array_equal(a.x, b.x) and np.array_equal(a.fun, b.fun)
+            else:
+                # (x: the fp32 roundings of the stored blocks move the iterates along the weakly determined directions)
+                assert abs(a.cost - b.cost) <= 1e-9 * a.cost and np.abs(a.fun - b.fun).max() <= 1e-3
+                assert np.abs(a.x - b.x).max() <= 1e-3 * np.abs(a.x).max()
+    dbg((tls,), "jfree", -1)
 
 
 def test_results_are_bitwise_reproducible(be):
