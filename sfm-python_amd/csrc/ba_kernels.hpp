@@ -959,6 +959,31 @@ __global__ void k_build_cam_major(const int* __restrict__ perm, const int* __res
     else reinterpret_cast<double2*>(cm_uv)[k] = reinterpret_cast<const double2*>(uv)[i];
 }
 
+// The observation arrays cross PCIe PACKED when they can (every call of the reference is a new problem, sfm.py:59-71, and at
+// a million observations the 24 MB of int32 indices and fp64 pixels were the longest single item of a call): camera
+// indices as uint16 (fewer than 65536 cameras), pixels as int16 pairs (the reference's pixels are integers, graph.py:112-113;
+// checked value by value on the host), and no point indices at all -- they follow from the run offsets.  6 bytes per
+// observation instead of 24; expanded here into the arrays the kernels read.
+__global__ __launch_bounds__(256) void k_unpack_obs(const unsigned short* __restrict__ ci16, const short2* __restrict__ uv16,
+                                                    int from, int to, int f32, int* __restrict__ cam_idx, double* __restrict__ uv) {
+    const int k = from + blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= to) return;
+    cam_idx[k] = (int)ci16[k];
+    const short2 q = uv16[k];
+    if (f32) reinterpret_cast<float2*>(uv)[k] = make_float2((float)q.x, (float)q.y);
+    else reinterpret_cast<double2*>(uv)[k] = make_double2((double)q.x, (double)q.y);
+}
+// pt_idx[k] = p for k in [pt_ptr[p], pt_ptr[p + 1]); the padding behind the last observation is 0 (one wave per 64 points)
+__global__ __launch_bounds__(256) void k_expand_pt_idx(const int* __restrict__ pt_ptr, int P, int N, int ld, int* __restrict__ pt_idx) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < P) {
+        const int b = pt_ptr[p], e = pt_ptr[p + 1];
+        for (int k = b; k < e; ++k) pt_idx[k] = p;
+    } else if (p == P) {
+        for (int k = N; k < ld; ++k) pt_idx[k] = 0;
+    }
+}
+
 // The camera-major order built ON THE DEVICE (the reference hands a new problem to every call, sfm.py:59-71, and the
 // host's counting sort + the upload of its permutation were 0.4-0.5 ms of a 3.6 ms call at a million observations): a
 // stable counting sort of the point-major positions by camera in three launches.  The observations are cut into

@@ -251,6 +251,7 @@ struct sfmba_handle {
         int xcd_chunks = -1;                 // 1 / 0: camera lists cut at the eight point-range boundaries (one chunk per XCD) whatever the size
         int rhsrec = -1;                     // 1 / 0: the rhs + preconditioner pass gathers its own 128-byte records whatever the size
         int cost_rider = -1;                 // 0: the trial cost is summed and posted by a k_finish launch of its own
+        int packed_upload = -1;              // 0: the observation arrays are uploaded as int32 / fp64 although they would pack
         int jfree = -1;                      // 1: the J-free iteration (measurement): K1 does not write the Jacobian, k_jdot and
                                              // k_backsub recompute its blocks from the LDS camera table
         int cm_device = -1;                  // 0: the camera-major order is sorted on the host and its permutation uploaded
@@ -319,8 +320,9 @@ struct sfmba_handle {
     double* h_scal = nullptr;                // pinned
     // set_problem: converted arrays of the current problem in pinned memory (upload source, and what the next
     // call is compared with), host copies of the structure tables, worker threads
-    struct Stage { PinnedBuf uv, ci, pi, perm, ptr, uvf, tables; } stage;
-    struct Prev { bool valid = false; bool f32 = false; int64_t N = 0, P = 0; } prev;
+    struct Stage { PinnedBuf uv, ci, pi, perm, ptr, uvf, tables, ci16, uv16; } stage;
+    DevBuf ci16_dev, uv16_dev;               // packed upload of the observation arrays (k_unpack_obs)
+    struct Prev { bool valid = false; bool f32 = false; bool packed = false; int64_t N = 0, P = 0; } prev;
     std::vector<int2> host_ranges, host_wsteps, host_steps;
     std::vector<int4> host_chunks;
     std::vector<int> host_chunk_ptr;
@@ -360,6 +362,8 @@ struct sfmba_handle {
                                           // call (sfm.py:59-71), and the counts repeat; with a record the speculative
                                           // batch is that count (+1 launch for the fused update), without the spare
     int64_t hist_C = 0, hist_P = 0, hist_N = 0;   // the problem pcg_hist was recorded on
+    unsigned long long hist_sig = 0;         // ... and its content: problem generation + a checksum of the start vector
+    unsigned long long problem_gen = 0;      // raised by every sfmba_set_problem whose arrays differ from the previous ones
     bool use_rhsrec = false;                 // the rhs + preconditioner pass gathers its own 128-byte records (many points)
     bool solved = false;
     bool transport_dropped = false;          // sfmba_set_problem tore down an active transport: the next compute call
@@ -1465,6 +1469,7 @@ int sfmba_debug_option(sfmba_handle* h, const char* name, int64_t value) {
     else if (n == "pcg_inline") h->dbg.pcg_inline = v;
     else if (n == "cm_device") h->dbg.cm_device = v;
     else if (n == "jfree") h->dbg.jfree = v;
+    else if (n == "packed_upload") h->dbg.packed_upload = v;
     else if (n == "pcg_mixed_b") h->dbg.pcg_mixed_b = v;
     else if (n == "cost_rider") h->dbg.cost_rider = v;
     else if (n == "rhsrec") h->dbg.rhsrec = v;
@@ -1772,6 +1777,15 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     HIPCHK(h, sg.perm.ensure(sizeof(int) * ldz, 0));
     HIPCHK(h, sg.ptr.ensure(sizeof(int) * ((size_t)P + 1), 0));
     if (f32) HIPCHK(h, sg.uvf.ensure(sizeof(float) * 2 * ldz, sizeof(float) * 2 * keep_obs));
+    const bool try_pack = h->dbg.packed_upload != 0 && C <= 65535;
+    const bool packed_prefix_ok = try_pack && prev.packed && n_cmp > 0;      // the staged prefix holds valid packed entries
+    if (try_pack) {
+        HIPCHK(h, sg.ci16.ensure(sizeof(unsigned short) * ldz, sizeof(unsigned short) * keep_obs));
+        HIPCHK(h, sg.uv16.ensure(sizeof(short) * 2 * ldz, sizeof(short) * 2 * keep_obs));
+    }
+    unsigned short* ci16 = try_pack ? sg.ci16.as<unsigned short>() : nullptr;
+    short* uv16 = try_pack ? sg.uv16.as<short>() : nullptr;
+    std::vector<char> not16((size_t)h->pool.parts_for(N), 0);       // a pixel that is no int16 integer: no packing
     double* uvs = sg.uv.as<double>();
     float* uvf = f32 ? sg.uvf.as<float>() : nullptr;
     int* ci = sg.ci.as<int>();
@@ -1800,8 +1814,14 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
                 if (uv) { u0 = uv[2 * s]; u1 = uv[2 * s + 1]; }
                 else { u0 = (double)uv_i64[2 * s]; u1 = (double)uv_i64[2 * s + 1]; }          // as numpy promotes
                 if (!fixed[(size_t)cv]) ++hc[cv];
-                if (k < n_compare && ci[k] == (int)cv && pi[k] == (int)pv && uvs[2 * k] == u0 && uvs[2 * k + 1] == u1)
-                    continue;
+                const bool same = k < n_compare && ci[k] == (int)cv && pi[k] == (int)pv && uvs[2 * k] == u0 && uvs[2 * k + 1] == u1;
+                if (ci16 && !(same && packed_prefix_ok)) {     // (an unchanged entry is packed already, if the previous call packed)
+                    const bool in = std::fabs(u0) < 32768.0 && std::fabs(u1) < 32768.0;
+                    const short q0 = in ? (short)u0 : (short)0, q1 = in ? (short)u1 : (short)0;
+                    if (!in || (double)q0 != u0 || (double)q1 != u1) not16[t] = 1;
+                    ci16[k] = (unsigned short)cv; uv16[2 * k] = q0; uv16[2 * k + 1] = q1;
+                }
+                if (same) continue;
                 if (fd == N) fd = k;
                 ci[k] = (int)cv; pi[k] = (int)pv; uvs[2 * k] = u0; uvs[2 * k + 1] = u1;
                 if (uvf) { uvf[2 * k] = (float)u0; uvf[2 * k + 1] = (float)u1; }    // integer pixels up to 2^24 are exact
@@ -1837,7 +1857,10 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     for (size_t k = (size_t)N; k < ldz; ++k) {                       // padding up to the next multiple of 256
         ci[k] = 0; pi[k] = 0; uvs[2 * k] = 0.0; uvs[2 * k + 1] = 0.0;
         if (uvf) { uvf[2 * k] = 0.f; uvf[2 * k + 1] = 0.f; }
+        if (ci16) { ci16[k] = 0; uv16[2 * k] = 0; uv16[2 * k + 1] = 0; }
     }
+    bool packed = try_pack;
+    for (char f : not16) packed = packed && !f;
     tp1 = now_s();
 
     // ---- camera-major order: stable counting sort of the positions by camera (per-part histograms, so that the
@@ -2150,12 +2173,31 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
         return hipMemcpyAsync(static_cast<char*>(dst) + elem * from, static_cast<const char*>(src) + elem * from,
                               elem * (to - from), hipMemcpyHostToDevice, h->stream);
     };
-    HIPCHK(h, up(h->cam_idx.p, ci, sizeof(int), keep, ldz));
-    HIPCHK(h, up(h->pt_idx.p, pi, sizeof(int), keep, ldz));
-    HIPCHK(h, up(h->uv.p, f32 ? (const void*)uvf : (const void*)uvs, 2 * esz, keep, ldz));
+    if (packed) {
+        HIPCHK(h, h->ci16_dev.ensure(sizeof(unsigned short) * ldz));
+        HIPCHK(h, h->uv16_dev.ensure(sizeof(short) * 2 * ldz));
+        HIPCHK(h, up(h->ci16_dev.p, ci16, sizeof(unsigned short), keep, ldz));
+        HIPCHK(h, up(h->uv16_dev.p, uv16, 2 * sizeof(short), keep, ldz));
+    } else {
+        HIPCHK(h, up(h->cam_idx.p, ci, sizeof(int), keep, ldz));
+        HIPCHK(h, up(h->pt_idx.p, pi, sizeof(int), keep, ldz));
+        HIPCHK(h, up(h->uv.p, f32 ? (const void*)uvf : (const void*)uvs, 2 * esz, keep, ldz));
+    }
     HIPCHK(h, up(h->pt_ptr.p, ptr, sizeof(int), (size_t)p_keep, (size_t)P + 1));
+    if (packed) {
+        if (keep < ldz) {
+            hipLaunchKernelGGL(k_unpack_obs, dim3((unsigned)((ldz - keep + 255) / 256)), dim3(256), 0, h->stream,
+                               (const unsigned short*)h->ci16_dev.as<unsigned short>(), (const short2*)h->uv16_dev.as<short2>(),
+                               (int)keep, (int)ldz, f32 ? 1 : 0, h->cam_idx.as<int>(), h->uv.as<double>());
+            LAUNCHED(h);
+            hipLaunchKernelGGL(k_expand_pt_idx, dim3((unsigned)((P + 1 + 255) / 256)), dim3(256), 0, h->stream,
+                               (const int*)h->pt_ptr.as<int>(), (int)P, (int)N, (int)ld, h->pt_idx.as<int>());
+            LAUNCHED(h);
+        }
+    }
     h->obs_reused = fdiff;
     h->obs_uploaded = ld - fdiff;
+    if (!(fdiff == N && n_cmp == N && prev.N == N && prev.P == P && h->C == C)) ++h->problem_gen;
     HIPCHK(h, hipMemcpyAsync(h->tables.p, sg.tables.p, tables_bytes, hipMemcpyHostToDevice, h->stream));
     {   // every zero-initialised array in ONE launch: the exchange arena; V, g_p (points without observations are never
         // written by the normal-block kernels: their blocks must be 0) and p (... and their step is 0); r; the point records
@@ -2221,6 +2263,7 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
                         "  (%lld of %lld observations re-used)\n",
                 1e3 * (tp1 - tp0), 1e3 * (tp2 - tp1), 1e3 * (tp3 - tp2), 1e3 * (now_s() - tp3), (long long)fdiff, (long long)N);
     if (sorted) { prev.valid = true; prev.f32 = f32; prev.N = N; prev.P = P; }
+    prev.packed = sorted && packed;
     h->have_problem = true;
     return 0;
 }
@@ -2549,7 +2592,18 @@ static int solve_impl(sfmba_handle* h, const double* x_start, double* x_inout, c
     // The record is trusted count for count only on the problem it was recorded on; on a neighbouring problem (the
     // reference's growing reconstruction: a camera or a few hundred observations more) it is a guess with a spare
     // launch; on an unrelated problem it is dropped together with the running hint.
-    const bool hist_same = h->hist_C == C && h->hist_P == P && h->hist_N == h->N;
+    // (content, not only sizes: the problem arrays' generation and a checksum of the start vector -- a different start on
+    // the same problem, or another problem of the same sizes, is a "neighbouring" one and gets the spare launch)
+    unsigned long long sig = h->problem_gen * 0x9E3779B97F4A7C15ull;
+    {
+        const int64_t stride = std::max<int64_t>(1, n / 509);
+        for (int64_t k = 0; k < n; k += stride) {
+            unsigned long long bits;
+            memcpy(&bits, x_start + k, sizeof bits);
+            sig = (sig ^ bits) * 0x100000001B3ull;
+        }
+    }
+    const bool hist_same = h->hist_C == C && h->hist_P == P && h->hist_N == h->N && h->hist_sig == sig;
     const bool hist_near = hist_same || (h->hist_N > 0 && std::llabs(h->hist_C - C) <= 1 && 2 * h->N >= h->hist_N && h->N <= 2 * h->hist_N);
     if (!hist_near) { h->pcg_hist.clear(); h->pcg_hint = 0; pcg_guess = 0; }
     if (!h->pcg_hist.empty() && h->pcg_hist[0] > 0) { pcg_guess = h->pcg_hist[0]; guess_exact = hist_same; }
@@ -2867,7 +2921,7 @@ static int solve_impl(sfmba_handle* h, const double* x_start, double* x_inout, c
         out->resjac_launches = (int64_t)evs.size();
     }
     h->pcg_hist.swap(pcg_hist_new);
-    h->hist_C = C; h->hist_P = P; h->hist_N = h->N;
+    h->hist_C = C; h->hist_P = P; h->hist_N = h->N; h->hist_sig = sig;
     out->cost = cost;
     out->optimality = g_norm;
     out->rmse = std::sqrt(2.0 * cost / m_total);

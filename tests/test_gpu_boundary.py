@@ -430,3 +430,47 @@ def test_camera_major_order_sorted_on_the_device_equals_the_hosts():
         for u, v in zip(a[:6], b[:6]):
             assert np.array_equal(u, v)
         assert a[6:] == b[6:]
+
+
+def test_packed_upload_of_the_observation_arrays_changes_nothing():
+    """set_problem sends the observation arrays over PCIe packed when they allow it -- camera indices as uint16, integer
+    pixels as int16 pairs, no point indices (they follow from the run offsets): 6 bytes per observation instead of 24 --
+    and expands them on the device (k_unpack_obs, k_expand_pt_idx).  Same residuals, blocks and solves to the BIT as the
+    plain upload (debug option packed_upload = 0); pixels that are no int16 integers (float pixels, a pixel of 40000) take
+    the plain path by themselves; growing problems keep their prefix in either form."""
+    import sfmba
+    base = sfmba.make_problem(40, 400, 5000, seed=3)
+    tiny = sfmba.make_problem(3, 8, 20, seed=0)
+    far = base.points_2d.copy()
+    far[17, 0] = 40000
+    cases = [(base.args, 64, base.x0), (base.args, 32, base.x0),
+             (base.args[:4] + (base.points_2d.astype(np.float64) + 0.25, base.K), 64, base.x0),
+             (base.args[:4] + (far, base.K), 64, base.x0), (tiny.args, 64, tiny.x0)]
+    for args, bits, x0 in cases:
+        outs = []
+        for packed in (0, -1):
+            be = sfmba.Backend(0)
+            try:
+                be.debug_option("packed_upload", packed)
+                be.debug_option("dense", 0)
+                be.set_precision(bits)
+                # a shorter problem first: the second call re-uses its prefix on the device
+                n_head = int(np.searchsorted(args[3], args[1] // 2, side="left"))
+                be.set_problem(args[0], args[1], args[2][:n_head], args[3][:n_head], args[4][:n_head], args[5])
+                be.set_problem(*args)
+                assert be.problem_reuse()[0] >= n_head
+                r = be.residuals(x0)
+                U, V, gc, gp = be.normal_blocks(x0)
+                opt = be.default_options()
+                opt.ftol = 1e-10
+                x, res, fun, grad = be.solve(x0, opt)
+                be.set_problem(*args)                                 # once more, unchanged: nothing uploaded
+                x2, res2, _, _ = be.solve(x0, opt)
+                assert np.array_equal(x, x2)
+                outs.append((r, U, V, x, fun, res.cost, res.nfev))
+            finally:
+                be.close()
+        a, b = outs
+        for u, v in zip(a[:5], b[:5]):
+            assert np.array_equal(u, v)
+        assert a[5:] == b[5:]
