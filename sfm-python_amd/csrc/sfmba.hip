@@ -2220,7 +2220,8 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
         const int per_slice = (int)(((N + B - 1) / B + 63) / 64 * 64);
         int key_bits = 0;
         while (((int64_t)1 << key_bits) < C) ++key_bits;
-        HIPCHK(h, h->sort_hist.ensure(sizeof(int) * (size_t)B * (size_t)C));
+        HIPCHK(h, h->sort_hist.ensure(sizeof(int) * 2 * (size_t)B * (size_t)C));          // counts | offsets
+        int* sort_off = h->sort_hist.as<int>() + (size_t)B * (size_t)C;
         const unsigned char* fixed_dev = nullptr;
         if (h->n_fixed > 0) {
             HIPCHK(h, h->fixed_dev.ensure((size_t)C));
@@ -2233,12 +2234,12 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
         hipLaunchKernelGGL(k_cam_hist, dim3(B), dim3(64), lds, h->stream, (const int*)h->cam_idx.as<int>(), fixed_dev, (int)N, (int)C,
                            per_slice, h->sort_hist.as<int>());
         LAUNCHED(h);
-        hipLaunchKernelGGL(k_cam_offsets, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, h->stream, h->sort_hist.as<int>(),
-                           (const int*)h->cam_ptr_dev.as<int>(), B, (int)C);
+        hipLaunchKernelGGL(k_cam_offsets, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, h->stream, (const int*)h->sort_hist.as<int>(),
+                           (const int*)h->cam_ptr_dev.as<int>(), B, (int)C, sort_off);
         LAUNCHED(h);
         hipLaunchKernelGGL(k_cam_scatter, dim3(B), dim3(64), lds, h->stream, (const int*)h->cam_idx.as<int>(), fixed_dev,
                            (const int*)h->pt_idx.as<int>(), (const double*)h->uv.as<double>(), f32 ? 1 : 0, (int)N, (int)C, per_slice,
-                           key_bits, (const int*)h->sort_hist.as<int>(), h->cm_pt.as<int>(), h->cm_uv.as<double>());
+                           key_bits, (const int*)sort_off, h->cm_pt.as<int>(), h->cm_uv.as<double>());
         LAUNCHED(h);
         if (h->xcd_b) {
             hipLaunchKernelGGL(k_xcd_chunks, dim3((unsigned)((h->n_chunks_b + 255) / 256)), dim3(256), 0, h->stream,

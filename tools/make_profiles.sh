@@ -1,12 +1,12 @@
 #!/bin/bash
-# Regenerates the rocprofv3 evidence under profiles/ on the GPU box:  bash tools/make_profiles.sh r03   (through gpurun)
+# Regenerates the rocprofv3 evidence under profiles/ on the GPU box:  bash tools/make_profiles.sh r04   (through gpurun)
 # Writes gpurun_out/<tag>_*: the default bench line, the same command under --kernel-trace --stats, the two PMC passes
 # (FETCH_SIZE, WRITE_SIZE -> <tag>_traffic.json), cfg2 under the tracer, the cfg3 / cfg5 bench lines, cfg5 (fp32 storage)
 # under the tracer, SQ / TA counters of the residual+Jacobian kernel at cfg4 and cfg5, the per-rank critical path of an
 # 8-way sharding (tools/shard_profiles.sh), back-to-back kernel timings, solve loops and the grid-barrier probe.  Raw CSV
 # directories are deleted at the end; the summaries are copied to profiles/ by hand afterwards.
 set -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
@@ -39,6 +39,26 @@ python3 tools/time_kernels.py cfg5 0,7,1,2,4,5,8 32 >> $OUT/${TAG}_time_kernels.
 for c in cfg4 cfg2 cfg3 1000,12500,125000; do python3 tools/solve_loop.py $c; done > $OUT/${TAG}_solve_loop.txt 2>&1
 python3 tools/solve_loop.py cfg5 6 32 >> $OUT/${TAG}_solve_loop.txt 2>&1
 python3 tools/solve_loop.py cfg5 6 64 >> $OUT/${TAG}_solve_loop.txt 2>&1
-timeout -k 10 120 ./tools/scratch/grid_barrier_probe > $OUT/${TAG}_barrier_probe.txt 2>&1
+# round 4: the mixed-precision product (kernel times, accuracy, solves; counters of pass A / pass B at cfg5 in both forms),
+# the sharded path with and without the per-camera exchange inside the producers, the J-free iteration, the N > 1 bench
+# path on one device, per-call overhead, the randomised parity run
+python3 tools/ab_mixed.py cfg5 32 > $OUT/${TAG}_ab_mixed.txt 2>&1
+python3 tools/ab_mixed.py cfg4 64 >> $OUT/${TAG}_ab_mixed.txt 2>&1
+cd /tmp
+for M in 1 0; do
+  SFMBA_DEBUG=pcg_mixed=$M rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_VALU --output-format csv -d $OUT/${TAG}_abc_a_$M -- python3 $R/tools/time_kernels.py cfg5 4,5 32 > /dev/null 2>> $OUT/${TAG}_k1c.err
+  SFMBA_DEBUG=pcg_mixed=$M rocprofv3 --pmc TA_BUSY_avr GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_WR --output-format csv -d $OUT/${TAG}_abc_b_$M -- python3 $R/tools/time_kernels.py cfg5 4,5 32 > /dev/null 2>> $OUT/${TAG}_k1c.err
+  python3 $R/tools/profile_summary.py counters $OUT/${TAG}_cfg5_passAB_counters_mixed$M.json "passes A and B of the Schur product back to back, cfg5 fp32 storage, pcg_mixed=$M" $OUT/${TAG}_abc_a_$M $OUT/${TAG}_abc_b_$M > /dev/null
+  rm -rf $OUT/${TAG}_abc_a_$M $OUT/${TAG}_abc_b_$M
+done
+cd $R
+bash tools/ab_shard.sh $TAG pcg_inline > $OUT/${TAG}_ab_shard_inline.txt 2>&1
+bash tools/ab_option.sh cfg4 64 jfree 20 > $OUT/${TAG}_ab_jfree.txt 2>&1
+bash tools/ab_trace.sh ${TAG}j cfg4 64 jfree 12 >> $OUT/${TAG}_ab_jfree.txt 2>&1
+timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29544 bench.py --gpus 2 --one-device --dist-backend gloo --exchange torch --steps 20 --warmup 5 --no-cpu-baseline 2> $OUT/${TAG}_bench_2rank_one_device.err | tail -1 > $OUT/${TAG}_bench_2rank_one_device.json
+python3 tools/call_overhead.py > $OUT/${TAG}_call_overhead.txt 2>&1
+python3 tools/call_overhead.py cfg2 >> $OUT/${TAG}_call_overhead.txt 2>&1
+python3 tools/fuzz_parity.py 300 0 > $OUT/${TAG}_fuzz.txt 2>&1
+python3 tools/fuzz_parity.py 300 7 >> $OUT/${TAG}_fuzz.txt 2>&1
 rm -rf $OUT/${TAG}_stats $OUT/${TAG}_stats_cfg2 $OUT/${TAG}_stats_cfg5 $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write $OUT/${TAG}_k1c_a_cfg4 $OUT/${TAG}_k1c_b_cfg4 $OUT/${TAG}_k1c_a_cfg5 $OUT/${TAG}_k1c_b_cfg5
-cat $OUT/${TAG}_time_kernels.txt $OUT/${TAG}_solve_loop.txt; tail -8 $OUT/${TAG}_shard.log
+cat $OUT/${TAG}_time_kernels.txt $OUT/${TAG}_solve_loop.txt $OUT/${TAG}_ab_mixed.txt $OUT/${TAG}_ab_shard_inline.txt; tail -8 $OUT/${TAG}_shard.log

@@ -7,7 +7,7 @@
 # buffer; every collective of an 8-GPU run is launched, only the xGMI hops are missing), the latter also under
 # rocprofv3 --kernel-trace --stats.
 set -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
