@@ -54,7 +54,8 @@ def pmc(dfetch, dwrite, out, workload):
         f_avg, w_avg = sum(f) / len(f) * 1024, sum(w) / len(w) * 1024
         res[k[:100]] = dict(launches=max(len(f), len(w)), launches_incl_cancelled=n_all, fetch_bytes_raw=f_avg, write_bytes=w_avg,
                             hbm_bytes_raw=f_avg + w_avg, hbm_bytes_corrected=2 * f_avg + w_avg)
-    k1 = [k for k in res if "k_resjac<true, true, true, false, true>" in k] or \
+    k1 = [k for k in res if "k_resjac<true, true, true, false, true, true>" in k] or \
+         [k for k in res if "k_resjac<true, true, true, false, true>" in k] or \
          [k for k in res if "k_resjac<true, true, true, false>" in k or "k_resjac<true, true, true>" in k]   # (older builds)
     summary = dict(workload=workload, note="per-launch averages; FETCH_SIZE x2 correction per MI355X_MICROARCH.md",
                    kernels=res)
