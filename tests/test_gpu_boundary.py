@@ -407,7 +407,7 @@ def test_camera_major_order_sorted_on_the_device_equals_the_hosts():
              (sfmba.make_problem(1300, 4000, 70000, seed=21), (), 32, 1), (sfmba.make_problem(3, 8, 20, seed=0), (1,), 64, -1)]
     for pb, fixed, bits, xcd in cases:
         outs = []
-        for dev in (0, 1):
+        for dev in (0, 1):                                        # (1: forced; the default takes the device path from 64k observations)
             be = sfmba.Backend(0)
             try:
                 be.debug_option("cm_device", dev)
@@ -448,7 +448,7 @@ def test_packed_upload_of_the_observation_arrays_changes_nothing():
              (base.args[:4] + (far, base.K), 64, base.x0), (tiny.args, 64, tiny.x0)]
     for args, bits, x0 in cases:
         outs = []
-        for packed in (0, -1):
+        for packed in (0, 1):                                     # (1: forced; by default problems under 64k observations upload plain)
             be = sfmba.Backend(0)
             try:
                 be.debug_option("packed_upload", packed)
