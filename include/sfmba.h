@@ -233,7 +233,8 @@ int  sfmba_tr2d_solve(const double* B3, const double* g2, double Delta, double* 
  *   "dense"          P  0: implicit Schur product + launched PCG although the reduced camera matrix would be formed
  *                       and solved inside one workgroup (6 n_cameras <= 128)
  *   "sweep_rc"       P  0: pass A of the Schur product reads the stored Jacobian instead of recomputing the blocks from
- *                       the camera table
+ *                       the camera table; 2: recomputes them from a table in GLOBAL memory (the form of > 1100 cameras)
+ *                       whatever the camera count
  *   "tab_lds", "vec_lds" P  0: camera table / camera vector read from L2 although they would fit the LDS
  *   "pcg_fused"      P  0: the PCG update as a kernel of its own instead of the prologue of pass A
  *   "pcg_local"         0: the fused PCG keeps its whole update in pass A's prologue (no per-camera tail in pass B)
@@ -246,7 +247,15 @@ int  sfmba_tr2d_solve(const double* B3, const double* g2, double Delta, double* 
  *   "rhsrec"         P  1 / 0: the rhs + preconditioner pass gathers dedicated 128-byte point records whatever the size
  *   "cost_rider"        0: the trial cost is summed and posted by a k_finish launch of its own instead of riding with
  *                       the normal-block launch
- *   "pcg_mixed"      P  1 / 0: fp32 operands with fp64 accumulation in the implicit Schur product (sfmba_set_precision)
+ *   "pcg_mixed"      P  1 / 0: fp32 operands with fp64 accumulation in the implicit Schur product (default: with fp32
+ *                       storage, sfmba_set_precision); "pcg_mixed_b" 0: pass B keeps its fp64 point records
+ *   "pcg_inline"        0: sharded solves over the direct link keep the all-reduces of the per-camera sums as launches
+ *                       of their own (default: exchanged by the producing workgroups; ranks that SHARE one device --
+ *                       rehearsals -- need 0 once their camera workgroups together exceed the device's resident slots)
+ *   "cm_device"      P  1 / 0: camera-major order sorted on the device / on the host (default: device from 64k
+ *                       observations on); "packed_upload" P 1 / 0: observation arrays uploaded packed (same default)
+ *   "jfree"          P  1: the J-free iteration (measurement): K1 does not write the Jacobian, k_jdot / k_backsub
+ *                       recompute its blocks (needs the camera table in LDS)
  *   "pcg_guess_bias"    added to the number of speculatively enqueued PCG iterations (negative: force misses)
  *   "wait_deadline_s"   a hand-off not posted within this many seconds fails the solve with -3 (default 120)
  *   "p2p_delay_ms"      sleep before the first collective of a solve (late-peer test)

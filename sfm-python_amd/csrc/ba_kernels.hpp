@@ -749,7 +749,7 @@ __device__ __forceinline__ void post_mailbox(const Mailbox& mb) {     // one ful
     constexpr int nc = (int)((sizeof(PcgCtrl) + 7) / 8);
     if (mb.ctrl != nullptr && lane >= kMboxCtrl && lane < kMboxCtrl + nc)
         mb.host[lane] = reinterpret_cast<const double*>(mb.ctrl)[lane - kMboxCtrl];
-    if (lane == kMboxErr) mb.host[lane] = (mb.err != nullptr && *mb.err != 0u) ? 1.0 : 0.0;
+    if (lane == kMboxErr) mb.host[lane] = mb.err != nullptr ? (double)*mb.err : 0.0;          // (the code: p2p_timeout_text)
     __threadfence_system();                       // every lane's element is out before lane 0 raises the number
     if (lane == 0)
         __hip_atomic_store(reinterpret_cast<unsigned long long*>(mb.host + kMboxSeq), mb.seq, __ATOMIC_RELAXED,
@@ -826,7 +826,9 @@ struct CamExchange {
 
 // lane k (< nv) of a camera's workgroup: `out` = its local sum -> the sum over the ranks, in rank order.  base = first
 // double of the slot set inside the region; slot (q, k, c) at base + (q nv + k) C + c.
-__device__ __forceinline__ double cam_exchange_value(const CamExchange& cx, size_t base, int nv, int k, int C, int c, double out) {
+// `kind` (2 pass B, 3 K3, 4 right-hand side) goes into the error word with k and c: 1 << 31 | kind << 28 | k << 23 | c.
+__device__ __forceinline__ double cam_exchange_value(const CamExchange& cx, size_t base, int nv, int k, int C, int c, double out,
+                                                     unsigned kind) {
     if (*cx.error != 0u) return out;                         // an earlier exchange of this solve gave up: do not wait again
     const size_t mine = base + ((size_t)cx.rank * nv + k) * C + c;
     for (int q = 0; q < cx.world; ++q)
@@ -839,7 +841,10 @@ __device__ __forceinline__ double cam_exchange_value(const CamExchange& cx, size
             unsigned long long* slot = reinterpret_cast<unsigned long long*>(cx.data[cx.rank] + base + ((size_t)q * nv + k) * C + c);
             unsigned long long bits;
             while ((bits = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) == kCamSlotEmpty) {
-                if (wall_clock64() - t0 > cx.timeout) { atomicExch(cx.error, 1u); break; }
+                if (wall_clock64() - t0 > cx.timeout) {
+                    atomicCAS(cx.error, 0u, 0x80000000u | kind << 28 | (unsigned)k << 23 | ((unsigned)c & 0x7FFFFFu));
+                    break;
+                }
                 __builtin_amdgcn_s_sleep(1);
             }
             __hip_atomic_store(slot, kCamSlotEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);     // consumed
@@ -923,7 +928,7 @@ __global__ __launch_bounds__(kCamThreads) void k_cam_blocks(CamMajor cm, const d
     }
     double s = cam_block_total<27>(a, red);
     if (threadIdx.x < 27) {
-        if (cx.world > 1) s = cam_exchange_value(cx, cam_slots_k3(cx.world, cx.C), 27, threadIdx.x, cx.C, ch.x, s);
+        if (cx.world > 1) s = cam_exchange_value(cx, cam_slots_k3(cx.world, cx.C), 27, threadIdx.x, cx.C, ch.x, s, 3u);
         if (ch.w == 1) Ugc[(size_t)ch.x * 27 + threadIdx.x] = s;
         else partial[(size_t)bid * 27 + threadIdx.x] = s;
     }
@@ -2645,7 +2650,7 @@ __global__ __launch_bounds__(kCamThreads) void k_cam_schur(CamMajor cm, const do
         }
     }
     if (MODE == 0 && cx.world > 1 && threadIdx.x < 6)        // (every camera is a single chunk in this form)
-        out = cam_exchange_value(cx, cam_slots_pcg(cx.world, C, l_it & 1), 6, threadIdx.x, C, ch.x, out);
+        out = cam_exchange_value(cx, cam_slots_pcg(cx.world, C, l_it & 1), 6, threadIdx.x, C, ch.x, out, 2u);
     if (threadIdx.x < 6) {
         if (ch.w == 1) acc[(size_t)threadIdx.x * C + ch.x] = out;
         else partial[(size_t)blockIdx.x * 6 + threadIdx.x] = out;
@@ -2905,7 +2910,7 @@ __global__ __launch_bounds__(kRhsThreads) void k_cam_rhs_diag(CamMajor cm, const
     }
     double s = cam_block_total<27, kRhsThreads / 64>(a, red);
     if (threadIdx.x < 27) {
-        if (cx.world > 1) s = cam_exchange_value(cx, cam_slots_rhs(cx.world, C), 27, threadIdx.x, C, ch.x, s);
+        if (cx.world > 1) s = cam_exchange_value(cx, cam_slots_rhs(cx.world, C), 27, threadIdx.x, C, ch.x, s, 4u);
         if (ch.w == 1) out[(size_t)threadIdx.x * C + ch.x] = s;
         else partial[(size_t)blockIdx.x * 27 + threadIdx.x] = s;
     }
@@ -3647,7 +3652,7 @@ __device__ __forceinline__ void p2p_allreduce_body(double* __restrict__ vec, int
         const unsigned long long* f = a.flags[a.rank] + ((size_t)par * a.world + tid) * kP2pFlagStride;
         const long long t0 = wall_clock64();
         while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
-            if (wall_clock64() - t0 > a.timeout) { atomicExch(a.error, 1u); break; }
+            if (wall_clock64() - t0 > a.timeout) { atomicCAS(a.error, 0u, 1u); break; }
             __builtin_amdgcn_s_sleep(1);
         }
     }
@@ -3779,7 +3784,7 @@ __global__ __launch_bounds__(kP2pPcgThreads) void k_p2p_pcg(double* __restrict__
             const unsigned long long* f = a.flags[a.rank] + ((size_t)par * a.world + tid) * kP2pFlagStride;
             const long long t0 = wall_clock64();
             while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
-                if (wall_clock64() - t0 > a.timeout) { atomicExch(a.error, 1u); break; }
+                if (wall_clock64() - t0 > a.timeout) { atomicCAS(a.error, 0u, 1u); break; }
                 __builtin_amdgcn_s_sleep(1);
             }
         }

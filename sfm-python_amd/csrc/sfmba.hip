@@ -316,6 +316,9 @@ struct sfmba_handle {
         unsigned* words = nullptr;           // [0] ticket, [1] error, [2..3] uint64 count of performed collectives
         int64_t calls = 0;
         bool first_in_solve = true;          // the next collective is the rendezvous of a solve (long timeout)
+        // agreed over the link itself at attach (every rank holds the same two values):
+        int shared_device = 1;               // ranks whose handle sits on the same physical GPU as this one's (rehearsals)
+        bool any_multi = false;              // some rank's shard has a camera of several chunks / the XCD-aware chunk table
     } p2p;
     double* h_scal = nullptr;                // pinned
     // set_problem: converted arrays of the current problem in pinned memory (upload source, and what the next
@@ -436,6 +439,7 @@ void p2p_close_peers(sfmba_handle* h);
 bool multi_rank(const sfmba_handle* h) { return h->p2p.ready || h->comm != nullptr || h->ar_fn != nullptr; }
 const unsigned* p2p_error_word(const sfmba_handle* h) { return h->p2p.ready ? h->p2p.words + 1 : nullptr; }
 
+constexpr long long kP2pFirstTicks = 6000000000ll, kP2pSteadyTicks = 3000000000ll;      // 60 s, 30 s at 100 MHz
 constexpr size_t kP2pFlagBytes = sizeof(unsigned long long) * 2 * kP2pMaxRanks * kP2pFlagStride;
 
 void p2p_fill_args(sfmba_handle* h, P2pArgs& a) {
@@ -444,24 +448,34 @@ void p2p_fill_args(sfmba_handle* h, P2pArgs& a) {
     a.rank = p.rank; a.world = p.world; a.stride = p.stride;
     a.seq = reinterpret_cast<unsigned long long*>(p.words + 2);
     a.ticket = p.words; a.error = p.words + 1;
-    // Ticks of the 100 MHz wall clock.  Steady state: 3 s.  The FIRST collective of a solve is the rendezvous of
-    // ranks that entered sfmba_solve at different times (Python skew, first-use code-object loads; no barrier is
-    // required before a solve): it waits up to 60 s.
-    a.timeout = p.first_in_solve ? 6000000000ll : 300000000ll;
+    // Ticks of the 100 MHz wall clock.  The FIRST collective of a solve is the rendezvous of ranks that entered
+    // sfmba_solve at different times (Python skew, first-use code-object loads; no barrier is required before a solve):
+    // it waits up to 60 s.  Steady state: 30 s -- the devices run in lockstep there, but a host thread that stalls between
+    // two launches (a cold page of a runtime library on a fresh machine, a descheduled process) holds its peers up for as
+    // long; the bound only decides how soon a dead peer is noticed (round 4: 3 s gave one spurious failure in a first solve
+    // on a fresh box).
+    a.timeout = p.first_in_solve ? kP2pFirstTicks : kP2pSteadyTicks;
     if (h->dbg.p2p_timeout_ms > 0) a.timeout = 100000ll * h->dbg.p2p_timeout_ms;       // test hook
     p.first_in_solve = false;
 }
 
 // sharded over the direct link, every camera a single chunk: per-camera sums are all-reduced by the workgroup that
 // forms them (CamExchange) instead of by a collective launch behind the kernel
-bool cam_inline(const sfmba_handle* h) { return h->p2p.ready && !h->cam_multi && h->dbg.pcg_inline != 0; }
+// -- on EVERY rank (the chunking is a property of the shard; ranks that disagreed would wait for each other in different
+// kernels), and not when ranks that share one GPU would fill it with waiting workgroups (p2p_inline_ok).
+constexpr int64_t kSharedDeviceCams = 1024;        // 256 CUs x 4 resident pass-B workgroups
+bool p2p_inline_ok(const sfmba_handle* h) {
+    const auto& p = h->p2p;
+    return p.ready && !p.any_multi && !(p.shared_device > 1 && h->C * p.shared_device > kSharedDeviceCams);
+}
+bool cam_inline(const sfmba_handle* h) { return p2p_inline_ok(h) && !h->cam_multi && h->dbg.pcg_inline != 0; }
 
 CamExchange cam_exchange(sfmba_handle* h) {
     CamExchange cx{};
     auto& p = h->p2p;
     for (int q = 0; q < p.world; ++q) cx.data[q] = p.camdata[q];
     cx.rank = p.rank; cx.world = p.world; cx.C = (int)h->C; cx.error = p.words + 1;
-    cx.timeout = p.first_in_solve ? 6000000000ll : 300000000ll;            // (as p2p_fill_args)
+    cx.timeout = p.first_in_solve ? kP2pFirstTicks : kP2pSteadyTicks;      // (as p2p_fill_args)
     if (h->dbg.p2p_timeout_ms > 0) cx.timeout = 100000ll * h->dbg.p2p_timeout_ms;
     p.first_in_solve = false;
     return cx;
@@ -580,11 +594,20 @@ int wait_stream(sfmba_handle* h) {
 // speculative launches cost 5.8 us before the first kernel of the next iteration.  The post of an iteration
 // arrives a few hundred microseconds after the host has finished enqueueing it; only past 5 ms is the stream
 // queried (every millisecond), to notice a failed launch instead of spinning forever.
+int p2p_timed_out(sfmba_handle* h, unsigned code);
 int mailbox_arrived(sfmba_handle* h, const char* where, double t0) {
     report_stall(h, where, now_s() - t0);
     if (h->mbox[kMboxErr] != 0.0)          // published with every post: a direct all-reduce gave up waiting for a peer
-        return fail(h, -5, "a direct all-reduce timed out waiting for a peer rank");
+        return p2p_timed_out(h, (unsigned)h->mbox[kMboxErr]);
     return 0;
+}
+
+// the error word of the direct link (k_p2p_allreduce: 1; cam_exchange_value: which exchange, value and camera) as text
+int p2p_timed_out(sfmba_handle* h, unsigned code) {
+    if ((code & 0x80000000u) == 0u) return fail(h, -5, "a direct all-reduce timed out waiting for a peer rank");
+    static const char* const kinds[8] = {"?", "?", "Schur product (pass B)", "camera blocks (K3)", "reduced right-hand side", "?", "?", "?"};
+    return fail(h, -5, "a direct all-reduce timed out waiting for a peer rank: the per-camera exchange of the %s, value %u of "
+                       "camera %u", kinds[(code >> 28) & 7u], (code >> 23) & 31u, code & 0x7FFFFFu);
 }
 
 int wait_mailbox(sfmba_handle* h, unsigned long long seq) {
@@ -1230,7 +1253,7 @@ int pcg_start(sfmba_handle* h, const sfmba_options& opt) {
     h->pcg_L = 0;
     // sharded over the direct link with single-chunk cameras: the local form itself, the all-reduce of the product inside
     // pass B (CamExchange); else the local form with its tail behind the reduction (pcg_split), else the general forms
-    h->pcg_inline = h->p2p.ready && !h->cam_multi && !h->xcd_b && h->dbg.pcg_inline != 0 && h->dbg.pcg_local != 0 &&
+    h->pcg_inline = p2p_inline_ok(h) && !h->cam_multi && !h->xcd_b && h->dbg.pcg_inline != 0 && h->dbg.pcg_local != 0 &&
                     h->dbg.precond != 0 && h->dbg.pcg_split != 1 && (h->pcg_fused || h->sweep_rc_g);
     h->pcg_split = !h->pcg_inline && pcg_split_mode(h);
     const bool own_cameras = (!multi_rank(h) && !h->cam_multi && !h->xcd_b) || h->pcg_split || h->pcg_inline;
@@ -1584,6 +1607,7 @@ void p2p_release(sfmba_handle* h) {
     if (p.own) (void)hipFree(p.own);
     if (p.words) (void)hipFree(p.words);
     p.own = nullptr; p.words = nullptr; p.ready = false; p.world = 0; p.stride = 0;
+    p.shared_device = 1; p.any_multi = false;
 }
 }  // namespace
 
@@ -1658,6 +1682,25 @@ int sfmba_p2p_attach(sfmba_handle* h, const void* handles, int32_t rank, int32_t
         double wsum = 0.5 * world * (world + 1) + (double)round * world;
         for (int k = 1; k < chain; ++k) wsum *= world;
         for (int i = 0; i < nt; ++i) ok = ok && v[i] == wsum * (double)(i % 97 + 1);
+    }
+    // What the ranks have to agree on before the per-camera exchanges may run inside the producing kernels (cam_inline):
+    // slot q = the identity of rank q's GPU (ranks sharing one: a rehearsal), slot `world` = how many ranks hold a shard
+    // whose cameras need combine launches.  One more sum over the link; exact (40-bit integers).
+    {
+        char bus[64] = {0};
+        (void)hipDeviceGetPCIBusId(bus, (int)sizeof bus - 1, h->device);
+        unsigned long long id = 1469598103934665603ull;
+        for (const char* c = bus; *c; ++c) id = (id ^ (unsigned char)*c) * 1099511628211ull;
+        std::fill(v.begin(), v.begin() + world + 1, 0.0);
+        v[(size_t)rank] = (double)(1 + (id >> 24));
+        v[(size_t)world] = (h->cam_multi || h->xcd_b) ? 1.0 : 0.0;
+        HIPCHK(h, hipMemcpyAsync(dev, v.data(), sizeof(double) * (world + 1), hipMemcpyHostToDevice, h->stream));
+        CHK(p2p_allreduce(h, dev, world + 1, 0, nullptr));
+        HIPCHK(h, hipMemcpyAsync(v.data(), dev, sizeof(double) * (world + 1), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        p.shared_device = 0;
+        for (int q = 0; q < world; ++q) p.shared_device += v[(size_t)q] == v[(size_t)rank] ? 1 : 0;
+        p.any_multi = v[(size_t)world] != 0.0;
     }
     const int nt = (int)sizes[2];
     unsigned words[2] = {0, 0};
@@ -2086,7 +2129,8 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     h->lds_vec = (size_t)C * 6 * sizeof(double) <= kLdsDynMax;
     if (h->dbg.tab_lds == 0) h->lds_tab = false;               // test hooks (sfmba_debug_option): force the L2 placements
     if (h->dbg.vec_lds == 0) h->lds_vec = false;
-    h->sweep_rc = C <= kRcMaxCams && (size_t)C * kRcRow * sizeof(double) <= kLdsDynMax && h->dbg.sweep_rc != 0;
+    h->sweep_rc = C <= kRcMaxCams && (size_t)C * kRcRow * sizeof(double) <= kLdsDynMax && h->dbg.sweep_rc != 0 &&
+                  h->dbg.sweep_rc != 2;                        // (2: test hook -- the table in global memory whatever the size)
     h->sweep_rc_g = !h->sweep_rc && h->dbg.sweep_rc != 0;      // too many cameras for the LDS: the table lives in L2
     h->pcg_fused = (h->lds_vec || h->sweep_rc) && C <= kSweepThreads;
     if (h->dbg.pcg_fused == 0) h->pcg_fused = false;
@@ -2919,7 +2963,7 @@ static int solve_impl(sfmba_handle* h, const double* x_start, double* x_inout, c
     if (h->p2p.ready) {
         unsigned err = 0;
         memcpy(&err, h->h_scal + 62, sizeof err);
-        if (err != 0) return fail(h, -5, "a direct all-reduce timed out waiting for a peer rank");
+        if (err != 0) return p2p_timed_out(h, err);
     }
     staging_copy(h, x_inout, mirrored ? h->mirror[xw].p : (const void*)h->h_x, xbytes);
     if (h->mirror_on) HIPCHK(h, hipStreamSynchronize(h->copy_stream));     // (a copy of a rejected last trial may still run)

@@ -173,6 +173,9 @@ class DirectLink:
             backend.p2p_detach()
             return
         self.active = True
+        # (sfmba_p2p_attach also settled, over the link itself, what the ranks must agree on before the per-camera sums may
+        # be exchanged inside the producing kernels: whether any rank's shard needs combine launches, and how many ranks
+        # share one GPU -- a rehearsal of N > 1 on one device, where waiting workgroups must not fill the card.)
 
     def close(self):
         if self.active:

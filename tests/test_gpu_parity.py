@@ -777,7 +777,7 @@ def test_exchange_path_world1_nccl(dbg):
 
 # ---- a REAL two-rank run of the C++ solver: both ranks share the one GPU, collectives over gloo ------------
 
-def _two_rank_worker(rank, world, port, q, direct=False, dims=(11, 3000, 10000, 0, 0.01)):
+def _two_rank_worker(rank, world, port, q, direct=False, dims=(11, 3000, 10000, 0, 0.01), debug=()):
     import torch
     import torch.distributed as td
     import sfmba
@@ -787,42 +787,52 @@ def _two_rank_worker(rank, world, port, q, direct=False, dims=(11, 3000, 10000, 
     torch.cuda.set_device(0)
     td.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        pb = sfmba.make_problem(dims[0], dims[1], dims[2], seed=dims[3], x0_noise=dims[4])
-        shards = sdist.partition_points(pb.point_indices, pb.n_points, world)
-        loc = sdist.shard_problem(pb, shards[rank])
-        be = sfmba.Backend(0)
-        stream = torch.cuda.Stream()
-        with torch.cuda.stream(stream):
-            be.set_stream(stream.cuda_stream)
-            be.set_problem(*loc.args)
-            ex = sdist.Exchange(be, n_obs_local=loc.n_obs, device="cuda")     # gloo all-reduces CUDA tensors
-            link = sdist.DirectLink(be) if direct else None                   # peers mapped through hipIpc
-            opt = be.default_options()
-            opt.ftol = 1e-10
-            x, res, fun, grad = be.solve(loc.x0, opt)
-            torch.cuda.synchronize()
-            x2 = be.solve(loc.x0, opt)[0] if direct else x                    # staging buffers are reusable
-        td.barrier()
-        direct_calls = be.p2p_calls()
-        if link is not None:
-            link_active = link.active
-            link.close()
-        else:
-            link_active = False
-        xs = [None] * world
-        td.all_gather_object(xs, x)
-        if rank == 0:
-            q.put(dict(x=sdist.merge_solutions(xs, shards, pb.n_cameras, pb.n_points),
-                       cams_equal=all(np.array_equal(xi[:6 * dims[0]], xs[0][:6 * dims[0]]) for xi in xs),
-                       status=int(res.status), nfev=int(res.nfev), cost=float(res.cost), rmse=float(res.rmse),
-                       calls=ex.n_calls, direct_calls=direct_calls, link_active=link_active,
-                       again=float(np.abs(x2 - x).max())))
-        be.close()
+        _two_rank_body(rank, world, q, direct, dims, debug, torch, td, sfmba, sdist)
+    except Exception as e:                                       # noqa: BLE001 -- the parent fails at once, with the text
+        q.put(dict(error=f"rank {rank}: {type(e).__name__}: {e}"))
+        raise
     finally:
         td.destroy_process_group()
 
 
-def _run_ranks(world, direct, dims=(11, 3000, 10000, 0, 0.01)):
+def _two_rank_body(rank, world, q, direct, dims, debug, torch, td, sfmba, sdist):
+    pb = sfmba.make_problem(dims[0], dims[1], dims[2], seed=dims[3], x0_noise=dims[4])
+    shards = sdist.partition_points(pb.point_indices, pb.n_points, world)
+    loc = sdist.shard_problem(pb, shards[rank])
+    be = sfmba.Backend(0)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        be.set_stream(stream.cuda_stream)
+        for name, value, *only in debug:                                  # (name, value[, the one rank it is set on])
+            if not only or only[0] == rank:
+                be.debug_option(name, value)
+        be.set_problem(*loc.args)
+        ex = sdist.Exchange(be, n_obs_local=loc.n_obs, device="cuda")     # gloo all-reduces CUDA tensors
+        link = sdist.DirectLink(be) if direct else None                   # peers mapped through hipIpc
+        opt = be.default_options()
+        opt.ftol = 1e-10
+        x, res, fun, grad = be.solve(loc.x0, opt)
+        torch.cuda.synchronize()
+        x2 = be.solve(loc.x0, opt)[0] if direct else x                    # staging buffers are reusable
+    td.barrier()
+    direct_calls = be.p2p_calls()
+    if link is not None:
+        link_active = link.active
+        link.close()
+    else:
+        link_active = False
+    xs = [None] * world
+    td.all_gather_object(xs, x)
+    if rank == 0:
+        q.put(dict(x=sdist.merge_solutions(xs, shards, pb.n_cameras, pb.n_points),
+                   cams_equal=all(np.array_equal(xi[:6 * dims[0]], xs[0][:6 * dims[0]]) for xi in xs),
+                   status=int(res.status), nfev=int(res.nfev), cost=float(res.cost), rmse=float(res.rmse),
+                   calls=ex.n_calls, direct_calls=direct_calls, link_active=link_active,
+                   again=float(np.abs(x2 - x).max())))
+    be.close()
+
+
+def _run_ranks(world, direct, dims=(11, 3000, 10000, 0, 0.01), debug=()):
     import socket
     import torch.multiprocessing as mp
     with socket.socket() as s:
@@ -830,13 +840,16 @@ def _run_ranks(world, direct, dims=(11, 3000, 10000, 0, 0.01)):
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, q, direct, dims)) for r in range(world)]
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, q, direct, dims, debug)) for r in range(world)]
     for p in procs:
         p.start()
     out = q.get(timeout=300)
     for p in procs:
-        p.join(timeout=300)
-        assert p.exitcode == 0
+        p.join(timeout=20 if "error" in out else 300)
+        if p.is_alive():
+            p.terminate()
+    assert "error" not in out, out["error"]
+    assert all(p.exitcode == 0 for p in procs)
     return out
 
 
@@ -863,7 +876,10 @@ def test_direct_allreduce_over_peer_mapped_memory(dbg):
         assert np.abs(out["x"] - ref.x).max() <= 1e-6 * np.abs(ref.x).max()
     # other shapes: an odd camera count (scalar slots no longer 16-byte aligned), a far start with rejected steps
     # (retries, speculative trials), and more cameras than a single-workgroup collective carries
-    for world, dims in ((3, (7, 500, 4000, 3, 0.01)), (2, (6, 80, 500, 5, 0.2)), (2, (300, 2000, 16000, 9, 0.01))):
+    # ... and more cameras than the LDS table of pass A holds (table in global memory, PCG update as a kernel of its own,
+    # the per-camera exchange inside pass B / K3 / the rhs pass as everywhere on the direct link)
+    for world, dims in ((3, (7, 500, 4000, 3, 0.01)), (2, (6, 80, 500, 5, 0.2)), (2, (300, 2000, 16000, 9, 0.01)),
+                        (2, (1300, 4000, 40000, 21, 0.01))):
         pb = sfmba.make_problem(dims[0], dims[1], dims[2], seed=dims[3], x0_noise=dims[4])
         ref = sfmba.least_squares(sfmba.compute_residuals, pb.x0, x_scale="jac", ftol=1e-10, method="trf",
                                   args=pb.args)
@@ -873,14 +889,29 @@ def test_direct_allreduce_over_peer_mapped_memory(dbg):
         # between differently ordered sums; the path (nfev, cost, x) is not
         assert out["nfev"] == ref.nfev and (out["status"] == ref.status or {out["status"], ref.status} <= {2, 3, 4})
         assert abs(out["cost"] - ref.cost) <= 1e-9 * ref.cost
+    # the form problems of more than 1100 cameras run -- pass A's table in global memory, the PCG update a kernel of its
+    # own -- WITH the per-camera exchange inside pass B (at its real size two ranks' camera workgroups do not fit one
+    # shared device, and DirectLink falls back to the collective launches: the 1300-camera case above); forced here at 300
+    # cameras through the test hooks, with fp64 and with fp32 operands
+    pb = sfmba.make_problem(300, 2000, 16000, seed=9)
+    ref = sfmba.least_squares(sfmba.compute_residuals, pb.x0, x_scale="jac", ftol=1e-10, method="trf", args=pb.args)
+    for extra in ((), (("pcg_mixed", 1),)):
+        out = _run_ranks(2, direct=True, dims=(300, 2000, 16000, 9, 0.01), debug=(("sweep_rc", 2), ("pcg_fused", 0)) + extra)
+        assert out["link_active"] and out["calls"] == 0 and out["cams_equal"] and out["again"] == 0.0
+        assert out["nfev"] == ref.nfev and (out["status"] == ref.status or {out["status"], ref.status} <= {2, 3, 4})
+        assert abs(out["cost"] - ref.cost) <= 1e-9 * ref.cost
+    # Whether a camera's list is cut into several chunks is a property of a rank's SHARD, and the in-kernel exchange needs
+    # single-chunk cameras: the ranks settle it at attach.  Rank 1 alone is given short chunks here -- every rank then
+    # keeps the collective launches (ranks that decided each for itself would wait for each other in different kernels).
+    out = _run_ranks(2, direct=True, dims=(300, 2000, 16000, 9, 0.01), debug=(("cam_chunk", 16, 1),))
+    assert out["link_active"] and out["calls"] == 0 and out["cams_equal"] and out["again"] == 0.0
+    assert out["nfev"] == ref.nfev and abs(out["cost"] - ref.cost) <= 1e-9 * ref.cost
 
 
 def test_two_rank_solve_on_one_gpu_gloo(dbg):
     """The production solver, observation-sharded over TWO processes that share the single GPU, with the
     callback transport over gloo: replicated cameras bitwise identical on both ranks, merged solution and
     cost equal to the single-process solve (and scipy's RMSE to 1e-6)."""
-    import socket
-    import torch.multiprocessing as mp
     import sfmba
     rec = json.load(open(os.path.join(GOLDEN, "scipy_cfg2_run.json")))
     pb = sfmba.make_problem(11, 3000, 10000, seed=0)
@@ -888,18 +919,7 @@ def test_two_rank_solve_on_one_gpu_gloo(dbg):
     dbg((sfmba.get_backend(0),), "pcg_split", 1)   # ... in the form sharded solves run
     ref = sfmba.least_squares(sfmba.compute_residuals, pb.x0, x_scale="jac", ftol=1e-10, method="trf",
                               args=pb.args)
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    out = q.get(timeout=300)
-    for p in procs:
-        p.join(timeout=300)
-        assert p.exitcode == 0
+    out = _run_ranks(2, direct=False)
     assert out["cams_equal"] and out["calls"] > 20
     # (2 / 3 / 4: which of ftol and xtol the last, 13th-digit step satisfies is rounding noise between sum orders)
     assert out["nfev"] == ref.nfev and (out["status"] == ref.status or {out["status"], ref.status} <= {2, 3, 4})
