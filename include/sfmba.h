@@ -169,7 +169,14 @@ int  sfmba_comm_destroy(sfmba_handle* h);
  *   (the caller all-gathers the handles over any channel, rank order)
  *   sfmba_p2p_attach  maps the peers' buffers and runs a 24-round self-test (the three message sizes of
  *                     the solver, chains of back-to-back collectives); returns -5 and detaches when
- *                     mapping or the self-test fails (the previous transport stays).
+ *                     mapping or the self-test fails (the previous transport stays).  Its last collective settles
+ *                     what the ranks must agree on for the per-camera sums to be exchanged INSIDE the kernels that
+ *                     form them (pass B of the Schur product, the camera blocks, the reduced right-hand side): that
+ *                     no rank's shard has a camera cut into several chunks, and how many ranks sit on one physical
+ *                     GPU (a rehearsal: waiting workgroups of one rank must not fill the card the other needs).
+ *                     Otherwise those sums keep collective launches of their own -- on every rank alike.
+ * A wait gives up after 30 s (60 s for the first collective of a solve, the rendezvous) and fails the solve with -5;
+ * the text of sfmba_last_error names the exchange and the camera whose peer value did not arrive.
  * All ranks must attach or none: agree on the minimum of the return codes and call sfmba_p2p_detach on
  * every rank if any failed.  world <= 16.  Results are summed in rank order: bitwise equal on all ranks. */
 int  sfmba_p2p_export(sfmba_handle* h, int32_t world, void* handle64_out);
