@@ -258,7 +258,12 @@ int  sfmba_tr2d_solve(const double* B3, const double* g2, double Delta, double* 
  *                       storage, sfmba_set_precision); "pcg_mixed_b" 0: pass B keeps its fp64 point records
  *   "pcg_inline"        0: sharded solves over the direct link keep the all-reduces of the per-camera sums as launches
  *                       of their own (default: exchanged by the producing workgroups; ranks that SHARE one device --
- *                       rehearsals -- need 0 once their camera workgroups together exceed the device's resident slots)
+ *                       rehearsals -- get 0 by themselves once their camera workgroups together exceed the device's
+ *                       resident slots: settled at sfmba_p2p_attach)
+ *   "pcg_skip_last"     0: the launches that a replayed record says find the PCG solve finished are enqueued all the
+ *                       same; 2: only the pass B is left out (default: neither the last pass A -- k_backsub's prologue
+ *                       does its update -- nor the pass B behind it is enqueued; both are owed if the record turns out
+ *                       too short)
  *   "cm_device"      P  1 / 0: camera-major order sorted on the device / on the host (default: device from 64k
  *                       observations on); "packed_upload" P 1 / 0: observation arrays uploaded packed (same default)
  *   "jfree"          P  1: the J-free iteration (measurement): K1 does not write the Jacobian, k_jdot / k_backsub

@@ -1644,6 +1644,44 @@ struct PcgFused {
 };
 constexpr int kPcgM = kPcgUcm;           // the local form keeps m = Minv s where the two-kernel form keeps its copy of u
 
+// The scalars of one iteration of the LOCAL form (see PcgFused), from the partial dot products pass B left per camera:
+// every thread of the workgroup (one camera each; 16 waves) returns alpha and the control block `co` that follows `ci`
+// (co.done = 3: S not SPD / NaN, alpha unusable).  One order of summation wherever it is evaluated -- the prologue of the
+// next pass A, or the prologue of k_backsub when the host left the last pass A out (FinalUpdate).
+__device__ __forceinline__ double pcg_local_step(const double* __restrict__ part, int C, const PcgCtrl& ci, PcgCtrl& co) {
+    __shared__ double red4[16][4];
+    const int cam = threadIdx.x;
+    double q4[4] = {0.0, 0.0, 0.0, 0.0};
+    if (cam < C) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q4[k] = part[(size_t)k * C + cam];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) q4[k] = wave_sum(q4[k]);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) red4[threadIdx.x >> 6][k] = q4[k];
+    }
+    __syncthreads();
+    double tot[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tot[k] += red4[w][k];
+    }
+    const double delta = tot[0], su = tot[1], sm = tot[2], gamma = tot[3];     // w.u, s.u, s.m, r.u (true gamma_i)
+    const double beta = ci.iters == 0 ? 0.0 : ci.rz / ci.rz_prev;             // the beta pass B built s and p with
+    const double den = delta - (ci.iters == 0 ? 0.0 : beta * gamma / ci.alpha_prev);
+    const double alpha = gamma / den;
+    co = ci;
+    if (!(den > 0.0) || !isfinite(alpha)) { co.done = 3; return 0.0; }
+    const double rz = gamma - 2.0 * alpha * su + alpha * alpha * sm;          // gamma_{i+1}
+    int done = 0;
+    if (!(rz > ci.tol2 * ci.rz0)) done = 1;                   // also catches NaN and a cancelled-out (<= 0) value
+    else if (ci.iters + 1 >= ci.max_iters) done = 2;
+    co.rz_prev = gamma; co.alpha_prev = alpha; co.rz = rz; co.iters = ci.iters + 1; co.done = done;
+    return alpha;
+}
+
 // The PCG update in the prologue of a fused pass-A launch (see PcgFused): returns false when the launch has
 // nothing more to do (the solve had finished or finishes here; grid-uniform).  Otherwise uu = the new u of
 // camera threadIdx.x (zeros for threads without a camera), which the caller puts into its LDS table.
@@ -1676,12 +1714,8 @@ __device__ __forceinline__ bool pcg_fused_update(const PcgFused& pf, const doubl
     }
     if (pf.part != nullptr && L != 0) {
         // ---- local form: iteration i = L - 1; its product and camera-side bookkeeping were done by pass B(L-1) ----
-        __shared__ double red4[16][4];
-        double q4[4] = {0.0, 0.0, 0.0, 0.0};
         double ue[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, me[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         if (has) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) q4[k] = pf.part[(size_t)k * C + cam];
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
                 const size_t e = (size_t)k * C + cam;
@@ -1689,35 +1723,11 @@ __device__ __forceinline__ bool pcg_fused_update(const PcgFused& pf, const doubl
                 me[k] = pf.vecs[kPcgM * n6 + e];
             }
         }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) q4[k] = wave_sum(q4[k]);
-        if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) red4[threadIdx.x >> 6][k] = q4[k];
-        }
-        __syncthreads();
-        double tot[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) tot[k] += red4[w][k];
-        }
-        const double delta = tot[0], su = tot[1], sm = tot[2], gamma = tot[3];     // w.u, s.u, s.m, r.u (true gamma_i)
-        const double beta = ci.iters == 0 ? 0.0 : ci.rz / ci.rz_prev;             // the beta pass B built s and p with
-        const double den = delta - (ci.iters == 0 ? 0.0 : beta * gamma / ci.alpha_prev);
-        const double alpha = gamma / den;
-        if (!(den > 0.0) || !isfinite(alpha)) {                // S not SPD / NaN: x stays the last good iterate
-            if (writer) { PcgCtrl co = ci; co.done = 3; *cout = co; }
-            return false;
-        }
-        const double rz = gamma - 2.0 * alpha * su + alpha * alpha * sm;          // gamma_{i+1}
-        int done = 0;
-        if (!(rz > ci.tol2 * ci.rz0)) done = 1;               // also catches NaN and a cancelled-out (<= 0) value
-        else if (ci.iters + 1 >= ci.max_iters) done = 2;
-        if (writer) {
-            PcgCtrl co = ci;
-            co.rz_prev = gamma; co.alpha_prev = alpha; co.rz = rz; co.iters = ci.iters + 1; co.done = done;
-            *cout = co;
-        }
+        PcgCtrl co;
+        const double alpha = pcg_local_step(pf.part, C, ci, co);
+        if (writer) *cout = co;
+        if (co.done == 3) return false;                        // S not SPD / NaN: x stays the last good iterate
+        const int done = co.done;
         if (has) {
 #pragma unroll
             for (int k = 0; k < 6; ++k) uu[k] = ue[k] - alpha * me[k];
@@ -3411,16 +3421,63 @@ __global__ __launch_bounds__(1024) void k_pcg_update(const double* __restrict__ 
 // q5 = g.p, q6 = |p s|^2, q7 = (D^2 g).p, q8 = |p|^2 -- the point part where each dp is produced (run heads),
 // the camera part spread over the workgroups.  part[block] = (G12, G22, q5..q8 points, q5..q8 cameras), kBacksubCols wide.
 constexpr int kBacksubCols = 10;
+// The last step of a PCG solve in the LOCAL fused form, done HERE instead of by one more launch of pass A (fu.part != null;
+// LDS_VEC only): when the host replays a record it trusts count for count, the launch of pass A whose prologue would only
+// find the solve finished -- alpha of the last iteration, x += alpha p, the control block -- is left out (8 us per outer
+// iteration) and every workgroup of this kernel forms alpha from pass B's partial dot products itself
+// (pcg_local_step: the same sums in the same order) while it stages the step into its LDS.  Workgroup 0 writes the
+// control block and the finished x exactly as that launch would have.  Should the solve NOT be finished (the record was
+// too short), the control block says so, k_tr_step cancels the trial as for any short guess, this launch returns at once
+// and the host enqueues the owed pass A / pass B pair: nothing the pair reads has been touched.
+struct FinalUpdate {
+    const double* __restrict__ part;     // [4][C] partial dot products of the cameras (null: x is final already)
+    double* __restrict__ vecs;           // PCG vector sets (x and p of the local form live in set 0, x in both)
+    PcgCtrl* __restrict__ ctrl2;
+    int L;                               // the launch of pass A that was left out
+};
 template <bool LDS_VEC, bool JFREE = false>
 __global__ __launch_bounds__(kSweepThreads) void k_backsub(
     const int2* __restrict__ ranges, int n_ranges, ObsArrays o, const double* __restrict__ dc_planes,
     double* __restrict__ dc, const double* __restrict__ Vinv, const double* __restrict__ gp,
     const double* __restrict__ t1, double* __restrict__ dp, double* __restrict__ part, int C,
     const PcgCtrl* __restrict__ ctrl2, int L, const double* __restrict__ gvec,
-    const double* __restrict__ si, const double* __restrict__ sg, Recompute rc) {
+    const double* __restrict__ si, const double* __restrict__ sg, Recompute rc, FinalUpdate fu) {
     static_assert(!(LDS_VEC && JFREE), "J-free: the LDS holds the camera table, the step vector comes from L2");
     extern __shared__ __align__(16) double smem[];
     __shared__ double red[kBacksubCols * kWavesPerSweepBlock];
+    if (LDS_VEC && fu.part != nullptr) {
+        const int n6 = 6 * C, cam = threadIdx.x;
+        const PcgCtrl ci = fu.ctrl2[fu.L & 1];
+        PcgCtrl co = ci;
+        double alpha = 0.0;
+        double xe[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, pe[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        if (cam < C) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                xe[k] = fu.vecs[kPcgX * n6 + (size_t)k * C + cam];
+                pe[k] = fu.vecs[kPcgP * n6 + (size_t)k * C + cam];
+            }
+        }
+        if (ci.done == 0) alpha = pcg_local_step(fu.part, C, ci, co);     // (else: finished earlier than the record says)
+        if (blockIdx.x == 0 && threadIdx.x == 0) fu.ctrl2[(fu.L + 1) & 1] = co;
+        if (co.done == 0) return;                                         // grid-uniform: the record was too short
+        const bool add = ci.done == 0 && co.done != 3;                    // (3: x stays the last good iterate)
+        if (cam < C) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const double xk = add ? xe[k] + alpha * pe[k] : xe[k];
+                smem[6 * cam + k] = xk;
+                if (blockIdx.x == 0) {
+                    dc[6 * cam + k] = xk;
+                    if (add) {
+                        fu.vecs[kPcgX * n6 + (size_t)k * C + cam] = xk;
+                        fu.vecs[(size_t)kPcgVecs * n6 + kPcgX * n6 + (size_t)k * C + cam] = xk;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    } else {
     if (ctrl2 != nullptr)                      // dc_planes = base of the PCG vector sets: take x of the final set
         dc_planes += (size_t)((ctrl2[L & 1].iters & 1) * kPcgVecs + kPcgX) * 6 * C;
     // dc_planes: PCG solution, plane-major [6][C]; dc: camera-major [C][6] copy (already written by
@@ -3433,6 +3490,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_backsub(
             if (blockIdx.x == 0) dc[6 * c + k] = val;
         }
         __syncthreads();
+    }
     }
     if (JFREE) stage_cam_table(rc.camtab, C, smem);
     const double* __restrict__ vv = LDS_VEC ? smem : dc;

@@ -256,6 +256,7 @@ struct sfmba_handle {
                                              // k_backsub recompute its blocks from the LDS camera table
         int cm_device = -1;                  // 0: the camera-major order is sorted on the host and its permutation uploaded
         int pcg_inline = -1;                 // 0: sharded solves keep the collective of the product as a launch of its own
+        int pcg_skip_last = -1;              // 0: the pass B behind the launch the record says is the last one is enqueued all the same
         int pcg_mixed_b = -1;                // 0: pass B keeps fp64 point records although pass A runs on fp32 operands
         int pcg_mixed = -1;                  // 1 / 0: fp32 operands in the implicit Schur product whatever the storage mode
         int pcg_split = -1;                  // 1: the local form with its tail in a kernel of its own (k_pcg_tail) on a
@@ -354,6 +355,8 @@ struct sfmba_handle {
     bool pcg_fused = false;               // PCG update fused into the launch of pass A (v in LDS, C <= 1024)
     bool pcg_local = false;               // ... with the per-camera bookkeeping in pass B (one rank, single-chunk cameras)
     bool pcg_local2 = false;              // the same bookkeeping with the light update as a kernel of its own (> 1024 cameras)
+    bool pcg_b_owed = false;              // the pass B behind the last enqueued pass A was left out (pcg_enqueue)
+    bool pcg_a_owed = false;              // ... and that pass A too: k_backsub does its update (FinalUpdate)
     bool pcg_inline = false;              // sharded, direct link, single-chunk cameras: the product's all-reduce runs inside
                                           // pass B, camera by camera (CamExchange), and the iteration is the local form
     bool pcg_split = false;               // local form whose per-camera tail runs behind the reduction (k_p2p_pcg / k_pcg_tail)
@@ -1065,7 +1068,7 @@ int launch_backsub(sfmba_handle* h, int* nparts) {
         CHK(set_lds(h, kern, lds));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), lds, h->stream, h->ranges.as<int2>(), h->n_ranges, obs_arrays(h),
                            h->vecs.as<double>(), dc, vinv_ptr(h), h->gp.as<double>(), h->t1.as<double>(), dp, h->partB(),
-                           (int)h->C, (const PcgCtrl*)nullptr, 0, h->g.as<double>(), h->si.as<double>(), h->sg.as<double>(), rc);
+                           (int)h->C, (const PcgCtrl*)nullptr, 0, h->g.as<double>(), h->si.as<double>(), h->sg.as<double>(), rc, FinalUpdate{});
     } else if (h->lds_vec) {
         const size_t lds = sizeof(double) * 6 * h->C;
         auto kern = k_backsub<true>;
@@ -1073,7 +1076,9 @@ int launch_backsub(sfmba_handle* h, int* nparts) {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), lds, h->stream, h->ranges.as<int2>(),
                            h->n_ranges, obs_arrays(h), h->vecs.as<double>(), dc, vinv_ptr(h),
                            h->gp.as<double>(), h->t1.as<double>(), dp, h->partB(), (int)h->C,
-                           ctrl2, h->pcg_L, h->g.as<double>(), h->si.as<double>(), h->sg.as<double>(), rc);
+                           ctrl2, h->pcg_L, h->g.as<double>(), h->si.as<double>(), h->sg.as<double>(), rc,
+                           h->pcg_a_owed ? FinalUpdate{h->pcg_part.as<double>(), h->vecs.as<double>(), h->ctrl.as<PcgCtrl>(), h->pcg_L - 1}
+                                         : FinalUpdate{});
     } else {
         hipLaunchKernelGGL(k_transpose, dim3((6 * h->C + 255) / 256), dim3(256), 0, h->stream,
                            (const double*)h->vecs.as<double>(), 6, (int)h->C, dc, ctrl2, h->pcg_L);
@@ -1082,7 +1087,7 @@ int launch_backsub(sfmba_handle* h, int* nparts) {
                            h->ranges.as<int2>(), h->n_ranges, obs_arrays(h), h->vecs.as<double>(), dc,
                            vinv_ptr(h), h->gp.as<double>(), h->t1.as<double>(), dp,
                            h->partB(), (int)h->C, (const PcgCtrl*)nullptr, 0, h->g.as<double>(),
-                           h->si.as<double>(), h->sg.as<double>(), rc);
+                           h->si.as<double>(), h->sg.as<double>(), rc, FinalUpdate{});
     }
     LAUNCHED(h);
     *nparts = grid;
@@ -1251,6 +1256,8 @@ int pcg_max_iters(const sfmba_handle* h, const sfmba_options& opt) {
 // x = 0, r = rhs, u = Minv r (acc holds the reduced right-hand side term of pass B, MODE 1)
 int pcg_start(sfmba_handle* h, const sfmba_options& opt) {
     h->pcg_L = 0;
+    h->pcg_b_owed = false;
+    h->pcg_a_owed = false;
     // sharded over the direct link with single-chunk cameras: the local form itself, the all-reduce of the product inside
     // pass B (CamExchange); else the local form with its tail behind the reduction (pcg_split), else the general forms
     h->pcg_inline = p2p_inline_ok(h) && !h->cam_multi && !h->xcd_b && h->dbg.pcg_inline != 0 && h->dbg.pcg_local != 0 &&
@@ -1300,20 +1307,48 @@ int launch_reduce_and_tail(sfmba_handle* h, const PcgCtrl* cd, int set) {
 }
 
 // enqueue `count` PCG iterations (pass A [+ update], pass B, all-reduce [, update]); iterations after
-// convergence are device-side no-ops, so over-enqueueing is harmless and deterministic
-int pcg_enqueue(sfmba_handle* h, int count) {
+// convergence are device-side no-ops, so over-enqueueing is harmless and deterministic.
+// `ends_here` (fused form, one rank, count taken from the record of the same solve): the last launch of pass A is the one
+// whose prologue finds the solve finished, so the pass B behind it would return at its first instruction -- 4.5 us of
+// launch for nothing, once per outer iteration: it is not enqueued.  Should the record be wrong after all (the control
+// block read back says "not finished"), the launch is owed: the next call here starts with it (pass B of launch L
+// needs nothing but the z of pass A of launch L and the vector sets, both untouched since).
+int pcg_pass_b(sfmba_handle* h, int L) {
+    const PcgCtrl* cd = h->ctrl.as<PcgCtrl>() + ((L + 1) & 1);
+    CHK(launch_cam_schur<0>(h, h->vecs.as<double>(), cd, L & 1, h->pcg_local && !h->pcg_split, h->pcg_inline));
+    if (h->pcg_split) CHK(launch_reduce_and_tail(h, cd, L & 1));
+    else if (!h->pcg_inline) CHK(exchange(h, h->acc(), 6 * h->C, 0, &cd->done));
+    return 0;
+}
+
+int pcg_enqueue(sfmba_handle* h, int count, bool ends_here = false) {
     PcgCtrl* ctrl2 = h->ctrl.as<PcgCtrl>();
+    if (h->pcg_a_owed) {                                        // (k_backsub stood in for this launch and found work left)
+        h->pcg_a_owed = false;
+        h->pcg_b_owed = true;
+        CHK(launch_pcg_fused(h, h->pcg_L - 1));
+    }
+    if (h->pcg_b_owed) {
+        h->pcg_b_owed = false;
+        CHK(pcg_pass_b(h, h->pcg_L - 1));
+    }
     for (int k = 0; k < count; ++k) {
         const int L = h->pcg_L;
         if (h->pcg_fused) {
+            const bool last = ends_here && k == count - 1 && !multi_rank(h) && h->dbg.pcg_skip_last != 0;
+            // ... and in the local form with the step vector in k_backsub's LDS not even that pass A: k_backsub's prologue
+            // does its update (FinalUpdate)
+            if (last && L > 0 && h->pcg_local && h->lds_vec && !h->jfree && h->dbg.pcg_skip_last != 2) {
+                h->pcg_L = L + 1;
+                h->pcg_a_owed = true;
+                break;
+            }
             CHK(launch_pcg_fused(h, L));
             // a launch that found the solve finished (or finished it) produced no z: its control block (written
             // to slot (L+1)&1) says so, and pass B and the collective behind it are void as well
-            const PcgCtrl* cd = ctrl2 + ((L + 1) & 1);
-            CHK(launch_cam_schur<0>(h, h->vecs.as<double>(), cd, L & 1, h->pcg_local && !h->pcg_split, h->pcg_inline));
-            if (h->pcg_split) CHK(launch_reduce_and_tail(h, cd, L & 1));
-            else if (!h->pcg_inline) CHK(exchange(h, h->acc(), 6 * h->C, 0, &cd->done));
             h->pcg_L = L + 1;
+            if (last) { h->pcg_b_owed = true; break; }
+            CHK(pcg_pass_b(h, L));
             continue;
         }
         const PcgCtrl* cd = ctrl2 + (L & 1);                     // current until k_pcg_update writes the other one
@@ -1490,6 +1525,7 @@ int sfmba_debug_option(sfmba_handle* h, const char* name, int64_t value) {
     else if (n == "pcg_split") h->dbg.pcg_split = v;
     else if (n == "pcg_mixed") h->dbg.pcg_mixed = v;
     else if (n == "pcg_inline") h->dbg.pcg_inline = v;
+    else if (n == "pcg_skip_last") h->dbg.pcg_skip_last = v;
     else if (n == "cm_device") h->dbg.cm_device = v;
     else if (n == "jfree") h->dbg.jfree = v;
     else if (n == "packed_upload") h->dbg.packed_upload = v;
@@ -2733,7 +2769,7 @@ static int solve_impl(sfmba_handle* h, const double* x_start, double* x_inout, c
         } else if (pcg_guess > 0) {
             // speculative: no read-back; surplus launches are no-ops.  Fused launches apply the update of
             // iteration k in launch k + 1, so k iterations need k + 1 launches; one spare either way.
-            CHK(pcg_enqueue(h, pcg_guess + (h->pcg_fused ? 1 : 0) + (guess_exact ? 0 : 1)));
+            CHK(pcg_enqueue(h, pcg_guess + (h->pcg_fused ? 1 : 0) + (guess_exact ? 0 : 1), guess_exact));
         } else {
             CHK(pcg_finish_polling(h, opt, &hc));
         }

@@ -482,6 +482,43 @@ def test_speculative_pcg_miss_changes_nothing(dbg):
             assert np.abs(r - b.fun).max() < 1e-8
 
 
+def test_replayed_pcg_record_that_turns_out_wrong(dbg):
+    """Back-to-back solves of the same problem from the same start replay the previous solve's PCG record count for
+    count: no spare launch, and the pass B behind the launch the record calls the last one is not even enqueued.  The
+    record is keyed on the problem and the start, not on the options: the same call with a tighter forcing term needs
+    MORE iterations than recorded.  The device then cancels the trial, the host enqueues the owed pass B and polls to the
+    end -- same result as on a handle without a record; a record that is too long costs empty launches only."""
+    import sfmba
+    pb = sfmba.make_problem(60, 900, 9000, seed=12)
+    hist = {}
+    for tol in (1e-2, 1e-5):
+        fresh = sfmba.Backend(0)
+        fresh.debug_option("dense", 0)
+        fresh.set_problem(*pb.args)
+        opt = fresh.default_options()
+        opt.ftol = 1e-10
+        opt.pcg_tol = tol
+        opt.pcg_tol_max = tol
+        x, res, _, _ = fresh.solve(pb.x0, opt)
+        hist[tol] = (x, res.nfev, res.cost, fresh.pcg_history())
+        fresh.close()
+    assert sum(hist[1e-5][3]) > sum(hist[1e-2][3]) + 5                   # the two records really differ
+    be = sfmba.Backend(0)
+    be.debug_option("dense", 0)
+    be.set_problem(*pb.args)
+    opt = be.default_options()
+    opt.ftol = 1e-10
+    for skip in (-1, 0):                                                 # (0: the last pass B is enqueued as before)
+        be.debug_option("pcg_skip_last", skip)
+        for tol in (1e-2, 1e-2, 1e-5, 1e-5, 1e-2):                       # exact replay, too short a record, too long a one
+            opt.pcg_tol = tol
+            opt.pcg_tol_max = tol
+            x, res, _, _ = be.solve(pb.x0, opt)
+            assert np.array_equal(x, hist[tol][0]) and (res.nfev, res.cost) == hist[tol][1:3]
+            assert be.pcg_history() == hist[tol][3]
+    be.close()
+
+
 def test_fused_pcg_launch_equals_sweep_plus_update(dbg):
     """With v in LDS and at most 1024 cameras, the PCG update of the previous product runs in the prologue of
     pass A (one launch less per iteration).  It must walk through the same iterates as the separate

@@ -3,6 +3,8 @@
     python tools/profile_summary.py stats  <rocprof_dir> <out.md>     # --kernel-trace --stats run
     python tools/profile_summary.py pmc    <fetch_dir> <write_dir> <out.json> <workload>
     python tools/profile_summary.py counters <out.json> <label> <dir> [<dir> ...]   # any --pmc passes: per-kernel averages
+    python tools/profile_summary.py timeline <rocprof_dir> <out.txt>   # the LAST solve of a --kernel-trace run, launch by
+                                                                       # launch: start, duration, idle time in front of it
 """
 import csv, glob, json, sys, collections
 
@@ -30,6 +32,27 @@ def stats(d, out):
                 r["Name"][:90], r["Calls"], float(r["TotalDurationNs"]) / 1e3, float(r["AverageNs"]) / 1e3,
                 float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"], v[len(v) // 2], len(real), sum(real) / max(1, len(real))))
     print(open(out).read())
+
+
+def timeline(d, out):
+    """The last solve of the trace (from its last K1 launch with Jacobian behind a gap of more than 150 us, i.e. the
+    upload of x0, to the end): every launch with the idle time in front of it, and the sums."""
+    tr = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in
+                 csv.DictReader(open(find(d, "kernel_trace.csv")))), key=lambda t: t[0])
+    starts = [i for i in range(1, len(tr)) if tr[i][0] - tr[i - 1][1] > 150000]
+    lo = starts[-1] if starts else 0
+    rows = tr[lo:]
+    busy = sum(e - s for s, e, _ in rows)
+    span = rows[-1][1] - rows[0][0]
+    gaps = [(rows[i][0] - rows[i - 1][1]) for i in range(1, len(rows))]
+    with open(out, "w") as f:
+        f.write(f"{len(rows)} launches, span {span / 1e3:.1f} us, kernels {busy / 1e3:.1f} us, idle {sum(gaps) / 1e3:.1f} us "
+                f"(median gap {sorted(gaps)[len(gaps) // 2] / 1e3:.2f} us)\n")
+        f.write("   t us   dur us  idle-before us  kernel\n")
+        for i, (s0, e0, n) in enumerate(rows):
+            g = 0 if i == 0 else s0 - rows[i - 1][1]
+            f.write(f"{(s0 - rows[0][0]) / 1e3:8.1f} {(e0 - s0) / 1e3:7.2f} {g / 1e3:8.2f}{'  <<<' if g > 4000 else '     '}  {n[:70]}\n")
+    print(open(out).read()[:6000])
 
 
 def pmc(dfetch, dwrite, out, workload):
@@ -85,6 +108,9 @@ def counters(out, label, dirs):
     print(json.dumps(res, indent=1)[:3000])
 
 
+if __name__ == "__main__" and sys.argv[1] == "timeline":
+    timeline(sys.argv[2], sys.argv[3])
+    sys.exit(0)
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
