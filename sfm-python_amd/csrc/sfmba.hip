@@ -1308,11 +1308,14 @@ int launch_reduce_and_tail(sfmba_handle* h, const PcgCtrl* cd, int set) {
 
 // enqueue `count` PCG iterations (pass A [+ update], pass B, all-reduce [, update]); iterations after
 // convergence are device-side no-ops, so over-enqueueing is harmless and deterministic.
-// `ends_here` (fused form, one rank, count taken from the record of the same solve): the last launch of pass A is the one
-// whose prologue finds the solve finished, so the pass B behind it would return at its first instruction -- 4.5 us of
-// launch for nothing, once per outer iteration: it is not enqueued.  Should the record be wrong after all (the control
-// block read back says "not finished"), the launch is owed: the next call here starts with it (pass B of launch L
-// needs nothing but the z of pass A of launch L and the vector sets, both untouched since).
+// `speculative` (fused form, one rank): the batch is the whole guess of an outer iteration and k_backsub follows it.  In
+// the fused form k iterations need k + 1 launches of pass A -- the last one only applies the update of iteration k - 1 and
+// finds the solve finished -- and the pass B behind that launch returns at its first instruction.  That last pair is not
+// enqueued: in the local form k_backsub's prologue does the update itself (FinalUpdate: alpha, x += alpha p, the control
+// block -- 8 us of launch less per outer iteration), otherwise pass A is launched and only its pass B is left out
+// (4.5 us).  Either way the control block tells whether the guess sufficed; if it did not, the pair is OWED: the next
+// call here starts with it (pass A / pass B of launch L need nothing but the vector sets, the partial sums and, for pass
+// B, the z of pass A of launch L, all untouched since).
 int pcg_pass_b(sfmba_handle* h, int L) {
     const PcgCtrl* cd = h->ctrl.as<PcgCtrl>() + ((L + 1) & 1);
     CHK(launch_cam_schur<0>(h, h->vecs.as<double>(), cd, L & 1, h->pcg_local && !h->pcg_split, h->pcg_inline));
@@ -1321,7 +1324,7 @@ int pcg_pass_b(sfmba_handle* h, int L) {
     return 0;
 }
 
-int pcg_enqueue(sfmba_handle* h, int count, bool ends_here = false) {
+int pcg_enqueue(sfmba_handle* h, int count, bool speculative = false) {
     PcgCtrl* ctrl2 = h->ctrl.as<PcgCtrl>();
     if (h->pcg_a_owed) {                                        // (k_backsub stood in for this launch and found work left)
         h->pcg_a_owed = false;
@@ -1335,7 +1338,7 @@ int pcg_enqueue(sfmba_handle* h, int count, bool ends_here = false) {
     for (int k = 0; k < count; ++k) {
         const int L = h->pcg_L;
         if (h->pcg_fused) {
-            const bool last = ends_here && k == count - 1 && !multi_rank(h) && h->dbg.pcg_skip_last != 0;
+            const bool last = speculative && k == count - 1 && !multi_rank(h) && h->dbg.pcg_skip_last != 0;
             // ... and in the local form with the step vector in k_backsub's LDS not even that pass A: k_backsub's prologue
             // does its update (FinalUpdate)
             if (last && L > 0 && h->pcg_local && h->lds_vec && !h->jfree && h->dbg.pcg_skip_last != 2) {
@@ -2769,7 +2772,7 @@ static int solve_impl(sfmba_handle* h, const double* x_start, double* x_inout, c
         } else if (pcg_guess > 0) {
             // speculative: no read-back; surplus launches are no-ops.  Fused launches apply the update of
             // iteration k in launch k + 1, so k iterations need k + 1 launches; one spare either way.
-            CHK(pcg_enqueue(h, pcg_guess + (h->pcg_fused ? 1 : 0) + (guess_exact ? 0 : 1), guess_exact));
+            CHK(pcg_enqueue(h, pcg_guess + (h->pcg_fused ? 1 : 0) + (guess_exact ? 0 : 1), true));
         } else {
             CHK(pcg_finish_polling(h, opt, &hc));
         }
