@@ -778,16 +778,39 @@ constexpr int kCamThreads = 256;
 constexpr int kCamWaves = kCamThreads / 64;
 constexpr int kCamUnroll = 4;
 
+// NV sums over the 64 lanes of a wave at the price of ~NV + 6 exchanges instead of 6 NV: a butterfly that HALVES the
+// values a lane carries at every step -- at mask m the lanes with bit m clear keep the lower half of their values, those
+// with bit m set the upper half, each sends the other half to its partner lane ^ m and adds what it receives.  After the
+// six steps value q's total sits in element 0 of ONE lane (returned index; -1: the lane holds none).  For the 27 sums of
+// the camera-major passes: 29 kept values x (two selects, one exchange, one add) against 27 x 6 DPP steps of three
+// instructions -- the reduction was a quarter of the vector instructions of k_cam_blocks (a wave there reduces 27 values
+// after four observations per lane).  Fixed order: bitwise reproducible.
+template <int N, int M>
+__device__ __forceinline__ void wave_fold_step(double* a, int lane, int& idx, int& nreal) {
+    constexpr int H = (N + 1) / 2;
+    const bool up = (lane & M) != 0;
+#pragma unroll
+    for (int i = 0; i < H; ++i) {
+        const double lo = a[i], hi = (i + H < N) ? a[i + H] : 0.0;
+        const double keep = up ? hi : lo, send = up ? lo : hi;
+        a[i] = keep + __shfl_xor(send, M);
+    }
+    if (up) { idx += H; nreal -= H; } else { nreal = nreal < H ? nreal : H; }
+    if constexpr (M > 1) wave_fold_step<H, M / 2>(a, lane, idx, nreal);
+}
+template <int NV>
+__device__ __forceinline__ int wave_fold_sum(double (&a)[NV], int lane) {
+    int idx = 0, nreal = NV;
+    wave_fold_step<NV, 32>(a, lane, idx, nreal);
+    return nreal >= 1 ? idx : -1;
+}
+
 // sums of one workgroup: NV values per lane -> out[col] (thread col < NV holds the total afterwards)
 template <int NV, int NW = kCamWaves>
 __device__ __forceinline__ double cam_block_total(double (&a)[NV], double (*red)[NV]) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-#pragma unroll
-    for (int q = 0; q < NV; ++q) a[q] = wave_sum(a[q]);
-    if (lane == 0) {
-#pragma unroll
-        for (int q = 0; q < NV; ++q) red[w][q] = a[q];
-    }
+    const int q = wave_fold_sum<NV>(a, lane);
+    if (q >= 0) red[w][q] = a[0];
     __syncthreads();
     double s = 0.0;
     if ((int)threadIdx.x < NV) {
@@ -2829,8 +2852,9 @@ __global__ __launch_bounds__(256) void k_cam_combine_w(const double* __restrict_
 // out[6..26] = sum_i W_i Vinv_p W_i^T  (packed upper triangle), W_i = Jc_i^T Jp_i.  Every W_i is formed anyway for the
 // first sum; the second costs one more gathered row per observation (Vinv_p, 48 bytes) and no pass of its own.
 // Output plane-major [27][C] (acc | sd: one contiguous vector for the all-reduce) or partial[chunk][27].
-// 192-thread workgroups: the kernel needs ~150 VGPRs (three waves per SIMD), and four 3-wave workgroups per CU keep
-// 1024 camera workgroups resident at once where three 4-wave ones would take a 1000-camera problem in two rounds.
+// 192-thread workgroups: the kernel needs ~150 VGPRs (three waves per SIMD; the record of the next trip is in flight
+// while the current one is worked on), and four 3-wave workgroups per CU keep 1024 camera workgroups resident at once
+// where three 4-wave ones would take a 1000-camera problem in two rounds.
 #ifndef SFMBA_RHS_THREADS
 #define SFMBA_RHS_THREADS 192
 #endif
@@ -2856,31 +2880,35 @@ __global__ __launch_bounds__(kRhsThreads) void k_cam_rhs_diag(CamMajor cm, const
     double a[27];
 #pragma unroll
     for (int q = 0; q < 27; ++q) a[q] = 0.0;
-    constexpr int kU = 1;                          // 27 sums + a 6x3 block pair per observation: no room to unroll
-    for (int k0 = ch.y + (int)threadIdx.x; k0 < ch.z; k0 += kRhsThreads * kU) {
-        int p[kU];
-        double X[kU][3], e[kU][3], vi[kU][6];
-#pragma unroll
-        for (int u = 0; u < kU; ++u) {
-            const int k = k0 + u * kRhsThreads;
-            p[u] = k < ch.z ? cm.pt[k] : -1;
-        }
-#pragma unroll
-        for (int u = 0; u < kU; ++u) {
-            const size_t pp = (size_t)(p[u] < 0 ? 0 : p[u]);
-            // one 128-byte record per observation (kRhsRec) when k_prep has written them, else the two gathers
-            const double2* __restrict__ rp = reinterpret_cast<const double2*>(rhsrec != nullptr ? rhsrec + kRhsRec * pp : rec + kRec * pp);
-            const double2* __restrict__ vp = rhsrec != nullptr ? rp + 4 : reinterpret_cast<const double2*>(Vinv + kVinvRow * pp);
-            const double2 r0 = rp[0], r1 = rp[1], r2 = rp[2], v0 = vp[0], v1 = vp[1], v2 = vp[2];
-            X[u][0] = r0.x; X[u][1] = r0.y; X[u][2] = r1.x;
-            e[u][0] = r1.y; e[u][1] = r2.x; e[u][2] = r2.y;
-            vi[u][0] = v0.x; vi[u][1] = v0.y; vi[u][2] = v1.x; vi[u][3] = v1.y; vi[u][4] = v2.x; vi[u][5] = v2.y;
-        }
-#pragma unroll
-        for (int u = 0; u < kU; ++u) {
-            if (p[u] < 0) continue;
+    // One observation per lane and trip (27 sums + two rows of a 6x3 block pair in registers: no room to unroll), software
+    // pipelined: the 1000 camera workgroups of a launch start together and walk in lockstep, so a trip whose index load,
+    // record gather and arithmetic follow each other costs the two latencies SIX times per launch (a camera's ~1000
+    // observations / 192 lanes) with nothing to hide them behind -- 33 us at cfg4, of which 13 are arithmetic.  Here the
+    // index is fetched two trips ahead and the record (120 of its 128 bytes: X | e | Vinv) one trip ahead, i.e. requested
+    // before the current trip's ~250 instructions issue.  Same observations per lane in the same order: same bits.
+    auto gather = [&](int pidx, double* Xo, double* eo, double* vo) {
+        const size_t pp = (size_t)(pidx < 0 ? 0 : pidx);
+        // one 128-byte record per observation (kRhsRec) when k_prep has written them, else the two gathers
+        const double2* __restrict__ rp = reinterpret_cast<const double2*>(rhsrec != nullptr ? rhsrec + kRhsRec * pp : rec + kRec * pp);
+        const double2* __restrict__ vp = rhsrec != nullptr ? rp + 4 : reinterpret_cast<const double2*>(Vinv + kVinvRow * pp);
+        const double2 r0 = rp[0], r1 = rp[1], r2 = rp[2], v0 = vp[0], v1 = vp[1], v2 = vp[2];
+        Xo[0] = r0.x; Xo[1] = r0.y; Xo[2] = r1.x;
+        eo[0] = r1.y; eo[1] = r2.x; eo[2] = r2.y;
+        vo[0] = v0.x; vo[1] = v0.y; vo[2] = v1.x; vo[3] = v1.y; vo[4] = v2.x; vo[5] = v2.y;
+    };
+    const int k_first = ch.y + (int)threadIdx.x;
+    int p_cur = k_first < ch.z ? cm.pt[k_first] : -1;
+    int p_nxt = k_first + kRhsThreads < ch.z ? cm.pt[k_first + kRhsThreads] : -1;
+    double X[3], e[3], vi[6];
+    gather(p_cur, X, e, vi);
+    for (int k0 = ch.y; k0 < ch.z; k0 += kRhsThreads) {            // (workgroup-uniform trip count)
+        const int k2 = k0 + (int)threadIdx.x + 2 * kRhsThreads;
+        const int p_n2 = k2 < ch.z ? cm.pt[k2] : -1;
+        double Xn[3], en[3], vn[6];
+        gather(p_nxt, Xn, en, vn);
+        if (p_cur >= 0) {
             double jc[12], jp[6], rx, ry;
-            observe<true>(t, X[u][0], X[u][1], X[u][2], 0.0, 0.0, K, rx, ry, jc, jp);
+            observe<true>(t, X[0], X[1], X[2], 0.0, 0.0, K, rx, ry, jc, jp);
             if (ROUND) {                           // as stored in fp32 (see k_cam_schur)
 #pragma unroll
                 for (int q = 0; q < 3; ++q) { jc[q] = (double)(float)jc[q]; jc[6 + q] = (double)(float)jc[6 + q]; }
@@ -2893,14 +2921,14 @@ __global__ __launch_bounds__(kRhsThreads) void k_cam_rhs_diag(CamMajor cm, const
             //     -W e          = -Jc^T (Jp e)
             //     W Vinv W^T    = Jc^T G Jc,   G = Jp Vinv Jp^T  (2 x 2, symmetric)
             // 111 multiply-adds per observation instead of 171, and no 6 x 3 temporaries in registers
-            const double s0 = jp[0] * e[u][0] + jp[1] * e[u][1] + jp[2] * e[u][2];
-            const double s1 = jp[3] * e[u][0] + jp[4] * e[u][1] + jp[5] * e[u][2];
-            const double h00 = vi[u][0] * jp[0] + vi[u][1] * jp[1] + vi[u][2] * jp[2];      // Vinv jp_0 (Vinv packed upper)
-            const double h01 = vi[u][1] * jp[0] + vi[u][3] * jp[1] + vi[u][4] * jp[2];
-            const double h02 = vi[u][2] * jp[0] + vi[u][4] * jp[1] + vi[u][5] * jp[2];
-            const double h10 = vi[u][0] * jp[3] + vi[u][1] * jp[4] + vi[u][2] * jp[5];      // Vinv jp_1
-            const double h11 = vi[u][1] * jp[3] + vi[u][3] * jp[4] + vi[u][4] * jp[5];
-            const double h12 = vi[u][2] * jp[3] + vi[u][4] * jp[4] + vi[u][5] * jp[5];
+            const double s0 = jp[0] * e[0] + jp[1] * e[1] + jp[2] * e[2];
+            const double s1 = jp[3] * e[0] + jp[4] * e[1] + jp[5] * e[2];
+            const double h00 = vi[0] * jp[0] + vi[1] * jp[1] + vi[2] * jp[2];      // Vinv jp_0 (Vinv packed upper)
+            const double h01 = vi[1] * jp[0] + vi[3] * jp[1] + vi[4] * jp[2];
+            const double h02 = vi[2] * jp[0] + vi[4] * jp[1] + vi[5] * jp[2];
+            const double h10 = vi[0] * jp[3] + vi[1] * jp[4] + vi[2] * jp[5];      // Vinv jp_1
+            const double h11 = vi[1] * jp[3] + vi[3] * jp[4] + vi[4] * jp[5];
+            const double h12 = vi[2] * jp[3] + vi[4] * jp[4] + vi[5] * jp[5];
             const double g00 = jp[0] * h00 + jp[1] * h01 + jp[2] * h02;
             const double g01 = jp[0] * h10 + jp[1] * h11 + jp[2] * h12;
             const double g11 = jp[3] * h10 + jp[4] * h11 + jp[5] * h12;
@@ -2917,6 +2945,11 @@ __global__ __launch_bounds__(kRhsThreads) void k_cam_rhs_diag(CamMajor cm, const
 #pragma unroll
                 for (int j = i; j < 6; ++j) a[n++] += jc[i] * m0[j] + jc[6 + i] * m1[j];
         }
+        p_cur = p_nxt; p_nxt = p_n2;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { X[q] = Xn[q]; e[q] = en[q]; }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) vi[q] = vn[q];
     }
     double s = cam_block_total<27, kRhsThreads / 64>(a, red);
     if (threadIdx.x < 27) {
