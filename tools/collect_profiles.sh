@@ -8,7 +8,7 @@ for f in bench_line.json bench_under_rocprof.json bench_kernel_stats.md traffic.
          shard8_cfg4_local.json shard8_cfg4_sharded.json shard8_cfg4_sharded_kernel_stats.md shard8_cfg4_sharded_under_rocprof.json \
          shard8_cfg5_local.json shard8_cfg5_sharded.json shard8_cfg5_sharded_kernel_stats.md shard8_cfg5_sharded_under_rocprof.json \
          shard.log time_kernels.txt solve_loop.txt ab_mixed.txt ab_shard_inline.txt ab_jfree.txt bench_2rank_one_device.json \
-         call_overhead.txt fuzz.txt; do
+         call_overhead.txt fuzz.txt timeline.txt cam_counters_cfg4.json ab_skip_last.txt; do
   cp gpurun_out/${TAG}_$f profiles/${TAG}_$f
 done
 cp gpurun_out/${TAG}j_jfree0_kernel_stats.md profiles/${TAG}_jfree0_kernel_stats.md

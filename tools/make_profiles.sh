@@ -56,6 +56,12 @@ bash tools/ab_shard.sh $TAG pcg_inline > $OUT/${TAG}_ab_shard_inline.txt 2>&1
 bash tools/ab_option.sh cfg4 64 jfree 20 > $OUT/${TAG}_ab_jfree.txt 2>&1
 bash tools/ab_trace.sh ${TAG}j cfg4 64 jfree 12 >> $OUT/${TAG}_ab_jfree.txt 2>&1
 timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29544 bench.py --gpus 2 --one-device --dist-backend gloo --exchange torch --steps 20 --warmup 5 --no-cpu-baseline 2> $OUT/${TAG}_bench_2rank_one_device.err | tail -1 > $OUT/${TAG}_bench_2rank_one_device.json
+# round 4, late: the launch-by-launch timeline of one solve, memory-side counters of the camera-major passes, and the A/B
+# of the launch pair a speculative PCG batch no longer enqueues
+bash tools/timeline.sh $TAG cfg4 > /dev/null 2>&1
+bash tools/cam_counters.sh $TAG cfg4 > /dev/null 2>&1
+cd $R
+bash tools/ab_option.sh cfg4 64 pcg_skip_last 20 > $OUT/${TAG}_ab_skip_last.txt 2>&1
 python3 tools/call_overhead.py > $OUT/${TAG}_call_overhead.txt 2>&1
 python3 tools/call_overhead.py cfg2 >> $OUT/${TAG}_call_overhead.txt 2>&1
 python3 tools/fuzz_parity.py 300 0 > $OUT/${TAG}_fuzz.txt 2>&1
