@@ -1338,7 +1338,9 @@ int pcg_enqueue(sfmba_handle* h, int count, bool speculative = false) {
     for (int k = 0; k < count; ++k) {
         const int L = h->pcg_L;
         if (h->pcg_fused) {
-            const bool last = speculative && k == count - 1 && !multi_rank(h) && h->dbg.pcg_skip_last != 0;
+            // (several ranks: only where the product's exchange sits inside pass B -- every rank then takes the same
+            // decision from the same record, and a launch that is not enqueued exchanges nothing on any of them)
+            const bool last = speculative && k == count - 1 && (!multi_rank(h) || h->pcg_inline) && h->dbg.pcg_skip_last != 0;
             // ... and in the local form with the step vector in k_backsub's LDS not even that pass A: k_backsub's prologue
             // does its update (FinalUpdate)
             if (last && L > 0 && h->pcg_local && h->lds_vec && !h->jfree && h->dbg.pcg_skip_last != 2) {

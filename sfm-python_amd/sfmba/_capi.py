@@ -47,6 +47,35 @@ PRINT_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p)
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  libsfmba.so needs `libamdhip64.so.7`; a PyTorch-ROCm wheel ships its own copy of that
+    library (and of the HSA runtime) under torch/lib and loads it by path.  Whichever is loaded first wins the SONAME, and
+    when the system's copy came first, `torch.cuda` later finds "No HIP GPUs" in this process (seen on this image: ROCm 7.2
+    under /opt/rocm, 7.0 inside the wheel).  The package works with torch at its side (streams handed over by
+    `set_stream`, `sfmba.dist`), so when torch is INSTALLED -- imported or not -- its copy is loaded first, and
+    libsfmba.so binds to it exactly as it does when `import torch` came first.  SFMBA_HIP_RUNTIME=system skips this."""
+    if os.environ.get("SFMBA_HIP_RUNTIME", "") == "system":
+        return
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return                                             # torch's libraries are in the process already
+    try:
+        spec = importlib.util.find_spec("torch")           # (locates the package without importing it)
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def load():
     """Load libsfmba.so (raises if it has not been built: there is no fallback path)."""
     global _lib
@@ -56,6 +85,7 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} not found: build the HIP back end first (python __graft_entry__.py, or "
             "make -C sfm-python_amd).  sfmba has no CPU fallback.")
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(LIB_PATH)
     P = C.c_void_p
     lib.sfmba_create.argtypes = [C.POINTER(P), C.c_int]

@@ -38,6 +38,31 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_capi.Result) == 128
 
 
+def test_one_hip_runtime_per_process_when_torch_is_installed():
+    """libsfmba.so and a PyTorch-ROCm wheel both want `libamdhip64.so.7`; the wheel ships its own copy.  Loaded in the
+    wrong order (the system's copy first), `torch.cuda` later finds no GPU in the process.  `_capi.load()` therefore loads
+    torch's copy first when torch is installed -- here: a fresh interpreter that never imports torch ends up with exactly
+    one libamdhip64 mapped, the wheel's; SFMBA_HIP_RUNTIME=system keeps the system's."""
+    import importlib.util
+    import subprocess
+    import sys
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not os.path.exists(os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")):
+        pytest.skip("no PyTorch-ROCm wheel with its own HIP runtime in this environment")
+    code = ("import sys; sys.path[:0] = [%r]; from sfmba import _capi; _capi.load(); "
+            "print(sorted({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l})); "
+            "print('torch' in sys.modules)") % os.path.join(ROOT, "sfm-python_amd")
+    for env_extra, want_torch_copy in (({}, True), ({"SFMBA_HIP_RUNTIME": "system"}, False)):
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120,
+                             env={**os.environ, **env_extra})
+        assert out.returncode == 0, out.stderr
+        libs, torch_imported = out.stdout.strip().splitlines()[-2:]
+        libs = eval(libs)
+        assert torch_imported == "False"                       # located, not imported
+        assert len(libs) == 1, libs
+        assert (os.sep + "torch" + os.sep in libs[0]) == want_torch_copy, libs
+
+
 def test_product_path_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():
