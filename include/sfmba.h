@@ -260,6 +260,8 @@ int  sfmba_tr2d_solve(const double* B3, const double* g2, double Delta, double* 
  *                       of their own (default: exchanged by the producing workgroups; ranks that SHARE one device --
  *                       rehearsals -- get 0 by themselves once their camera workgroups together exceed the device's
  *                       resident slots: settled at sfmba_p2p_attach)
+ *   "xcd_cam"        P  0: K3 and the rhs + preconditioner pass keep one workgroup per camera where pass B takes the
+ *                       XCD-aware chunk table ("xcd_chunks"; default from 250k points on: all three one wave per chunk)
  *   "pcg_skip_last"     0: the launches that a replayed record says find the PCG solve finished are enqueued all the
  *                       same; 2: only the pass B is left out (default: neither the last pass A -- k_backsub's prologue
  *                       does its update -- nor the pass B behind it is enqueued; both are owed if the record turns out

@@ -777,6 +777,7 @@ struct CamMajor {
 constexpr int kCamThreads = 256;
 constexpr int kCamWaves = kCamThreads / 64;
 constexpr int kCamUnroll = 4;
+constexpr int kWaveChunkCams = 4, kWaveChunkRanges = 8;      // the XCD-aware chunk table (k_cam_schur_w, k_cam_blocks_w, k_cam_rhs_diag_w)
 
 // NV sums over the 64 lanes of a wave at the price of ~NV + 6 exchanges instead of 6 NV: a butterfly that HALVES the
 // values a lane carries at every step -- at mask m the lanes with bit m clear keep the lower half of their values, those
@@ -955,6 +956,77 @@ __global__ __launch_bounds__(kCamThreads) void k_cam_blocks(CamMajor cm, const d
         if (ch.w == 1) Ugc[(size_t)ch.x * 27 + threadIdx.x] = s;
         else partial[(size_t)bid * 27 + threadIdx.x] = s;
     }
+}
+
+// K3 over the XCD-aware chunk table (many points; see k_cam_schur_w): ONE WAVE PER CHUNK.  Workgroup 8 g + k runs on
+// XCD k and its four waves take range k of cameras 4 g .. 4 g + 3, so each L2 serves an eighth of the point records; a
+// wave walks its ~250 observations two per lane and trip and reduces its 27 sums with wave_fold_sum alone (no LDS, no
+// barrier).  Row q of `partial` = the 27 sums of chunk q (zeros for an empty one); k_cam_combine_w<27> adds a camera's
+// eight rows in range order.  (Round 3 measured the cut as a LOSS for this pass -- 208 -> 320 us at cfg5 -- when a chunk
+// was a 256-thread workgroup with its block reduction and every wave paid 27 x 6 DPP steps; the halving butterfly
+// and one wave per chunk turn it round.)  Riders as in k_cam_blocks.
+template <bool F32>
+__global__ __launch_bounds__(kCamThreads) void k_cam_blocks_w(CamMajor cm, const double* __restrict__ camtab,
+                                                              const double* __restrict__ rec, KMat K,
+                                                              double* __restrict__ partial,
+                                                              const double* __restrict__ skip, int n_wgs,
+                                                              const int* __restrict__ pt_idx, int N, PointBlocksOut pb,
+                                                              Piggyback fin, Mailbox mb) {
+    const int bid = (int)blockIdx.x - (fin.part != nullptr ? 1 : 0);        // (the FIRST workgroup: dispatched at once)
+    if (bid < 0) {
+        if (!(skip != nullptr && *skip != 0.0)) { finish_in_block(fin); __syncthreads(); }
+        if (mb.host != nullptr && threadIdx.x < 64) post_mailbox(mb);      // (also when the trial was cancelled)
+        return;
+    }
+    if (skip != nullptr && *skip != 0.0) return;   // speculative launch cancelled by k_tr_step
+    if (bid >= n_wgs) {                            // riders: the point rows K1's tiles cut (see k_resjac)
+        point_edge_fixup((bid - n_wgs) * kCamThreads + (int)threadIdx.x, pt_idx, N, pb);
+        return;
+    }
+    const int lane = threadIdx.x & 63;
+    const int q = __builtin_amdgcn_readfirstlane(bid * kWaveChunkCams + ((int)threadIdx.x >> 6));   // wave-uniform
+    const int4 ch = cm.chunks[q];
+    if (ch.x < 0) return;                                       // padding behind the last camera
+    double t[kCamTab];
+#pragma unroll
+    for (int k = 0; k < kCamTab; ++k) t[k] = camtab[(size_t)ch.x * kCamRow + k];      // wave-uniform: scalar loads
+    double a[27];
+#pragma unroll
+    for (int n = 0; n < 27; ++n) a[n] = 0.0;
+    constexpr int kU = 2;
+    for (int k0 = ch.y + lane; k0 < ch.z; k0 += 64 * kU) {
+        int p[kU];
+        double2 uv[kU];
+        double X[kU][3];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int k = k0 + u * 64;
+            p[u] = -1;
+            uv[u] = make_double2(0.0, 0.0);
+            if (k < ch.z) { p[u] = cm.pt[k]; uv[u] = load_pair(cm.uv, F32, k); }
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const double2* __restrict__ rp = reinterpret_cast<const double2*>(rec + (size_t)kRec * (p[u] < 0 ? 0 : p[u]));
+            const double2 xy = rp[0], zz = rp[1];
+            X[u][0] = xy.x; X[u][1] = xy.y; X[u][2] = zz.x;
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            if (p[u] < 0) continue;
+            double jc[12], jp[6], rx, ry;
+            observe<true>(t, X[u][0], X[u][1], X[u][2], uv[u].x, uv[u].y, K, rx, ry, jc, jp);
+            int n = 0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = i; j < 6; ++j) a[n++] += jc[i] * jc[j] + jc[6 + i] * jc[6 + j];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) a[21 + i] += jc[i] * rx + jc[6 + i] * ry;
+        }
+    }
+    const int col = wave_fold_sum<27>(a, lane);
+    if (col >= 0) partial[(size_t)q * 27 + col] = a[0];
 }
 
 // out[c * cs + col * ks] = sum of the chunk rows of camera c, in chunk order, for the cameras that have more
@@ -2729,7 +2801,6 @@ __global__ __launch_bounds__(kCamThreads) void k_cam_schur(CamMajor cm, const do
 // which runs on XCD k), each wave walks its chunk with four gathers per lane in flight and reduces with DPP / readlane
 // alone; no LDS, no barrier.  Row q = (8 g + k) 4 + j of `partial` holds the sums of camera 4 g + j over range k;
 // k_cam_combine_w adds a camera's eight rows in range order.
-constexpr int kWaveChunkCams = 4, kWaveChunkRanges = 8;
 template <bool MIXED>
 __global__ __launch_bounds__(kCamThreads) void k_cam_schur_w(CamMajor cm, const double* __restrict__ camtab,
                                                              const double* __restrict__ rec, KMat K,
@@ -2832,19 +2903,23 @@ __global__ __launch_bounds__(kCamThreads) void k_cam_schur_w(CamMajor cm, const 
         partial[(size_t)q * 6 + lane] = out;
     }
 }
-// acc[k][c] = sum over the eight ranges of camera c's rows of k_cam_schur_w, in range order
-__global__ __launch_bounds__(256) void k_cam_combine_w(const double* __restrict__ partial, int C, double* __restrict__ acc,
-                                                       const int* __restrict__ done) {
+// out[c * cs + col * ks] = sum over the eight ranges of camera c's rows (NC values each) of a wave-per-chunk pass, in
+// range order (pass B: NC = 6, acc plane-major; K3: 27, [U | g_c] camera-major; rhs pass: 27, acc | sd plane-major)
+template <int NC>
+__global__ __launch_bounds__(256) void k_cam_combine_w(const double* __restrict__ partial, int C, double* __restrict__ out,
+                                                       int cs, int ks, const int* __restrict__ done,
+                                                       const double* __restrict__ skip) {
     if (done != nullptr && *done != 0) return;
+    if (skip != nullptr && *skip != 0.0) return;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= C * 6) return;
-    const int c = e / 6, col = e - c * 6;
+    if (e >= C * NC) return;
+    const int c = e / NC, col = e - c * NC;
     const int g = c / kWaveChunkCams, j = c - g * kWaveChunkCams;
     double s = 0.0;
 #pragma unroll
     for (int k = 0; k < kWaveChunkRanges; ++k)
-        s += partial[(size_t)((g * kWaveChunkRanges + k) * kWaveChunkCams + j) * 6 + col];
-    acc[(size_t)col * C + c] = s;
+        s += partial[(size_t)((g * kWaveChunkRanges + k) * kWaveChunkCams + j) * NC + col];
+    out[(size_t)c * cs + (size_t)col * ks] = s;
 }
 
 // Reduced right-hand side WITH the diagonal blocks of W Vinv W^T (Schur-diagonal preconditioner): one camera-major
@@ -2979,6 +3054,89 @@ __global__ __launch_bounds__(kRhsThreads) void k_cam_rhs_diag(CamMajor cm, const
             for (int q = 0; q < 21; ++q) mp.Minv[(size_t)q * C + ch.x] = inv[q];
         }
     }
+}
+
+// The rhs + preconditioner pass over the XCD-aware chunk table, one wave per chunk (see k_cam_blocks_w): row q of
+// `partial` = the chunk's 27 sums (6 of -W e, 21 of W Vinv W^T); k_cam_combine_w<27> adds the eight rows of a camera into
+// acc | sd and k_cam_prep_schur inverts the preconditioner blocks.
+template <bool ROUND>
+__global__ __launch_bounds__(kCamThreads) void k_cam_rhs_diag_w(CamMajor cm, const double* __restrict__ camtab,
+                                                                const double* __restrict__ rec,
+                                                                const double* __restrict__ Vinv, KMat K,
+                                                                double* __restrict__ partial,
+                                                                const double* __restrict__ rhsrec) {
+    const int lane = threadIdx.x & 63;
+    const int q = __builtin_amdgcn_readfirstlane((int)blockIdx.x * kWaveChunkCams + ((int)threadIdx.x >> 6));   // wave-uniform
+    const int4 ch = cm.chunks[q];
+    if (ch.x < 0) return;                                       // padding behind the last camera
+    double t[kCamTab];
+#pragma unroll
+    for (int k = 0; k < kCamTab; ++k) t[k] = camtab[(size_t)ch.x * kCamRow + k];      // wave-uniform: scalar loads
+    double a[27];
+#pragma unroll
+    for (int n = 0; n < 27; ++n) a[n] = 0.0;
+    auto gather = [&](int pidx, double* Xo, double* eo, double* vo) {
+        const size_t pp = (size_t)(pidx < 0 ? 0 : pidx);
+        const double2* __restrict__ rp = reinterpret_cast<const double2*>(rhsrec != nullptr ? rhsrec + kRhsRec * pp : rec + kRec * pp);
+        const double2* __restrict__ vp = rhsrec != nullptr ? rp + 4 : reinterpret_cast<const double2*>(Vinv + kVinvRow * pp);
+        const double2 r0 = rp[0], r1 = rp[1], r2 = rp[2], v0 = vp[0], v1 = vp[1], v2 = vp[2];
+        Xo[0] = r0.x; Xo[1] = r0.y; Xo[2] = r1.x;
+        eo[0] = r1.y; eo[1] = r2.x; eo[2] = r2.y;
+        vo[0] = v0.x; vo[1] = v0.y; vo[2] = v1.x; vo[3] = v1.y; vo[4] = v2.x; vo[5] = v2.y;
+    };
+    const int k_first = ch.y + lane;
+    int p_cur = k_first < ch.z ? cm.pt[k_first] : -1;
+    int p_nxt = k_first + 64 < ch.z ? cm.pt[k_first + 64] : -1;
+    double X[3], e[3], vi[6];
+    gather(p_cur, X, e, vi);
+    for (int k0 = ch.y; k0 < ch.z; k0 += 64) {                     // (wave-uniform trip count; software pipelined as k_cam_rhs_diag)
+        const int k2 = k0 + lane + 128;
+        const int p_n2 = k2 < ch.z ? cm.pt[k2] : -1;
+        double Xn[3], en[3], vn[6];
+        gather(p_nxt, Xn, en, vn);
+        if (p_cur >= 0) {
+            double jc[12], jp[6], rx, ry;
+            observe<true>(t, X[0], X[1], X[2], 0.0, 0.0, K, rx, ry, jc, jp);
+            if (ROUND) {                           // as stored in fp32 (see k_cam_schur)
+#pragma unroll
+                for (int n = 0; n < 3; ++n) { jc[n] = (double)(float)jc[n]; jc[6 + n] = (double)(float)jc[6 + n]; }
+#pragma unroll
+                for (int n = 0; n < 6; ++n) jp[n] = (double)(float)jp[n];
+#pragma unroll
+                for (int n = 0; n < 3; ++n) { jc[3 + n] = -jp[n]; jc[9 + n] = -jp[3 + n]; }
+            }
+            const double s0 = jp[0] * e[0] + jp[1] * e[1] + jp[2] * e[2];
+            const double s1 = jp[3] * e[0] + jp[4] * e[1] + jp[5] * e[2];
+            const double h00 = vi[0] * jp[0] + vi[1] * jp[1] + vi[2] * jp[2];      // Vinv jp_0 (Vinv packed upper)
+            const double h01 = vi[1] * jp[0] + vi[3] * jp[1] + vi[4] * jp[2];
+            const double h02 = vi[2] * jp[0] + vi[4] * jp[1] + vi[5] * jp[2];
+            const double h10 = vi[0] * jp[3] + vi[1] * jp[4] + vi[2] * jp[5];      // Vinv jp_1
+            const double h11 = vi[1] * jp[3] + vi[3] * jp[4] + vi[4] * jp[5];
+            const double h12 = vi[2] * jp[3] + vi[4] * jp[4] + vi[5] * jp[5];
+            const double g00 = jp[0] * h00 + jp[1] * h01 + jp[2] * h02;
+            const double g01 = jp[0] * h10 + jp[1] * h11 + jp[2] * h12;
+            const double g11 = jp[3] * h10 + jp[4] * h11 + jp[5] * h12;
+            double m0[6], m1[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                a[i] -= jc[i] * s0 + jc[6 + i] * s1;
+                m0[i] = g00 * jc[i] + g01 * jc[6 + i];
+                m1[i] = g01 * jc[i] + g11 * jc[6 + i];
+            }
+            int n = 6;
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = i; j < 6; ++j) a[n++] += jc[i] * m0[j] + jc[6 + i] * m1[j];
+        }
+        p_cur = p_nxt; p_nxt = p_n2;
+#pragma unroll
+        for (int n = 0; n < 3; ++n) { X[n] = Xn[n]; e[n] = en[n]; }
+#pragma unroll
+        for (int n = 0; n < 6; ++n) vi[n] = vn[n];
+    }
+    const int col = wave_fold_sum<27>(a, lane);
+    if (col >= 0) partial[(size_t)q * 27 + col] = a[0];
 }
 
 // ---------------------------------------------------------------------------------------------

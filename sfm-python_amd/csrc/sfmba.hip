@@ -256,6 +256,7 @@ struct sfmba_handle {
                                              // k_backsub recompute its blocks from the LDS camera table
         int cm_device = -1;                  // 0: the camera-major order is sorted on the host and its permutation uploaded
         int pcg_inline = -1;                 // 0: sharded solves keep the collective of the product as a launch of its own
+        int xcd_cam = -1;                    // 0: K3 and the rhs pass keep the one-chunk-per-camera table where pass B takes the XCD-aware one
         int pcg_skip_last = -1;              // 0: the pass B behind the launch the record says is the last one is enqueued all the same
         int pcg_mixed_b = -1;                // 0: pass B keeps fp64 point records although pass A runs on fp32 operands
         int pcg_mixed = -1;                  // 1 / 0: fp32 operands in the implicit Schur product whatever the storage mode
@@ -471,7 +472,9 @@ bool p2p_inline_ok(const sfmba_handle* h) {
     const auto& p = h->p2p;
     return p.ready && !p.any_multi && !(p.shared_device > 1 && h->C * p.shared_device > kSharedDeviceCams);
 }
-bool cam_inline(const sfmba_handle* h) { return p2p_inline_ok(h) && !h->cam_multi && h->dbg.pcg_inline != 0; }
+// K3 and the rhs pass over the XCD-aware chunk table, one wave per chunk (k_cam_blocks_w, k_cam_rhs_diag_w)
+bool xcd_cam(const sfmba_handle* h) { return h->xcd_b && h->dbg.xcd_cam != 0; }
+bool cam_inline(const sfmba_handle* h) { return p2p_inline_ok(h) && !h->cam_multi && !xcd_cam(h) && h->dbg.pcg_inline != 0; }
 
 CamExchange cam_exchange(sfmba_handle* h) {
     CamExchange cx{};
@@ -773,6 +776,19 @@ int launch_normal_blocks_v(sfmba_handle* h, const double* x, const double* tab, 
         fin.job.row0[0] = 0; fin.job.nrows[0] = cost_parts;
         for (int k = 0; k < kFinishCols; ++k) { fin.job.slot[0][k] = k; fin.job.slot[1][k] = -1; }
     }
+    if (xcd_cam(h)) {                                           // many points: one wave per chunk of the XCD-aware table
+        const CamMajor cmb{h->cam_chunks_b.as<int4>(), h->cm_pt.as<int>(), h->cm_uv.as<double>()};
+        const int wgrid = h->n_chunks_b / kWaveChunkCams;
+        hipLaunchKernelGGL((k_cam_blocks_w<F32>), dim3(wgrid + riders + (cost_parts > 0 ? 1 : 0)), dim3(kCamThreads), 0, h->stream,
+                           cmb, tab, rec, h->K, h->cam_partial.as<double>(), h->skip, wgrid,
+                           (const int*)h->pt_idx.as<int>(), (int)h->N, point_blocks_out(h), fin, mb);
+        LAUNCHED(h);
+        hipLaunchKernelGGL(k_cam_combine_w<27>, dim3((unsigned)((27 * h->C + 255) / 256)), dim3(256), 0, h->stream,
+                           (const double*)h->cam_partial.as<double>(), (int)h->C, h->Ugc(), 27, 1, (const int*)nullptr,
+                           (const double*)h->skip);
+        LAUNCHED(h);
+        return exchange(h, h->Ugc(), 27 * h->C, 0);
+    }
     hipLaunchKernelGGL((k_cam_blocks<F32>), dim3(h->n_chunks + riders + (cost_parts > 0 ? 1 : 0)), dim3(kCamThreads), 0, h->stream,
                        cam_major(h), tab, rec, h->K, h->Ugc(), h->cam_partial.as<double>(), h->skip, (int)h->n_chunks,
                        (const int*)h->pt_idx.as<int>(), (int)h->N, point_blocks_out(h), fin, mb, cx);
@@ -923,8 +939,9 @@ int launch_cam_schur(sfmba_handle* h, const double* vin, const PcgCtrl* ctrl_don
             hipLaunchKernelGGL((k_cam_schur_w<false>), dim3(wgrid), dim3(kCamThreads), 0, h->stream, cm, (const double*)h->tab,
                                (const double*)h->rec, h->K, vin, (int)h->C, h->cam_partial.as<double>(), ctrl_done, set, mxb);
         LAUNCHED(h);
-        hipLaunchKernelGGL(k_cam_combine_w, dim3((unsigned)((6 * h->C + 255) / 256)), dim3(256), 0, h->stream,
-                           (const double*)h->cam_partial.as<double>(), (int)h->C, h->acc(), ctrl_done ? &ctrl_done->done : (const int*)nullptr);
+        hipLaunchKernelGGL(k_cam_combine_w<6>, dim3((unsigned)((6 * h->C + 255) / 256)), dim3(256), 0, h->stream,
+                           (const double*)h->cam_partial.as<double>(), (int)h->C, h->acc(), 1, (int)h->C,
+                           ctrl_done ? &ctrl_done->done : (const int*)nullptr, (const double*)nullptr);
         LAUNCHED(h);
         return 0;
     }
@@ -965,6 +982,27 @@ int launch_rhs_and_preconditioner(sfmba_handle* h) {
     // (CamExchange): every workgroup holds its camera's complete sums and inverts its own preconditioner block (RhsPrecond)
     CamExchange cx{};
     if (cam_inline(h)) { cx = cam_exchange(h); ++h->p2p.calls; ++h->n_collectives; }
+    if (xcd_cam(h)) {
+        const CamMajor cmb{h->cam_chunks_b.as<int4>(), h->cm_pt.as<int>(), h->cm_uv.as<double>()};
+        const int wgrid = h->n_chunks_b / kWaveChunkCams;
+        const double* rr = h->use_rhsrec ? (const double*)h->rhsrec.as<double>() : (const double*)nullptr;
+        if (h->f32 && !h->sweep_rc && !h->sweep_rc_g)
+            hipLaunchKernelGGL((k_cam_rhs_diag_w<true>), dim3(wgrid), dim3(kCamThreads), 0, h->stream, cmb, (const double*)h->tab,
+                               (const double*)h->rec, (const double*)vinv_ptr(h), h->K, h->cam_partial.as<double>(), rr);
+        else
+            hipLaunchKernelGGL((k_cam_rhs_diag_w<false>), dim3(wgrid), dim3(kCamThreads), 0, h->stream, cmb, (const double*)h->tab,
+                               (const double*)h->rec, (const double*)vinv_ptr(h), h->K, h->cam_partial.as<double>(), rr);
+        LAUNCHED(h);
+        hipLaunchKernelGGL(k_cam_combine_w<27>, dim3((unsigned)((27 * C + 255) / 256)), dim3(256), 0, h->stream,
+                           (const double*)h->cam_partial.as<double>(), (int)C, h->acc(), 1, (int)C, (const int*)nullptr,
+                           (const double*)nullptr);
+        LAUNCHED(h);
+        CHK(exchange(h, h->acc(), 27 * C, 0));                  // acc | sd: one contiguous plane-major vector
+        hipLaunchKernelGGL(k_cam_prep_schur, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, h->stream, (const double*)h->Ugc(),
+                           (const double*)h->sd(), (int)C, h->Dc.as<double>(), h->Minv.as<double>());
+        LAUNCHED(h);
+        return 0;
+    }
     const bool own_inverse = !h->cam_multi && (!multi_rank(h) || cam_inline(h));
     const RhsPrecond mp = own_inverse ? RhsPrecond{h->Ugc(), h->Dc.as<double>(), h->Minv.as<double>()} : RhsPrecond{nullptr, nullptr, nullptr};
     if (h->f32 && !h->sweep_rc && !h->sweep_rc_g)
@@ -1531,6 +1569,7 @@ int sfmba_debug_option(sfmba_handle* h, const char* name, int64_t value) {
     else if (n == "pcg_mixed") h->dbg.pcg_mixed = v;
     else if (n == "pcg_inline") h->dbg.pcg_inline = v;
     else if (n == "pcg_skip_last") h->dbg.pcg_skip_last = v;
+    else if (n == "xcd_cam") h->dbg.xcd_cam = v;
     else if (n == "cm_device") h->dbg.cm_device = v;
     else if (n == "jfree") h->dbg.jfree = v;
     else if (n == "packed_upload") h->dbg.packed_upload = v;
@@ -2219,7 +2258,7 @@ static int set_problem_impl(sfmba_handle* h, int64_t C, int64_t P, int64_t N, co
     HIPCHK(h, h->cm_perm.ensure(sizeof(int) * ldz));
     HIPCHK(h, h->cm_pt.ensure(sizeof(int) * ldz));
     HIPCHK(h, h->cm_uv.ensure(esz * 2 * ldz));
-    HIPCHK(h, h->cam_partial.ensure(sizeof(double) * std::max<size_t>(27 * chunks.size(), 6 * h->host_chunks_b.size())));
+    HIPCHK(h, h->cam_partial.ensure(sizeof(double) * std::max<size_t>(27 * chunks.size(), 27 * h->host_chunks_b.size())));
     HIPCHK(h, h->recA.ensure(sizeof(double) * kRec * P));
     HIPCHK(h, h->recB.ensure(sizeof(double) * kRec * P));
     // One 128-byte gather record per point for k_cam_rhs_diag pays once the point tables no longer sit in the L2s
@@ -2556,6 +2595,7 @@ int sfmba_time_kernel(sfmba_handle* h, const double* x, int32_t which, int32_t r
             case 6: CHK(launch_cam_schur<1>(h, nullptr, nullptr, 0)); break;
             case 7: CHK((launch_resjac<true, true>(h, h->x, h->tab, &np, nullptr, nullptr, /*blocks=*/false))); break;
             case 8:    // reduced right-hand side + Schur-diagonal blocks (without the 6x6 inverses)
+                if (xcd_cam(h)) { CHK(launch_rhs_and_preconditioner(h)); break; }      // (wave-per-chunk form: with combine + inverses)
                 hipLaunchKernelGGL((k_cam_rhs_diag<false>), dim3(h->n_chunks), dim3(kRhsThreads), 0, h->stream, cam_major(h),
                                    (const double*)h->tab, (const double*)h->rec, (const double*)vinv_ptr(h), h->K, (int)h->C,
                                    h->acc(), h->cam_partial.as<double>(), RhsPrecond{nullptr, nullptr, nullptr},
