@@ -221,7 +221,7 @@ def dbg():
             touched.append((b, name))
     yield set_
     defaults = dict(pcg_fused=-1, tab_lds=-1, vec_lds=-1, cam_chunk=0, pcg_guess_bias=0, sweep_rc=-1, dense=-1, precond=-1, pcg_local=-1,
-                    pcg_split=-1, rhsrec=-1, cost_rider=-1, xcd_chunks=-1, pcg_mixed=-1, pcg_mixed_b=-1, jfree=-1)
+                    pcg_split=-1, rhsrec=-1, cost_rider=-1, xcd_chunks=-1, pcg_mixed=-1, pcg_mixed_b=-1, jfree=-1, xcd_cam=-1)
     for b, name in touched:
         b.debug_option(name, defaults[name])
 
@@ -237,12 +237,13 @@ def test_operand_placements_and_camera_chunking(be, orc, dbg):
     ref = None
     # (rhsrec: the rhs + preconditioner pass gathering one 128-byte record per observation instead of the point record
     # and the inverse block -- the form problems of >= 250k points run; tab_lds = 0: camera rows through LDS-DMA slabs)
-    # xcd_chunks: every camera's list cut at the eight point-range boundaries (one chunk per XCD; >= 250k points)
-    for tab_lds, vec_lds, chunk, rc, rr, xc in ((-1, -1, 0, -1, -1, -1), (-1, -1, 0, 0, -1, -1), (0, -1, 0, 0, 1, -1),
-                                                (-1, 0, 0, 0, -1, -1), (-1, -1, 64, -1, 1, -1), (0, 0, 50, 0, -1, -1),
-                                                (-1, -1, 0, -1, 1, 1), (0, -1, 0, -1, -1, 1)):
+    # xcd_chunks: every camera's list cut at the eight point-range boundaries (one chunk per XCD; >= 250k points) -- pass B,
+    # K3 and the rhs pass then run one wave per chunk; xcd_cam = 0: pass B alone (K3 and the rhs pass one workgroup per camera)
+    for tab_lds, vec_lds, chunk, rc, rr, xc, xk in ((-1, -1, 0, -1, -1, -1, -1), (-1, -1, 0, 0, -1, -1, -1), (0, -1, 0, 0, 1, -1, -1),
+                                                    (-1, 0, 0, 0, -1, -1, -1), (-1, -1, 64, -1, 1, -1, -1), (0, 0, 50, 0, -1, -1, -1),
+                                                    (-1, -1, 0, -1, 1, 1, -1), (0, -1, 0, -1, -1, 1, -1), (-1, -1, 0, -1, -1, 1, 0)):
         for name, v in (("tab_lds", tab_lds), ("vec_lds", vec_lds), ("cam_chunk", chunk), ("sweep_rc", rc), ("rhsrec", rr),
-                        ("xcd_chunks", xc)):
+                        ("xcd_chunks", xc), ("xcd_cam", xk)):
             dbg((be, tls), name, v)
         nb = _blocks_case(be, orc, pb)
         y = _matvec_case(be, orc, pb, nb)
