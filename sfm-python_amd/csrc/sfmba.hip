@@ -466,11 +466,18 @@ void p2p_fill_args(sfmba_handle* h, P2pArgs& a) {
 // sharded over the direct link, every camera a single chunk: per-camera sums are all-reduced by the workgroup that
 // forms them (CamExchange) instead of by a collective launch behind the kernel
 // -- on EVERY rank (the chunking is a property of the shard; ranks that disagreed would wait for each other in different
-// kernels), and not when ranks that share one GPU would fill it with waiting workgroups (p2p_inline_ok).
-constexpr int64_t kSharedDeviceCams = 1024;        // 256 CUs x 4 resident pass-B workgroups
+// kernels), and practically never between ranks that SHARE one GPU (p2p_inline_ok).  With a GPU per rank a waiting
+// workgroup costs its own device a slot and nothing else.  On a shared device the ranks compete for the CUs: a camera
+// workgroup that waits for its peer holds registers on its CU, and the peer -- if it is one kernel behind, which two
+// processes drift apart by easily -- first has to run pass A, whose 1024-thread workgroups need the whole register file of
+// a CU.  Three hundred waiting workgroups sit on every CU of the card, pass A of the other rank then never starts, and
+// both time out (seen at 2 x 300 and 2 x 1000 cameras, one run in four; the collective LAUNCHES never had the problem:
+// they are one or a few workgroups).  So rehearsals on one device take the exchange inside the kernels only while the
+// waiting workgroups of all other ranks leave half the CUs alone -- small tests -- and the collective launches otherwise.
+constexpr int64_t kSharedDeviceCams = 128;         // (ranks - 1) x cameras: at most half of the 256 CUs hold a waiting workgroup
 bool p2p_inline_ok(const sfmba_handle* h) {
     const auto& p = h->p2p;
-    return p.ready && !p.any_multi && !(p.shared_device > 1 && h->C * p.shared_device > kSharedDeviceCams);
+    return p.ready && !p.any_multi && !(p.shared_device > 1 && h->C * (p.shared_device - 1) > kSharedDeviceCams);
 }
 // K3 and the rhs pass over the XCD-aware chunk table, one wave per chunk (k_cam_blocks_w, k_cam_rhs_diag_w)
 bool xcd_cam(const sfmba_handle* h) { return h->xcd_b && h->dbg.xcd_cam != 0; }

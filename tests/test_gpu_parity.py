@@ -849,7 +849,9 @@ def _two_rank_body(rank, world, q, direct, dims, debug, torch, td, sfmba, sdist)
         link = sdist.DirectLink(be) if direct else None                   # peers mapped through hipIpc
         opt = be.default_options()
         opt.ftol = 1e-10
+        n0 = be.counters()[0]
         x, res, fun, grad = be.solve(loc.x0, opt)
+        launches = be.counters()[0] - n0
         torch.cuda.synchronize()
         x2 = be.solve(loc.x0, opt)[0] if direct else x                    # staging buffers are reusable
     td.barrier()
@@ -865,7 +867,7 @@ def _two_rank_body(rank, world, q, direct, dims, debug, torch, td, sfmba, sdist)
         q.put(dict(x=sdist.merge_solutions(xs, shards, pb.n_cameras, pb.n_points),
                    cams_equal=all(np.array_equal(xi[:6 * dims[0]], xs[0][:6 * dims[0]]) for xi in xs),
                    status=int(res.status), nfev=int(res.nfev), cost=float(res.cost), rmse=float(res.rmse),
-                   calls=ex.n_calls, direct_calls=direct_calls, link_active=link_active,
+                   calls=ex.n_calls, direct_calls=direct_calls, link_active=link_active, launches=int(launches),
                    again=float(np.abs(x2 - x).max())))
     be.close()
 
@@ -913,11 +915,11 @@ def test_direct_allreduce_over_peer_mapped_memory(dbg):
         assert abs(out["cost"] - ref.cost) <= 1e-10 * ref.cost
         assert np.abs(out["x"] - ref.x).max() <= 1e-6 * np.abs(ref.x).max()
     # other shapes: an odd camera count (scalar slots no longer 16-byte aligned), a far start with rejected steps
-    # (retries, speculative trials), and more cameras than a single-workgroup collective carries
-    # ... and more cameras than the LDS table of pass A holds (table in global memory, PCG update as a kernel of its own,
-    # the per-camera exchange inside pass B / K3 / the rhs pass as everywhere on the direct link)
-    for world, dims in ((3, (7, 500, 4000, 3, 0.01)), (2, (6, 80, 500, 5, 0.2)), (2, (300, 2000, 16000, 9, 0.01)),
-                        (2, (1300, 4000, 40000, 21, 0.01))):
+    # (retries, speculative trials), a hundred cameras, and sizes at which ranks that SHARE a device fall back to the
+    # collective launches by themselves (300 cameras; 1300: also more than the LDS table of pass A holds) -- waiting camera
+    # workgroups of one rank on every CU would keep the other rank's pass A from ever starting
+    for world, dims in ((3, (7, 500, 4000, 3, 0.01)), (2, (6, 80, 500, 5, 0.2)), (2, (100, 1500, 12000, 4, 0.01)),
+                        (3, (60, 900, 8000, 6, 0.01)), (2, (300, 2000, 16000, 9, 0.01)), (2, (1300, 4000, 40000, 21, 0.01))):
         pb = sfmba.make_problem(dims[0], dims[1], dims[2], seed=dims[3], x0_noise=dims[4])
         ref = sfmba.least_squares(sfmba.compute_residuals, pb.x0, x_scale="jac", ftol=1e-10, method="trf",
                                   args=pb.args)
@@ -927,21 +929,26 @@ def test_direct_allreduce_over_peer_mapped_memory(dbg):
         # between differently ordered sums; the path (nfev, cost, x) is not
         assert out["nfev"] == ref.nfev and (out["status"] == ref.status or {out["status"], ref.status} <= {2, 3, 4})
         assert abs(out["cost"] - ref.cost) <= 1e-9 * ref.cost
+        if dims[0] in (100, 300):
+            # the exchange really ran inside the producing kernels at 100 cameras (fewer launches than with the
+            # collectives as launches of their own, same result) and did not at 300
+            off = _run_ranks(world, direct=True, dims=dims, debug=(("pcg_inline", 0),))
+            assert off["nfev"] == out["nfev"] and abs(off["cost"] - out["cost"]) <= 1e-9 * out["cost"]
+            assert (out["launches"] < off["launches"]) == (dims[0] == 100), (out["launches"], off["launches"])
     # the form problems of more than 1100 cameras run -- pass A's table in global memory, the PCG update a kernel of its
-    # own -- WITH the per-camera exchange inside pass B (at its real size two ranks' camera workgroups do not fit one
-    # shared device, and DirectLink falls back to the collective launches: the 1300-camera case above); forced here at 300
-    # cameras through the test hooks, with fp64 and with fp32 operands
-    pb = sfmba.make_problem(300, 2000, 16000, seed=9)
+    # own -- WITH the per-camera exchange inside pass B / K3 / the rhs pass; forced at 100 cameras through the test hooks (the
+    # camera count at which two ranks on one device still take the in-kernel exchange), with fp64 and with fp32 operands
+    pb = sfmba.make_problem(100, 1500, 12000, seed=4)
     ref = sfmba.least_squares(sfmba.compute_residuals, pb.x0, x_scale="jac", ftol=1e-10, method="trf", args=pb.args)
     for extra in ((), (("pcg_mixed", 1),)):
-        out = _run_ranks(2, direct=True, dims=(300, 2000, 16000, 9, 0.01), debug=(("sweep_rc", 2), ("pcg_fused", 0)) + extra)
+        out = _run_ranks(2, direct=True, dims=(100, 1500, 12000, 4, 0.01), debug=(("sweep_rc", 2), ("pcg_fused", 0)) + extra)
         assert out["link_active"] and out["calls"] == 0 and out["cams_equal"] and out["again"] == 0.0
         assert out["nfev"] == ref.nfev and (out["status"] == ref.status or {out["status"], ref.status} <= {2, 3, 4})
         assert abs(out["cost"] - ref.cost) <= 1e-9 * ref.cost
     # Whether a camera's list is cut into several chunks is a property of a rank's SHARD, and the in-kernel exchange needs
     # single-chunk cameras: the ranks settle it at attach.  Rank 1 alone is given short chunks here -- every rank then
     # keeps the collective launches (ranks that decided each for itself would wait for each other in different kernels).
-    out = _run_ranks(2, direct=True, dims=(300, 2000, 16000, 9, 0.01), debug=(("cam_chunk", 16, 1),))
+    out = _run_ranks(2, direct=True, dims=(100, 1500, 12000, 4, 0.01), debug=(("cam_chunk", 16, 1),))
     assert out["link_active"] and out["calls"] == 0 and out["cams_equal"] and out["again"] == 0.0
     assert out["nfev"] == ref.nfev and abs(out["cost"] - ref.cost) <= 1e-9 * ref.cost
 

@@ -15,7 +15,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- pyt
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -- python3 $R/bench.py --no-cpu-baseline --no-per-call --steps 10 --warmup 5 --settle 0.1 > $OUT/${TAG}_pmc_fetch.json 2> $OUT/${TAG}_pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_write -- python3 $R/bench.py --no-cpu-baseline --no-per-call --steps 10 --warmup 5 --settle 0.1 > $OUT/${TAG}_pmc_write.json 2> $OUT/${TAG}_pmc_write.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats_cfg2 -- python3 $R/bench.py --workload cfg2 --no-cpu-baseline --no-per-call 2> $OUT/${TAG}_stats_cfg2.err | tail -1 > $OUT/${TAG}_bench_cfg2.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats_cfg5 -- python3 $R/tools/solve_loop.py cfg5 6 32 > $OUT/${TAG}_cfg5_f32_solve_loop.txt 2> $OUT/${TAG}_stats_cfg5.err
+# (SFMBA_HIP_RUNTIME=system: this tool does not import torch, and with the wheel's ROCm 7.0 runtime under the 7.2 tracer the
+# 24 MB copies of the trial point to its host mirror run as blit kernels beside K1 instead of on the SDMA engines -- K1 then
+# reads 750 us in the trace; untraced, and in bench.py with either runtime, they do not)
+SFMBA_HIP_RUNTIME=system rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats_cfg5 -- python3 $R/tools/solve_loop.py cfg5 6 32 > $OUT/${TAG}_cfg5_f32_solve_loop.txt 2> $OUT/${TAG}_stats_cfg5.err
 # what gates the residual+Jacobian kernel: SQ / TA counters, two passes per size, the kernel launched back to back
 for W in cfg4 cfg5; do
   B=64; [ $W = cfg5 ] && B=32
