@@ -231,6 +231,7 @@ def main():
             if a.exchange == "torch":
                 ex = sdist.Exchange(be, n_obs_local=Nl, device="cuda")
             link = None
+            link_dropped = False
             if (world > 1 or a.force_exchange) and not a.no_direct:
                 try:
                     link = sdist.DirectLink(be, allow_single=a.force_exchange)
@@ -279,7 +280,30 @@ def main():
             while time.perf_counter() - t_settle < a.settle:
                 run_iterations(5)
         else:                      # every solve is a sequence of collectives: all ranks must run the same number
-            for _ in range(int(round(a.settle * 100))):
+            # The first solves of a multi-rank run are also the first time the direct link carries real traffic between
+            # THESE devices (the attach self-test covers the collective launches, not the per-camera exchange inside the
+            # kernels).  Should a solve fail there on any rank (time-out of a peer: error -5), every rank drops the link
+            # and the run continues on the transport registered before it (RCCL / torch.distributed) instead of ending
+            # without a line; the line then says so in "transport".
+            try:
+                run_iterations(5)
+                ok = 1
+            except sfmba.BackendError as exc:
+                ok = 0
+                print(f"[bench] rank {rank}: first sharded solve failed ({exc})", file=sys.stderr, flush=True)
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if td.get_backend() == "nccl" else "cpu")
+            td.all_reduce(flag, op=td.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                if link is not None and link.active:
+                    link.close()
+                link = None
+                link_dropped = True
+                if rank == 0:
+                    print("[bench] direct link dropped on every rank after a failed solve; collectives use the "
+                          f"{a.exchange} transport", file=sys.stderr, flush=True)
+                td.barrier()
+                run_iterations(5)
+            for _ in range(max(0, int(round(a.settle * 100)) - 1)):
                 run_iterations(5)
         run_iterations(max(1, a.warmup))
         barrier()
@@ -365,7 +389,9 @@ def main():
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f64" if a.storage_bits == 64 else "f64 arithmetic, f32 storage", "data": "synthetic",
             "transport": None if td is None else (f"direct xGMI all-reduce kernel ({be.p2p_calls()} collectives; "
-                                                  f"fallback {a.exchange})" if be.p2p_calls() > 0 else a.exchange),
+                                                  f"fallback {a.exchange})" if (link is not None and link.active)
+                                                  else (f"{a.exchange} (direct link dropped after a failed first solve)"
+                                                        if link_dropped else a.exchange)),
             "value_is": "back-to-back solves from the same x0 (each replays the previous solve's PCG iteration record)",
             "first_solve_fresh_handle": first_solve,
             "j_free_iteration": j_free,
