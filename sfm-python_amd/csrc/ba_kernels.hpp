@@ -3617,7 +3617,7 @@ constexpr int kBacksubCols = 10;
 // find the solve finished -- alpha of the last iteration, x += alpha p, the control block -- is left out (8 us per outer
 // iteration) and every workgroup of this kernel forms alpha from pass B's partial dot products itself
 // (pcg_local_step: the same sums in the same order) while it stages the step into its LDS.  Workgroup 0 writes the
-// control block and the finished x exactly as that launch would have.  Should the solve NOT be finished (the record was
+// control block as that launch would have, and the finished x into the step vector.  Should the solve NOT be finished (the record was
 // too short), the control block says so, k_tr_step cancels the trial as for any short guess, this launch returns at once
 // and the host enqueues the owed pass A / pass B pair: nothing the pair reads has been touched.
 struct FinalUpdate {
@@ -3658,13 +3658,9 @@ __global__ __launch_bounds__(kSweepThreads) void k_backsub(
             for (int k = 0; k < 6; ++k) {
                 const double xk = add ? xe[k] + alpha * pe[k] : xe[k];
                 smem[6 * cam + k] = xk;
-                if (blockIdx.x == 0) {
-                    dc[6 * cam + k] = xk;
-                    if (add) {
-                        fu.vecs[kPcgX * n6 + (size_t)k * C + cam] = xk;
-                        fu.vecs[(size_t)kPcgVecs * n6 + kPcgX * n6 + (size_t)k * C + cam] = xk;
-                    }
-                }
+                // (the finished x goes to the step vector only: every workgroup of this launch reads x and p of the
+                // vector sets, so nobody may write them here; nothing reads x there before the next solve resets it)
+                if (blockIdx.x == 0) dc[6 * cam + k] = xk;
             }
         }
         __syncthreads();
