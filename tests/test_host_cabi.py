@@ -43,6 +43,7 @@ def test_one_hip_runtime_per_process_when_torch_is_installed():
     wrong order (the system's copy first), `torch.cuda` later finds no GPU in the process.  `_capi.load()` therefore loads
     torch's copy first when torch is installed -- here: a fresh interpreter that never imports torch ends up with exactly
     one libamdhip64 mapped, the wheel's; SFMBA_HIP_RUNTIME=system keeps the system's."""
+    import ast
     import importlib.util
     import subprocess
     import sys
@@ -57,7 +58,7 @@ def test_one_hip_runtime_per_process_when_torch_is_installed():
                              env={**os.environ, **env_extra})
         assert out.returncode == 0, out.stderr
         libs, torch_imported = out.stdout.strip().splitlines()[-2:]
-        libs = eval(libs)
+        libs = ast.literal_eval(libs)
         assert torch_imported == "False"                       # located, not imported
         assert len(libs) == 1, libs
         assert (os.sep + "torch" + os.sep in libs[0]) == want_torch_copy, libs
